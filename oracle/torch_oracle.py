@@ -1,0 +1,374 @@
+"""ORACLE (test infrastructure -- never imported by the product path).
+
+A CPU restatement, in stock fp32 torch ops, of the reference's cost-volume hot path.  Only
+tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; it is
+the *checker*, never the thing measured or shipped.
+
+Pinning: every function here is compared against the reference's own Python files (imported from
+/root/reference in the build container by tests/golden/make_golden.py) and the resulting
+input/output vectors are committed under tests/golden/*.npz; tests/test_oracle_golden.py replays
+them.  The reference ships no tests/golden vectors of its own for this path.
+
+Everything is *functional over a state-dict*: `sd` maps the reference's parameter names
+(`dres0.0.0.weight`, `dres2.conv5.1.running_var`, ...) to tensors, so the same dict can be loaded
+into the reference modules, into the product modules and evaluated here.
+
+Citations are relative to /root/reference/stereo_toolbox/models.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------- volume builders
+def groupwise_correlation(fea1, fea2, num_groups):
+    """GwcNet/submodule.py:44-50: per-group mean of channel products."""
+    B, C, H, W = fea1.shape
+    assert C % num_groups == 0
+    return (fea1 * fea2).view(B, num_groups, C // num_groups, H, W).mean(dim=2)
+
+
+def _shift_right(t, maxdisp):
+    """[B,C,H,W] -> [B,C,D,H,W] with out[..., d, h, w] = w>=d ? t[..., h, w-d] : 0 (gather form)."""
+    B, C, H, W = t.shape
+    w = torch.arange(W).view(1, W)
+    d = torch.arange(maxdisp).view(maxdisp, 1)
+    idx = (w - d).clamp(min=0)                     # [D, W]
+    valid = (w >= d).to(t.dtype)                   # [D, W]
+    g = t[:, :, :, idx]                            # [B,C,H,D,W]
+    g = g * valid.view(1, 1, 1, maxdisp, W)
+    return g.permute(0, 1, 3, 2, 4).contiguous(), valid
+
+
+def build_gwc_volume(ref, tgt, maxdisp, num_groups):
+    """GwcNet/submodule.py:53-63 (dup ACVNet/submodule.py:228-238)."""
+    B, C, H, W = ref.shape
+    assert C % num_groups == 0
+    cpg = C // num_groups
+    shifted, _ = _shift_right(tgt, maxdisp)                       # [B,C,D,H,W]
+    prod = ref.unsqueeze(2) * shifted
+    return prod.view(B, num_groups, cpg, maxdisp, H, W).mean(dim=2)
+
+
+def build_concat_volume(ref, tgt, maxdisp, mask_left=True):
+    """mask_left=True: GwcNet/submodule.py:30-41 and PSMNet/stackhourglass.py:111-120.
+    mask_left=False: ACVNet/submodule.py:180-191 (left feature copied to every column)."""
+    B, C, H, W = ref.shape
+    right, valid = _shift_right(tgt, maxdisp)
+    left = ref.unsqueeze(2).expand(B, C, maxdisp, H, W)
+    if mask_left:
+        left = left * valid.view(1, 1, maxdisp, 1, W)
+    return torch.cat((left, right), dim=1).contiguous()
+
+
+# ----------------------------------------------------------------------------- regression head
+def disparity_regression(x, maxdisp, keepdim=False):
+    """GwcNet/submodule.py:23-27 (keepdim=False); PSMNet/submodule.py:46-54 and
+    disparity_estimators/__init__.py:7-10 (keepdim=True)."""
+    assert x.dim() == 4
+    disp = torch.arange(maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+    return torch.sum(x * disp, 1, keepdim=keepdim)
+
+
+def argmax_disparity_estimator(x, maxdisp=192):
+    """disparity_estimators/__init__.py:13-15."""
+    return torch.argmax(x, 1, keepdim=True)
+
+
+def regression_head(cost, maxdisp, H, W, keepdim=False):
+    """upsample(trilinear) -> squeeze -> softmax(dim=1) -> disparity_regression
+    (GwcNet/gwcnet.py:219-224, PSMNet/stackhourglass.py:147-153, ACVNet/acv.py:247-251)."""
+    c = F.interpolate(cost, [maxdisp, H, W], mode="trilinear", align_corners=False)
+    c = torch.squeeze(c, 1)
+    p = F.softmax(c, dim=1)
+    return disparity_regression(p, maxdisp, keepdim=keepdim)
+
+
+# ----------------------------------------------------------------------------- conv/BN blocks
+class Ctx:
+    """Carries the state-dict, the train/eval flag and the BN running-stat updates."""
+
+    def __init__(self, sd, training=False):
+        self.sd = sd
+        self.training = training
+        self.new_stats = {}
+
+    def bn(self, x, prefix):
+        sd = self.sd
+        rm = sd[prefix + ".running_mean"].clone()
+        rv = sd[prefix + ".running_var"].clone()
+        y = F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], self.training, MOMENTUM, EPS)
+        if self.training:
+            self.new_stats[prefix + ".running_mean"] = rm
+            self.new_stats[prefix + ".running_var"] = rv
+        return y
+
+
+def convbn_3d(cx, x, prefix, stride=1, pad=1):
+    """GwcNet/submodule.py:17-20: Conv3d(bias=False) + BatchNorm3d; `prefix`.0 conv, `prefix`.1 BN."""
+    y = F.conv3d(x, cx.sd[prefix + ".0.weight"], None, stride, pad)
+    return cx.bn(y, prefix + ".1")
+
+
+def deconvbn_3d(cx, x, prefix):
+    """ConvTranspose3d(k3, s2, p1, op1, bias=False) + BatchNorm3d (GwcNet/gwcnet.py:84-90)."""
+    y = F.conv_transpose3d(x, cx.sd[prefix + ".0.weight"], None, stride=2, padding=1, output_padding=1)
+    return cx.bn(y, prefix + ".1")
+
+
+def convbn_2d(cx, x, prefix, stride, pad, dilation):
+    """GwcNet/submodule.py:11-14."""
+    y = F.conv2d(x, cx.sd[prefix + ".0.weight"], None, stride, dilation if dilation > 1 else pad, dilation)
+    return cx.bn(y, prefix + ".1")
+
+
+def dres0(cx, x, p="dres0"):
+    """GwcNet/gwcnet.py:124-127: 2 x (convbn_3d + ReLU)."""
+    x = F.relu(convbn_3d(cx, x, p + ".0"))
+    return F.relu(convbn_3d(cx, x, p + ".2"))
+
+
+def dres1(cx, x, p="dres1"):
+    """GwcNet/gwcnet.py:129-131: convbn_3d + ReLU + convbn_3d (residual added by the caller)."""
+    x = F.relu(convbn_3d(cx, x, p + ".0"))
+    return convbn_3d(cx, x, p + ".2")
+
+
+def classif(cx, x, p):
+    """GwcNet/gwcnet.py:139-153: convbn_3d + ReLU + Conv3d(32->1)."""
+    x = F.relu(convbn_3d(cx, x, p + ".0"))
+    return F.conv3d(x, cx.sd[p + ".2.weight"], None, 1, 1)
+
+
+def hourglass_gwc(cx, x, p, attention=None):
+    """GwcNet/gwcnet.py:68-105 (ACVNet/acv.py:56-93 adds `attention` after conv4)."""
+    c1 = F.relu(convbn_3d(cx, x, p + ".conv1.0", stride=2))
+    c2 = F.relu(convbn_3d(cx, c1, p + ".conv2.0"))
+    c3 = F.relu(convbn_3d(cx, c2, p + ".conv3.0", stride=2))
+    c4 = F.relu(convbn_3d(cx, c3, p + ".conv4.0"))
+    if attention is not None:
+        c4 = attention(cx, c4, p + ".attention_block")
+    c5 = F.relu(deconvbn_3d(cx, c4, p + ".conv5") + convbn_3d(cx, c2, p + ".redir2", pad=0))
+    c6 = F.relu(deconvbn_3d(cx, c5, p + ".conv6") + convbn_3d(cx, x, p + ".redir1", pad=0))
+    return c6
+
+
+def hourglass_psm(cx, x, presqu, postsqu, p):
+    """PSMNet/stackhourglass.py:10-50."""
+    out = F.relu(convbn_3d(cx, x, p + ".conv1.0", stride=2))
+    pre = convbn_3d(cx, out, p + ".conv2")
+    pre = F.relu(pre + postsqu) if postsqu is not None else F.relu(pre)
+    out = F.relu(convbn_3d(cx, pre, p + ".conv3.0", stride=2))
+    out = F.relu(convbn_3d(cx, out, p + ".conv4.0"))
+    if presqu is not None:
+        post = F.relu(deconvbn_3d(cx, out, p + ".conv5") + presqu)
+    else:
+        post = F.relu(deconvbn_3d(cx, out, p + ".conv5") + pre)
+    out = deconvbn_3d(cx, post, p + ".conv6")
+    return out, pre, post
+
+
+def attention_block(cx, x, p, num_heads=16, block=(4, 4, 4)):
+    """ACVNet/submodule.py:383-429 (windowed 3-D self attention)."""
+    sd = cx.sd
+    B, C, D, H0, W0 = x.shape
+    pad_r = (block[2] - W0 % block[2]) % block[2]
+    pad_b = (block[1] - H0 % block[1]) % block[1]
+    x = F.pad(x, (0, pad_r, 0, pad_b))
+    B, C, D, H, W = x.shape
+    d, h, w = D // block[0], H // block[1], W // block[2]
+    x = x.view(B, C, d, block[0], h, block[1], w, block[2]).permute(0, 2, 4, 6, 3, 5, 7, 1)
+    qkv = F.linear(x, sd[p + ".qkv_3d.weight"], sd[p + ".qkv_3d.bias"])
+    nb = block[0] * block[1] * block[2]
+    qkv = qkv.reshape(B, d * h * w, nb, 3, num_heads, C // num_heads).permute(3, 0, 1, 4, 2, 5)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * ((C // num_heads) ** -0.5)
+    if pad_r > 0 or pad_b > 0:
+        mask = torch.zeros((1, H, W), device=x.device)
+        mask[:, -pad_b:, :].fill_(1)
+        mask[:, :, -pad_r:].fill_(1)
+        mask = mask.reshape(1, h, block[1], w, block[2]).transpose(2, 3).reshape(1, h * w, block[1] * block[2])
+        am = mask.unsqueeze(2) - mask.unsqueeze(3)
+        am = am.masked_fill(am != 0, float(-1000.0)).masked_fill(am == 0, float(0.0))
+        attn = attn + am.repeat(1, d, block[0], block[0]).unsqueeze(2)
+    attn = torch.softmax(attn, dim=-1)
+    x = (attn @ v).view(B, d, h, w, num_heads, block[0], block[1], block[2], -1).permute(0, 4, 8, 1, 5, 2, 6, 3, 7)
+    x = x.reshape(B, C, D, H, W)
+    if pad_r > 0 or pad_b > 0:
+        x = x[:, :, :, :H0, :W0]
+    return F.conv3d(x, sd[p + ".final1x1.weight"], sd[p + ".final1x1.bias"])
+
+
+# ----------------------------------------------------------------------------- 2-D feature CNNs
+def _basic_block(cx, x, p, stride, pad, dilation, has_down):
+    out = F.relu(convbn_2d(cx, x, p + ".conv1.0", stride, pad, dilation))
+    out = convbn_2d(cx, out, p + ".conv2", 1, pad, dilation)
+    if has_down:
+        x = convbn_2d(cx, x, p + ".downsample", stride, 0, 1)
+    return out + x
+
+
+def _trunk(cx, x, p):
+    """firstconv + layer1..4 shared by the three models (GwcNet/gwcnet.py:17-58)."""
+    x = F.relu(convbn_2d(cx, x, p + ".firstconv.0", 2, 1, 1))
+    x = F.relu(convbn_2d(cx, x, p + ".firstconv.2", 1, 1, 1))
+    x = F.relu(convbn_2d(cx, x, p + ".firstconv.4", 1, 1, 1))
+    for i in range(3):
+        x = _basic_block(cx, x, f"{p}.layer1.{i}", 1, 1, 1, False)
+    l2 = x
+    for i in range(16):
+        l2 = _basic_block(cx, l2, f"{p}.layer2.{i}", 2 if i == 0 else 1, 1, 1, i == 0)
+    l3 = l2
+    for i in range(3):
+        l3 = _basic_block(cx, l3, f"{p}.layer3.{i}", 1, 1, 1, i == 0)
+    l4 = l3
+    for i in range(3):
+        l4 = _basic_block(cx, l4, f"{p}.layer4.{i}", 1, 1, 2, False)
+    return l2, l3, l4
+
+
+def features_gwc(cx, x, concat, p="feature_extraction"):
+    """GwcNet/gwcnet.py:12-65."""
+    l2, l3, l4 = _trunk(cx, x, p)
+    gwc = torch.cat((l2, l3, l4), dim=1)
+    if not concat:
+        return gwc, None
+    c = F.relu(convbn_2d(cx, gwc, p + ".lastconv.0", 1, 1, 1))
+    c = F.conv2d(c, cx.sd[p + ".lastconv.2.weight"])
+    return gwc, c
+
+
+def features_psm(cx, x, p="feature_extraction"):
+    """PSMNet/submodule.py:57-132 (SPP)."""
+    l2, l3, l4 = _trunk(cx, x, p)
+    size = (l4.shape[2], l4.shape[3])
+    branches = []
+    for name, k in (("branch1", 64), ("branch2", 32), ("branch3", 16), ("branch4", 8)):
+        b = F.avg_pool2d(l4, (k, k), stride=(k, k))
+        b = F.relu(convbn_2d(cx, b, f"{p}.{name}.1", 1, 0, 1))
+        branches.append(F.interpolate(b, size, mode="bilinear", align_corners=False))
+    feat = torch.cat((l2, l4, branches[3], branches[2], branches[1], branches[0]), 1)
+    f = F.relu(convbn_2d(cx, feat, p + ".lastconv.0", 1, 1, 1))
+    return F.conv2d(f, cx.sd[p + ".lastconv.2.weight"])
+
+
+# ----------------------------------------------------------------------------- whole models
+def gwcnet_forward(sd, left, right, maxdisp, use_concat_volume, training=False, return_ctx=False):
+    """GwcNet/gwcnet.py:171-224."""
+    cx = Ctx(sd, training)
+    gl, cl = features_gwc(cx, left, use_concat_volume)
+    gr, cr = features_gwc(cx, right, use_concat_volume)
+    vol = build_gwc_volume(gl, gr, maxdisp // 4, 40)
+    if use_concat_volume:
+        vol = torch.cat((vol, build_concat_volume(cl, cr, maxdisp // 4)), 1)
+    cost0 = dres0(cx, vol)
+    cost0 = dres1(cx, cost0) + cost0
+    out1 = hourglass_gwc(cx, cost0, "dres2")
+    out2 = hourglass_gwc(cx, out1, "dres3")
+    out3 = hourglass_gwc(cx, out2, "dres4")
+    H, W = left.shape[2], left.shape[3]
+    if training:
+        preds = [regression_head(classif(cx, o, f"classif{i}"), maxdisp, H, W)
+                 for i, o in enumerate((cost0, out1, out2, out3))]
+        return (preds, cx) if return_ctx else preds
+    pred = regression_head(classif(cx, out3, "classif3"), maxdisp, H, W)
+    return (pred, cx) if return_ctx else pred
+
+
+def psmnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):
+    """PSMNet/stackhourglass.py:103-161."""
+    cx = Ctx(sd, training)
+    fl = features_psm(cx, left)
+    fr = features_psm(cx, right)
+    cost = build_concat_volume(fl, fr, maxdisp // 4)
+    cost0 = dres0(cx, cost)
+    cost0 = dres1(cx, cost0) + cost0
+    out1, pre1, post1 = hourglass_psm(cx, cost0, None, None, "dres2")
+    out1 = out1 + cost0
+    out2, pre2, post2 = hourglass_psm(cx, out1, pre1, post1, "dres3")
+    out2 = out2 + cost0
+    out3, pre3, post3 = hourglass_psm(cx, out2, pre1, post2, "dres4")
+    out3 = out3 + cost0
+    cost1 = classif(cx, out1, "classif1")
+    cost2 = classif(cx, out2, "classif2") + cost1
+    cost3 = classif(cx, out3, "classif3") + cost2
+    H, W = left.shape[2], left.shape[3]
+    pred3 = regression_head(cost3, maxdisp, H, W, keepdim=True)
+    if training:
+        pred1 = regression_head(cost1, maxdisp, H, W, keepdim=True)
+        pred2 = regression_head(cost2, maxdisp, H, W, keepdim=True)
+        out = [pred1, pred2, pred3]
+        return (out, cx) if return_ctx else out
+    return (pred3, cx) if return_ctx else pred3
+
+
+def acv_patch_volume(sd, gwc_volume):
+    """ACVNet/acv.py:109-112,183-187: depth-wise (1,3,3) convs, dilations 1 / 1,2,3."""
+    v = F.conv3d(gwc_volume, sd["patch.weight"], None, 1, (0, 1, 1), 1, 40)
+    p1 = F.conv3d(v[:, :8], sd["patch_l1.weight"], None, 1, (0, 1, 1), 1, 8)
+    p2 = F.conv3d(v[:, 8:24], sd["patch_l2.weight"], None, 1, (0, 2, 2), 2, 16)
+    p3 = F.conv3d(v[:, 24:40], sd["patch_l3.weight"], None, 1, (0, 3, 3), 3, 16)
+    return torch.cat((p1, p2, p3), dim=1)
+
+
+def acvnet_forward(sd, left, right, maxdisp, attn_weights_only=False, freeze_attn_weights=False,
+                   training=False, return_ctx=False):
+    """ACVNet/acv.py:162-253."""
+    cx = Ctx(sd, training)
+    H, W = left.shape[2], left.shape[3]
+
+    def att_branch():
+        gl, _ = features_gwc(cx, left, False)
+        gr, _ = features_gwc(cx, right, False)
+        gwc = build_gwc_volume(gl, gr, maxdisp // 4, 40)
+        pv = acv_patch_volume(sd, gwc)
+        ca = dres1(cx, pv, "dres1_att_")
+        ca = hourglass_gwc(cx, ca, "dres2_att_", attention=attention_block)
+        return gl, gr, classif(cx, ca, "classif_att_")
+
+    if freeze_attn_weights:
+        with torch.no_grad():
+            gl, gr, att = att_branch()
+    else:
+        gl, gr, att = att_branch()
+
+    if not attn_weights_only:
+        def concatconv(g):
+            c = F.relu(convbn_2d(cx, g, "concatconv.0", 1, 1, 1))
+            return F.conv2d(c, sd["concatconv.2.weight"])
+        cvol = build_concat_volume(concatconv(gl), concatconv(gr), maxdisp // 4, mask_left=False)
+        ac = F.softmax(att, dim=2) * cvol
+        cost0 = dres0(cx, ac)
+        cost0 = dres1(cx, cost0) + cost0
+        out1 = hourglass_gwc(cx, cost0, "dres2", attention=attention_block)
+        out2 = hourglass_gwc(cx, out1, "dres3", attention=attention_block)
+
+    if training:
+        preds = []
+        if not freeze_attn_weights:
+            preds.append(regression_head(att, maxdisp, H, W))
+        if not attn_weights_only:
+            preds += [regression_head(classif(cx, o, f"classif{i}"), maxdisp, H, W)
+                      for i, o in enumerate((cost0, out1, out2))]
+        return (preds, cx) if return_ctx else preds
+    if attn_weights_only:
+        pred = regression_head(att, maxdisp, H, W)
+    else:
+        pred = regression_head(classif(cx, out2, "classif2"), maxdisp, H, W)
+    return (pred, cx) if return_ctx else pred
+
+
+# ----------------------------------------------------------------------------- loss used by bench/tests
+def smooth_l1_multi(preds, gt, maxdisp, weights):
+    """Supervised loss for the train step (the reference ships none for these models; weights
+    follow the GwcNet paper).  Valid mask: trainer/trainer_torchrun.py:272."""
+    mask = (gt > 0) & (gt < maxdisp - 1)
+    loss = 0.0
+    for p, w in zip(preds, weights):
+        p = p.squeeze(1) if p.dim() == 4 else p
+        loss = loss + w * F.smooth_l1_loss(p[mask], gt[mask], reduction="mean")
+    return loss

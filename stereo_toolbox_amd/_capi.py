@@ -1,0 +1,101 @@
+"""ctypes binding of the C-ABI declared in include/stx_hip.h.
+
+The product path loads exactly one library: the in-tree gfx950 build
+`stereo_toolbox_amd/lib/libstx_hip.so`.  There is no CPU fallback: if the library is missing or a
+tensor is not on a ROCm device the call raises.  (tests/ may instantiate `StxLib` on the host
+emulator build of the same sources to check index math without a GPU -- see tests/hipemu.)
+"""
+import ctypes
+import os
+import threading
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_L = ctypes.c_longlong
+
+# name -> argtypes (every entry point returns int: 0 ok, else see stx_last_error()).
+SIGNATURES = {
+    # cost_volume.hip
+    "stx_cost_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "stx_cost_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    # head.hip
+    "stx_head_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_head_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_softargmax_fwd": [_P, _P, _I, _I, _I, _P],
+    "stx_argmax_fwd": [_P, _P, _I, _I, _I, _P],
+    "stx_softmax_d_fwd": [_P, _P, _I, _I, _I, _P],
+    # conv3d.hip
+    "stx_conv3d_pack_weight": [_P, _P, _I, _I, _I, _I, _P],
+    "stx_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_conv3d_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    # bn.hip
+    "stx_bn_stats": [_P, _P, _L, _I, _P],
+    "stx_bn_finalize": [_P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
+    "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+}
+_RET_CHARP = ("stx_last_error", "stx_build_info")
+
+
+class StxError(RuntimeError):
+    pass
+
+
+class StxLib:
+    """Thin typed handle over one shared object exporting the stx_* C-ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise StxError(
+                f"HIP library not found: {path}. Build it with `python -m stereo_toolbox_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback for the cost-volume hot path.")
+        self.path = path
+        self._dll = ctypes.CDLL(path)
+        for name in _RET_CHARP:
+            fn = getattr(self._dll, name)
+            fn.restype = ctypes.c_char_p
+            fn.argtypes = []
+        self._fns = {}
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(self._dll, name, None)
+            if fn is None:
+                continue
+            fn.restype = ctypes.c_longlong if name.endswith("_bytes") else _I
+            fn.argtypes = argtypes
+            self._fns[name] = fn
+
+    def has(self, name):
+        return name in self._fns
+
+    def build_info(self):
+        return self._dll.stx_build_info().decode()
+
+    def raw(self, name):
+        return self._fns[name]
+
+    def call(self, name, *args):
+        fn = self._fns.get(name)
+        if fn is None:
+            raise StxError(f"{self.path} does not export {name}")
+        rc = fn(*args)
+        if rc != 0:
+            raise StxError(f"{name} failed ({rc}): {self._dll.stx_last_error().decode()}")
+
+
+_LIB = None
+_LOCK = threading.Lock()
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstx_hip.so")
+
+
+def get_lib():
+    """The gfx950 library (loaded once per process). Raises StxError if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        with _LOCK:
+            if _LIB is None:
+                _LIB = StxLib(LIB_PATH)
+    return _LIB

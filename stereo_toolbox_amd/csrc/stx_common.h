@@ -1,0 +1,38 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of the cost-volume hot path.
+//
+// Every kernel in this directory is written for MI355X only: 64-lane wavefronts,
+// 160 KiB LDS per CU, fp32-input MFMA (v_mfma_f32_32x32x2_f32).  The STX_HIPEMU
+// branch below is NOT a second backend: it is the hook through which tests/hipemu
+// compiles these same sources for the host so that index math can be checked in a
+// GPU-less container (see tests/hipemu/hipemu.h).  The product loads only the
+// gfx950 shared object.
+#pragma once
+#ifdef STX_HIPEMU
+#include "hipemu.h"
+#define STX_DYN_SMEM(name) char* name = hipemu::dyn_smem()
+#else
+#include <hip/hip_runtime.h>
+#define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define STX_OK 0
+#define STX_ERR_ARG 1
+#define STX_ERR_LAUNCH 2
+
+// Records the message returned by stx_last_error() (thread local) and returns `code`.
+int stx_set_error(int code, const char* fmt, ...);
+int stx_check_launch(const char* what);
+
+#define STX_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return stx_set_error(STX_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+static inline int stx_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float4 stx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -1,0 +1,38 @@
+"""Helpers to drive the host-emulator build of the HIP kernels from CPU tensors (tests only)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+
+_EMU = None
+
+
+def emu_lib():
+    global _EMU
+    if _EMU is None:
+        from build_emu import build_emu
+        from stereo_toolbox_amd._capi import StxLib
+        _EMU = StxLib(build_emu())
+    return _EMU
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last_3d), "non-dense tensor"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ndhwc(t):
+    """[B,C,D,H,W] -> dense [B,D,H,W,C] copy."""
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncdhw(t):
+    """dense [B,D,H,W,C] -> [B,C,D,H,W] contiguous copy."""
+    return t.permute(0, 4, 1, 2, 3).contiguous()

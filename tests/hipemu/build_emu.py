@@ -1,0 +1,48 @@
+"""Compiles stereo_toolbox_amd/csrc/*.hip for the HOST with the SIMT emulator (tests only).
+
+Output: tests/hipemu/_build/libstx_emu.so with the same C-ABI as the gfx950 library, so the
+CPU test-suite can drive the very same kernel sources through ctypes on numpy/torch-CPU buffers.
+"""
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "stereo_toolbox_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libstx_emu.so")
+CXX = os.environ.get("STX_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DSTX_HIPEMU", "-ffp-contract=off",
+         "-Wno-unused-value", "-Wno-deprecated-declarations", "-I", HERE, "-I", CSRC]
+
+
+def build_emu(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    deps = [os.path.join(HERE, "hipemu.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(OUT, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        newest = max(os.path.getmtime(p) for p in [s] + deps)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < newest:
+            jobs.append([CXX, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[emu build]", cmd[-3], flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("emu compile failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=8) as ex:
+            list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([CXX, "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_emu(verbose=True))

@@ -21,22 +21,25 @@ SIGNATURES = {
     "stx_cost_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # head.hip
     "stx_head_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "stx_head_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_head_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_softargmax_fwd": [_P, _P, _I, _I, _I, _P],
     "stx_argmax_fwd": [_P, _P, _I, _I, _I, _P],
     "stx_softmax_d_fwd": [_P, _P, _I, _I, _I, _P],
     # conv3d.hip
+    "stx_conv3d_packed_floats": [_I, _I, _I],
     "stx_conv3d_pack_weight": [_P, _P, _I, _I, _I, _I, _P],
-    "stx_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "stx_conv3d_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "stx_conv3d_fwd_blocks": [_I, _I, _I],
+    "stx_deconv3d_fwd_blocks": [_I, _I, _I],
+    "stx_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_conv3d_wgrad_workspace_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     # bn.hip
-    "stx_bn_stats": [_P, _P, _L, _I, _P],
-    "stx_bn_finalize": [_P, _L, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P],
+    "stx_bn_reduce_blocks": [],
+    "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
 }
 _RET_CHARP = ("stx_last_error", "stx_build_info")
 
@@ -64,7 +67,7 @@ class StxLib:
             fn = getattr(self._dll, name, None)
             if fn is None:
                 continue
-            fn.restype = ctypes.c_longlong if name.endswith("_bytes") else _I
+            fn.restype = ctypes.c_longlong if name.endswith("_floats") else _I
             fn.argtypes = argtypes
             self._fns[name] = fn
 

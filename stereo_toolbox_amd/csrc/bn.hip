@@ -1,0 +1,251 @@
+// Train-mode BatchNorm3d around the MFMA convolutions, for gfx950 (channels-last activations).
+//
+// Replaces the nn.BatchNorm3d half of convbn_3d (reference models/GwcNet/submodule.py:17-20 and
+// twins) plus the ReLU / residual adds that follow it (GwcNet/gwcnet.py:96-103,185;
+// PSMNet/stackhourglass.py:31-48,123-132) when the module is in train() mode, and their backward.
+// (In eval() mode BN is folded into the convolution epilogue and none of this runs.)
+//
+//   forward : conv epilogue emits per-workgroup (sum z, sum z^2) partials  -> stx_bn_finalize
+//             (fp64 reduction; mean/var -> scale=gamma*invstd, shift=beta-mean*scale; running
+//             stats updated with momentum and the unbiased variance, as torch does)
+//             -> stx_bn_apply: y = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + residual])
+//   backward: stx_bn_bwd_reduce: sums of g, g*xhat1, g*xhat2 with g = gy*[y>0]
+//             stx_bn_bwd_apply : dz_k = gamma_k*invstd_k*(g - mean(g) - xhat_k*mean(g*xhat_k))
+// All kernels are HBM-bound streaming passes (16-B accesses, one float4 channel quad per lane).
+#include "stx_common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_RED_BLOCKS = 1024;
+
+// out[m] = sum_r partials[r][m]  (fp64 accumulate), one workgroup per column m.
+__device__ __forceinline__ double bn_block_sum(double v, double* red, int tid) {
+    red[tid] = v;
+    __syncthreads();
+    for (int s = BN_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
+    const float* __restrict__ partials, int nrows, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+    float* __restrict__ invstd_out) {
+    __shared__ double red[BN_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = tid; r < nrows; r += BN_THREADS) {
+        s1 += (double)partials[(size_t)r * 2 * C + c];
+        s2 += (double)partials[(size_t)r * 2 * C + C + c];
+    }
+    s1 = bn_block_sum(s1, red, tid);
+    s2 = bn_block_sum(s2, red, tid);
+    if (tid == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = bt - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(
+    const float* __restrict__ z1, const float* __restrict__ scale1, const float* __restrict__ shift1,
+    const float* __restrict__ z2, const float* __restrict__ scale2, const float* __restrict__ shift2,
+    float* __restrict__ out, size_t nquads, int CQ, int relu) {
+    for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * BN_THREADS) {
+        const int cq = (int)(i % CQ) * 4;
+        float4 v = stx_ld4(z1 + i * 4);
+        const float4 a = stx_ld4(scale1 + cq), b = stx_ld4(shift1 + cq);
+        v.x = fmaf(v.x, a.x, b.x); v.y = fmaf(v.y, a.y, b.y); v.z = fmaf(v.z, a.z, b.z); v.w = fmaf(v.w, a.w, b.w);
+        if (z2) {
+            float4 u = stx_ld4(z2 + i * 4);
+            if (scale2) {
+                const float4 a2 = stx_ld4(scale2 + cq), b2 = stx_ld4(shift2 + cq);
+                u.x = fmaf(u.x, a2.x, b2.x); u.y = fmaf(u.y, a2.y, b2.y);
+                u.z = fmaf(u.z, a2.z, b2.z); u.w = fmaf(u.w, a2.w, b2.w);
+            }
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        if (relu) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
+        stx_st4(out + i * 4, v);
+    }
+}
+
+// partial[blk][0..2][C] = sum g, sum g*xhat1, sum g*xhat2 over the workgroup's voxels.
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
+    const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ z1,
+    const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ z2,
+    const float* __restrict__ mean2, const float* __restrict__ invstd2, float* __restrict__ partials,
+    size_t nvox, int C, int relu) {
+    __shared__ float red[BN_THREADS * 12];
+    const int tid = threadIdx.x;
+    const int CQ = C >> 2;
+    const int cq = tid % CQ, vl = tid / CQ, VPB = BN_THREADS / CQ;
+    const float4 m1 = stx_ld4(mean1 + 4 * cq), i1 = stx_ld4(invstd1 + 4 * cq);
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f), i2 = m2;
+    const bool has2 = z2 && mean2;
+    if (has2) { m2 = stx_ld4(mean2 + 4 * cq); i2 = stx_ld4(invstd2 + 4 * cq); }
+    float s[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s[k] = 0.f;
+    for (size_t v = (size_t)blockIdx.x * VPB + vl; v < nvox; v += (size_t)gridDim.x * VPB) {
+        const size_t o = v * C + 4 * cq;
+        float4 g = stx_ld4(gy + o);
+        if (relu) {
+            const float4 yy = stx_ld4(y + o);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        const float4 a = stx_ld4(z1 + o);
+        s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
+        s[4] = fmaf(g.x, (a.x - m1.x) * i1.x, s[4]); s[5] = fmaf(g.y, (a.y - m1.y) * i1.y, s[5]);
+        s[6] = fmaf(g.z, (a.z - m1.z) * i1.z, s[6]); s[7] = fmaf(g.w, (a.w - m1.w) * i1.w, s[7]);
+        if (has2) {
+            const float4 c = stx_ld4(z2 + o);
+            s[8] = fmaf(g.x, (c.x - m2.x) * i2.x, s[8]); s[9] = fmaf(g.y, (c.y - m2.y) * i2.y, s[9]);
+            s[10] = fmaf(g.z, (c.z - m2.z) * i2.z, s[10]); s[11] = fmaf(g.w, (c.w - m2.w) * i2.w, s[11]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) red[k * BN_THREADS + tid] = s[k];
+    __syncthreads();
+    // threads with the same cq differ by multiples of CQ
+    for (int idx = tid; idx < 12 * CQ; idx += BN_THREADS) {
+        const int k = idx / CQ, q = idx % CQ;
+        float t = 0.f;
+        for (int j = q; j < BN_THREADS; j += CQ) t += red[k * BN_THREADS + j];
+        // k = which*4 + component
+        partials[((size_t)blockIdx.x * 3 + (k >> 2)) * C + 4 * q + (k & 3)] = t;
+    }
+}
+
+// sums[m] = sum over rows of partials[r][m], fp64 accumulate; one workgroup per column.
+__global__ __launch_bounds__(BN_THREADS) void bn_colsum_kernel(const float* __restrict__ partials, int nrows, int M,
+                                                               float* __restrict__ sums) {
+    __shared__ double red[BN_THREADS];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int r = tid; r < nrows; r += BN_THREADS) s += (double)partials[(size_t)r * M + m];
+    s = bn_block_sum(s, red, tid);
+    if (tid == 0) sums[m] = (float)s;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
+    const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ z1,
+    const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ gamma1,
+    const float* __restrict__ z2, const float* __restrict__ mean2, const float* __restrict__ invstd2,
+    const float* __restrict__ gamma2, const float* __restrict__ sums, float* __restrict__ dz1,
+    float* __restrict__ dz2, float* __restrict__ gout, size_t nquads, int C, int relu, float inv_n) {
+    const int CQ = C >> 2;
+    const bool has2 = z2 && mean2 && dz2;
+    for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * BN_THREADS) {
+        const int c = (int)(i % CQ) * 4;
+        float4 g = stx_ld4(gy + i * 4);
+        if (relu) {
+            const float4 yy = stx_ld4(y + i * 4);
+            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        if (gout) stx_st4(gout + i * 4, g);
+        const float4 sg = stx_ld4(sums + c);
+        {
+            const float4 a = stx_ld4(z1 + i * 4), m = stx_ld4(mean1 + c), is = stx_ld4(invstd1 + c);
+            const float4 gm = gamma1 ? stx_ld4(gamma1 + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sx = stx_ld4(sums + C + c);
+            float4 d;
+            d.x = gm.x * is.x * (g.x - sg.x * inv_n - (a.x - m.x) * is.x * sx.x * inv_n);
+            d.y = gm.y * is.y * (g.y - sg.y * inv_n - (a.y - m.y) * is.y * sx.y * inv_n);
+            d.z = gm.z * is.z * (g.z - sg.z * inv_n - (a.z - m.z) * is.z * sx.z * inv_n);
+            d.w = gm.w * is.w * (g.w - sg.w * inv_n - (a.w - m.w) * is.w * sx.w * inv_n);
+            stx_st4(dz1 + i * 4, d);
+        }
+        if (has2) {
+            const float4 a = stx_ld4(z2 + i * 4), m = stx_ld4(mean2 + c), is = stx_ld4(invstd2 + c);
+            const float4 gm = gamma2 ? stx_ld4(gamma2 + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sx = stx_ld4(sums + 2 * C + c);
+            float4 d;
+            d.x = gm.x * is.x * (g.x - sg.x * inv_n - (a.x - m.x) * is.x * sx.x * inv_n);
+            d.y = gm.y * is.y * (g.y - sg.y * inv_n - (a.y - m.y) * is.y * sx.y * inv_n);
+            d.z = gm.z * is.z * (g.z - sg.z * inv_n - (a.z - m.z) * is.z * sx.z * inv_n);
+            d.w = gm.w * is.w * (g.w - sg.w * inv_n - (a.w - m.w) * is.w * sx.w * inv_n);
+            stx_st4(dz2 + i * 4, d);
+        }
+    }
+}
+
+int bn_grid(size_t nquads) {
+    size_t g = (nquads + BN_THREADS - 1) / BN_THREADS;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int stx_bn_reduce_blocks(void) { return BN_RED_BLOCKS; }
+
+extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    return stx_check_launch("bn_finalize");
+}
+
+extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2,
+                            const float* scale2, const float* shift2, float* out, long long nvox, int C, int relu,
+                            void* stream) {
+    STX_REQUIRE(z1 && scale1 && shift1 && out && nvox > 0 && C > 0 && C % 4 == 0, "bn_apply: bad args (C=%d)", C);
+    STX_REQUIRE(!scale2 || (z2 && shift2), "bn_apply: second affine needs z2 and shift2");
+    const size_t nquads = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, z1, scale1,
+                       shift1, z2, scale2, shift2, out, nquads, C / 4, relu);
+    return stx_check_launch("bn_apply");
+}
+
+extern "C" int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1,
+                                 const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
+                                 float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
+    STX_REQUIRE(gy && z1 && mean1 && invstd1 && partials && sums && nvox > 0, "bn_bwd_reduce: null operand");
+    STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
+    STX_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_RED_BLOCKS), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
+                       z2, mean2, invstd2, partials, (size_t)nvox, C, relu);
+    int rc = stx_check_launch("bn_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, BN_RED_BLOCKS, 3 * C, sums);
+    return stx_check_launch("bn_colsum");
+}
+
+extern "C" int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const float* mean1,
+                                const float* invstd1, const float* gamma1, const float* z2, const float* mean2,
+                                const float* invstd2, const float* gamma2, const float* sums, float* dz1, float* dz2,
+                                float* gout, long long nvox, int C, int relu, void* stream) {
+    STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
+    STX_REQUIRE(!relu || y, "bn_bwd_apply: relu mask needs y");
+    const size_t nquads = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
+                       mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, sums, dz1, dz2, gout, nquads, C, relu,
+                       (float)(1.0 / (double)nvox));
+    return stx_check_launch("bn_bwd_apply");
+}

@@ -1,0 +1,632 @@
+// Conv3d / ConvTranspose3d aggregation for gfx950 as implicit GEMM on the fp32-input matrix
+// cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157.3 TFLOP/s chip peak).
+//
+// Replaces the nn.Conv3d / nn.ConvTranspose3d (+BatchNorm3d, ReLU, residual add) stacks of
+// (reference, /root/reference/stereo_toolbox/models):
+//   convbn_3d                         GwcNet/submodule.py:17-20, PSMNet/submodule.py:16-19,
+//                                     ACVNet/submodule.py:94-97
+//   dres0/dres1/classifN              GwcNet/gwcnet.py:124-153, PSMNet/stackhourglass.py:59-84,
+//                                     ACVNet/acv.py:114-144
+//   hourglass (conv1-6, redir1/2)     GwcNet/gwcnet.py:68-105, PSMNet/stackhourglass.py:10-50,
+//                                     ACVNet/acv.py:56-93
+// and their autograd backward (dgrad = the same two kernels on re-packed weights, wgrad below).
+//
+// Layout.  Activations are channels-last: [B][D][H][W][C] fp32, so C is the contiguous GEMM-K
+// axis and one voxel of 32 channels is one 128-B line.  GEMM view of a layer:
+//   M = output voxels (one MFMA row block = 32 consecutive output columns w),
+//   N = Cout (32 per MFMA column block), K = taps x Cin.
+// A workgroup (4 waves) stages the input halo tile of its TD x TH x 32 output voxels into LDS
+// once per 32-channel K-chunk with coalesced 16-B loads ([voxel][CK+4] dwords: the +4 pad makes
+// the operand reads -- ds_read_b128, lane = voxel -- bank-conflict free, guide 6/G4); every tap
+// then reads its A operand from that tile.  The B operand (weights) is pre-packed on the device
+// into exactly the per-lane MFMA order (stx_conv3d_pack_weight), so a wave fetches 1 KiB of
+// contiguous, L2-resident weights per four MFMAs.  fp32 MFMA issues once per 64 cycles per SIMD,
+// so one 16-B operand read feeds 256 cycles of matrix work: the kernels are MFMA-bound, not
+// LDS- or HBM-bound (arithmetic intensity of a 32->32 layer = 216 FLOP/B).
+//
+// Epilogue (fused): optional per-channel affine (folded eval-mode BN), residual add, ReLU, and
+// per-workgroup sum / sum-of-squares partials of the raw conv output for train-mode BatchNorm
+// statistics (finalised by stx_bn_finalize; deterministic, no atomics).
+#include "stx_common.h"
+
+namespace {
+
+constexpr int CONV_THREADS = 256;
+
+struct ConvArgs {
+    const float* x;         // [B][Di][Hi][Wi][Cin]
+    const float* wp;        // packed weights
+    float* out;             // [B][Do][Ho][Wo][Cout]
+    const float* scale;     // [Cout] or null
+    const float* bias;      // [Cout] or null
+    const float* residual;  // like out, or null
+    float* stats;           // [nblocks][2][Cout] partial sums of raw output, or null
+    int Di, Hi, Wi, Cin;
+    int Do, Ho, Wo, Cout;
+    int relu;
+    int nDt, nHt, nWt;
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// Fused epilogue for one 32x32 accumulator block. `vox` = linear output voxel index of row 0 of
+// the block (rows are consecutive voxels when `rstride`==1), nrows_valid = rows that exist.
+__device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32x16& acc, size_t vox0, int rstride,
+                                                    int nvalid_rows, int n, float sc, float bs, int lane,
+                                                    float& s1, float& s2) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < nvalid_rows && n < a.Cout) {
+            const size_t idx = (vox0 + (size_t)row * rstride) * a.Cout + n;
+            float v = acc[r];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+            v = fmaf(v, sc, bs);
+            if (a.residual) v += a.residual[idx];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out[idx] = v;
+        }
+    }
+}
+
+// Reduce per-lane stats (channel = lane&31 within column block nt) over the workgroup and write
+// the partial slab row.  `red` = LDS scratch of 4*NT*32*2 floats.
+template <int NT>
+__device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[NT], float (&s2)[NT], float* red,
+                                                 int tid, size_t slab) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] += __shfl_xor(s1[nt], 32);
+        s2[nt] += __shfl_xor(s2[nt], 32);
+    }
+    __syncthreads();   // LDS tile no longer read by anyone
+    if (lane < 32) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            red[((wave * NT + nt) * 32 + lane) * 2 + 0] = s1[nt];
+            red[((wave * NT + nt) * 32 + lane) * 2 + 1] = s2[nt];
+        }
+    }
+    __syncthreads();
+    if (tid < NT * 32 && tid < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            t1 += red[((w * NT) * 32 + tid) * 2 + 0];
+            t2 += red[((w * NT) * 32 + tid) * 2 + 1];
+        }
+        a.stats[slab * 2 * a.Cout + tid] = t1;
+        a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Direct convolution, kernel KS^3 (pad KS/2), stride S.
+template <int KS, int S, int TD, int TH, int NT, int CK>
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
+    constexpr int EWH = (EW + 1) / 2;
+    constexpr int EWS = (S == 2) ? 2 * EWH : EW;     // LDS slots per row (S=2: even/odd de-interleaved)
+    constexpr int MT = TD * TH / 4;
+    constexpr int VS = CK + 4;
+    constexpr int NF4 = CK / 4;
+    static_assert(TD * TH % 4 == 0, "tile must split over 4 waves");
+    STX_DYN_SMEM(smem);
+    float* tile = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int bid = blockIdx.x, b = blockIdx.y;
+    const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
+    const int od0 = dt * TD, oh0 = ht * TH, ow0 = wt * 32;
+    const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+    const int NQ = a.Cin / 8;
+
+    f32x16 acc[MT][NT];
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mtile = wave * MT + m;
+        const int td = mtile / TH, th = mtile % TH;
+        abase[m] = ((td * S * EH + th * S) * EWS + i) * VS + 4 * half;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16();
+    }
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();
+        for (int idx = tid; idx < ED * EH * EW * NF4; idx += CONV_THREADS) {
+            const int v = idx / NF4, f = idx - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
+            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+            stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val);
+        }
+        __syncthreads();
+        const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
+        for (int tap = 0; tap < KS * KS * KS; ++tap) {
+            const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+            const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
+                                      : ((kd * EH + kh) * EWS + kw) * VS;
+            const float* wtap = wq + (size_t)tap * NQ * NT * 256;
+#pragma unroll
+            for (int q = 0; q < CK / 8; ++q) {
+                float4 av[MT], bv[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[m] = stx_ld4(tile + abase[m] + toff + q * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bv[nt].x, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bv[nt].y, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bv[nt].z, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bv[nt].w, acc[m][nt], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mtile = wave * MT + m;
+        const int od = od0 + mtile / TH, oh = oh0 + mtile % TH;
+        int nrows = (od < a.Do && oh < a.Ho) ? (a.Wo - ow0) : 0;
+        nrows = nrows > 32 ? 32 : nrows;
+        const size_t vox0 = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i;
+            const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+            const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+            conv_epilogue_block(a, acc[m][nt], vox0, 1, nrows, n, sc, bs, lane, s1[nt], s2[nt]);
+        }
+    }
+    if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Transposed convolution k3, stride 2, padding 1, output_padding 1 (out = 2 x in), computed as its
+// 8 output-parity classes with 1/2/2/2/4/4/4/8 taps: true MACs only, no zero insertion.
+//   out[2m+p] (per axis): p=0 -> tap k=1 at input m;  p=1 -> tap k=0 at input m+1 and k=2 at m.
+// A workgroup owns TWO rows of 32 input columns; each row is shared by two waves that split the 8
+// classes 13/14 taps ({111,100,010,000} / {011,101,110,001}); accumulators of a wave's four
+// classes persist over the K-chunks so the input tile is staged once per chunk.
+template <int NT, int CK>
+__global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a) {
+    constexpr int TH = 2;
+    constexpr int ED = 2, EH = TH + 1, EW = 33;
+    constexpr int VS = CK + 4, NF4 = CK / 4;
+    STX_DYN_SMEM(smem);
+    float* tile = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int bid = blockIdx.x, b = blockIdx.y;
+    const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
+    const int md0 = dt, mh0 = ht * TH, mw0 = wt * 32;
+    const int NQ = a.Cin / 8;
+    const int th = wave >> 1, cset = wave & 1;
+    // class ids (pd<<2 | ph<<1 | pw) per wave set
+    const int cls_tab[2][4] = {{7, 4, 2, 0}, {3, 5, 6, 1}};
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[c][nt] = zero16();
+    const int abase = ((th * EW) + i) * VS + 4 * half;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();
+        for (int idx = tid; idx < ED * EH * EW * NF4; idx += CONV_THREADS) {
+            const int v = idx / NF4, f = idx - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int gd = md0 + dz, gh = mh0 + hy, gw = mw0 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gd < a.Di && gh < a.Hi && gw < a.Wi)
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
+            stx_st4(tile + ((dz * EH + hy) * EW + wx) * VS + 4 * f, val);
+        }
+        __syncthreads();
+        const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int cls = cls_tab[cset][c];
+            const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+            for (int sd = 0; sd <= pd; ++sd)
+                for (int sh = 0; sh <= ph; ++sh)
+                    for (int sw = 0; sw <= pw; ++sw) {
+                        // parity 0: (k=1, delta=0); parity 1: s=0 -> (k=0, delta=1), s=1 -> (k=2, delta=0)
+                        const int kd = pd ? (sd ? 2 : 0) : 1, dd = pd ? (sd ? 0 : 1) : 0;
+                        const int kh = ph ? (sh ? 2 : 0) : 1, dh = ph ? (sh ? 0 : 1) : 0;
+                        const int kw = pw ? (sw ? 2 : 0) : 1, dw = pw ? (sw ? 0 : 1) : 0;
+                        const int tap = (kd * 3 + kh) * 3 + kw;
+                        const int toff = ((dd * EH + dh) * EW + dw) * VS;
+                        const float* wtap = wq + (size_t)tap * NQ * NT * 256;
+#pragma unroll
+                        for (int q = 0; q < CK / 8; ++q) {
+                            const float4 av = stx_ld4(tile + abase + toff + q * 8);
+                            float4 bv[NT];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) bv[nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) {
+                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[c][nt], 0, 0, 0);
+                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[c][nt], 0, 0, 0);
+                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[nt].z, acc[c][nt], 0, 0, 0);
+                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[nt].w, acc[c][nt], 0, 0, 0);
+                            }
+                        }
+                    }
+        }
+    }
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    const int mh = mh0 + th;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cls = cls_tab[cset][c];
+        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        const int od = 2 * md0 + pd, oh = 2 * mh + ph, ow_first = 2 * mw0 + pw;
+        int nrows = 0;
+        if (md0 < a.Di && mh < a.Hi && od < a.Do && oh < a.Ho) {
+            nrows = (a.Wo - ow_first + 1) / 2;           // rows with 2*row+ow_first < Wo
+            const int nin = a.Wi - mw0;                  // rows backed by an input column
+            nrows = nrows < nin ? nrows : nin;
+            nrows = nrows > 32 ? 32 : (nrows < 0 ? 0 : nrows);
+        }
+        const size_t vox0 = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow_first;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i;
+            const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+            const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+            conv_epilogue_block(a, acc[c][nt], vox0, 2, nrows, n, sc, bs, lane, s1[nt], s2[nt]);
+        }
+    }
+    if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight packing into the per-lane MFMA B-operand order:
+//   wp[tap][q][nt][lane][j] = Wk[tap][k = 8q + 4*(lane>>5) + j][n = 32nt + (lane&31)]
+// from a torch weight w[A][B][T]:
+//   mode 0 (conv fwd, deconv dgrad):      K = B, N = A, Wk[tap][k][n] = w[n][k][tap]
+//   mode 1 (stride-1 conv dgrad):         K = A, N = B, Wk[tap][k][n] = w[k][n][T-1-tap]
+//   mode 2 (deconv fwd, stride-2 dgrad):  K = A, N = B, Wk[tap][k][n] = w[k][n][tap]
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                                   int A, int Bd, int T, int mode, int K, int N,
+                                                                   int NT, size_t total) {
+    const size_t idx = (size_t)blockIdx.x * CONV_THREADS + threadIdx.x;
+    if (idx >= total) return;
+    const int j = idx & 3, lane = (idx >> 2) & 63;
+    size_t r = idx >> 8;
+    const int nt = r % NT; r /= NT;
+    const int NQ = K / 8;
+    const int q = r % NQ;
+    const int tap = r / NQ;
+    const int k = 8 * q + 4 * (lane >> 5) + j, n = 32 * nt + (lane & 31);
+    float v = 0.f;
+    if (n < N && k < K) {
+        if (mode == 0) v = w[((size_t)n * Bd + k) * T + tap];
+        else if (mode == 1) v = w[((size_t)k * Bd + n) * T + (T - 1 - tap)];
+        else v = w[((size_t)k * Bd + n) * T + tap];
+    }
+    wp[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: G[tap][cf][cc] = sum_o F[S*o + tap - pad][cf] * C[o][cc]
+//   conv:   F = layer input x (fine), C = grad of output (coarse);  dW[cc][cf][tap] = G
+//   deconv: F = grad of output (fine), C = layer input x (coarse);  dWt[cc][cf][tap] = G
+// MFMA view: D[32 cf][32 cc] += A[cf][k = voxel pair] * B[k][cc]; K runs over output voxels.
+// A workgroup owns one (cf-block, cc-block) pair, walks a strided set of spatial tiles
+// (1 x TH x TW coarse voxels each) and keeps all its taps' 32x32 partial sums in registers
+// (taps are dealt round-robin to the 4 waves; for 1x1x1 the waves split the voxels instead).
+// Partials go to a slab [pair][chunk][(wave)][tap][32][32]; wgrad_reduce_kernel sums the slab in a
+// fixed order (deterministic) and writes the torch-layout weight gradient.
+struct WgradArgs {
+    const float* f;     // [B][Df][Hf][Wf][CF]
+    const float* c;     // [B][Dc][Hc][Wc][CC]
+    float* slab;
+    int B, Df, Hf, Wf, CF;
+    int Dc, Hc, Wc, CC;
+    int nHt, nWt, ntiles;
+};
+
+template <int KS, int S, int TH, int TW>
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int T = KS * KS * KS;
+    constexpr int ED = KS, EH = (TH - 1) * S + KS, EW = (TW - 1) * S + KS;
+    constexpr int EWH = (EW + 1) / 2;
+    constexpr int EWS = (S == 2) ? 2 * EWH : EW;
+    constexpr int NTAP = (T + 3) / 4;               // taps per wave (KS=3: 7)
+    constexpr int NV = TH * TW;                     // coarse voxels per tile
+    STX_DYN_SMEM(smem);
+    float* ftile = reinterpret_cast<float*>(smem);          // [ED*EH*EWS][32]
+    float* ctile = ftile + ED * EH * EWS * 32;              // [NV][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int ncf = a.CF / 32;
+    const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) acc[t] = zero16();
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        int r = tile;
+        const int wt = r % a.nWt; r /= a.nWt;
+        const int ht = r % a.nHt; r /= a.nHt;
+        const int od = r % a.Dc;
+        const int b = r / a.Dc;
+        const int oh0 = ht * TH, ow0 = wt * TW;
+        const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        __syncthreads();
+        for (int idx = tid; idx < ED * EH * EW * 8; idx += CONV_THREADS) {
+            const int v = idx >> 3, f = idx & 7;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gd >= 0 && gd < a.Df && gh >= 0 && gh < a.Hf && gw >= 0 && gw < a.Wf)
+                val = stx_ld4(a.f + ((((size_t)b * a.Df + gd) * a.Hf + gh) * a.Wf + gw) * a.CF + cfb * 32 + 4 * f);
+            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+            stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, val);
+        }
+        for (int idx = tid; idx < NV * 8; idx += CONV_THREADS) {
+            const int v = idx >> 3, f = idx & 7;
+            const int ow = ow0 + v % TW, oh = oh0 + v / TW;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oh < a.Hc && ow < a.Wc)
+                val = stx_ld4(a.c + ((((size_t)b * a.Dc + od) * a.Hc + oh) * a.Wc + ow) * a.CC + ccb * 32 + 4 * f);
+            stx_st4(ctile + v * 32 + 4 * f, val);
+        }
+        __syncthreads();
+        if (KS == 1) {
+            // waves split the voxel pairs
+            for (int p = wave; p < NV / 2; p += 4) {
+                const int v = 2 * p + half;
+                const int lw = v % TW, lh = v / TW;
+                const float bv = ctile[v * 32 + i];
+                const float av = ftile[(lh * EWS + lw) * 32 + i];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+            }
+        } else {
+            for (int p = 0; p < NV / 2; ++p) {
+                const int v = 2 * p + half;
+                const int lw = v % TW, lh = v / TW;
+                const float bv = ctile[v * 32 + i];
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    const int tap = t * 4 + wave;
+                    if (tap < T) {
+                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                        const int wx = lw * S + kw, hy = lh * S + kh;
+                        const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+                        const float av = ftile[((kd * EH + hy) * EWS + slot) * 32 + i];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // partial slab: KS=3: [blockIdx.y][blockIdx.x][tap][cf 32][cc 32]; KS=1: [..][wave][32][32]
+    constexpr int ROWS = (KS == 1) ? 4 : T;
+    float* dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ROWS * 1024;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int row = (KS == 1) ? wave : t * 4 + wave;
+        if (KS == 1 ? (t == 0) : (row < T)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cf = (r & 3) + 8 * (r >> 2) + 4 * half;
+                dst[(size_t)row * 1024 + cf * 32 + i] = acc[t][r];
+            }
+        }
+    }
+}
+
+// dW[cc][cf][tap] = sum over chunks (and waves for KS=1) of the slab.
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                           float* __restrict__ dw, int CF, int CC,
+                                                                           int T, int nchunks, int rows_per_chunk) {
+    const int idx = blockIdx.x * CONV_THREADS + threadIdx.x;      // over [pair][tap][cf32][cc32]
+    const int ncf = CF / 32;
+    const int total = (CF / 32) * (CC / 32) * T * 1024;
+    if (idx >= total) return;
+    const int cc_l = idx & 31, cf_l = (idx >> 5) & 31;
+    const int tap = (idx >> 10) % T, pair = (idx >> 10) / T;
+    const int cfb = pair % ncf, ccb = pair / ncf;
+    float s = 0.f;
+    if (rows_per_chunk == T) {
+        const float* p = slab + ((size_t)pair * nchunks * T + tap) * 1024 + cf_l * 32 + cc_l;
+        for (int c = 0; c < nchunks; ++c) s += p[(size_t)c * T * 1024];
+    } else {  // KS=1: 4 wave rows per chunk
+        const float* p = slab + ((size_t)pair * nchunks * 4) * 1024 + cf_l * 32 + cc_l;
+        for (int c = 0; c < nchunks * 4; ++c) s += p[(size_t)c * 1024];
+    }
+    dw[((size_t)(ccb * 32 + cc_l) * CF + cfb * 32 + cf_l) * T + tap] = s;
+}
+
+template <typename K>
+int launch_with_lds(K kernel, dim3 grid, size_t lds, hipStream_t st, ConvArgs a) {
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kernel, grid, dim3(CONV_THREADS), lds, st, a);
+    return 0;
+}
+
+constexpr int CONV_TD = 2, CONV_TH = 2;
+
+template <int KS, int S>
+size_t conv_lds_bytes(int CK, int NT) {
+    const int ED = (CONV_TD - 1) * S + KS, EH = (CONV_TH - 1) * S + KS, EW = 31 * S + KS;
+    const int EWS = (S == 2) ? 2 * ((EW + 1) / 2) : EW;
+    size_t t = (size_t)ED * EH * EWS * (CK + 4) * 4;
+    size_t red = (size_t)4 * NT * 32 * 2 * 4;
+    return t > red ? t : red;
+}
+
+template <int KS, int S>
+int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) {
+    const size_t lds = conv_lds_bytes<KS, S>(CK, NT);
+#define CONV_CASE(NT_, CK_)                                                                                        \
+    if (NT == NT_ && CK == CK_)                                                                                    \
+        return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, grid, lds, st, a);
+    CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32)
+    CONV_CASE(1, 8) CONV_CASE(2, 8) CONV_CASE(4, 8)
+#undef CONV_CASE
+    return stx_set_error(STX_ERR_ARG, "conv3d: unsupported NT=%d CK=%d", NT, CK);
+}
+
+}  // namespace
+
+// Cin chunk used by the kernels for a given Cin (multiple of 8).
+static int conv_pick_ck(int Cin) { return (Cin % 32 == 0) ? 32 : 8; }
+// 32-wide MFMA column blocks used for N output channels (1, 2 or 4).
+static int conv_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
+
+extern "C" long long stx_conv3d_packed_floats(int K, int N, int T) {
+    return (long long)T * (K / 8) * conv_nt(N) * 256;
+}
+
+extern "C" int stx_conv3d_pack_weight(const float* w, float* wp, int A, int Bd, int T, int mode, void* stream) {
+    STX_REQUIRE(w && wp && A > 0 && Bd > 0 && (T == 1 || T == 27), "conv3d_pack_weight: bad args");
+    STX_REQUIRE(mode >= 0 && mode <= 2, "conv3d_pack_weight: mode %d", mode);
+    const int K = (mode == 0) ? Bd : A, N = (mode == 0) ? A : Bd;
+    STX_REQUIRE(K % 8 == 0 && N <= 128, "conv3d_pack_weight: GEMM-K channels (%d) must be a multiple of 8, N (%d) <= 128", K, N);
+    const int NT = conv_nt(N);
+    const size_t total = (size_t)T * (K / 8) * NT * 256;
+    hipLaunchKernelGGL(conv3d_pack_kernel, dim3((unsigned)((total + CONV_THREADS - 1) / CONV_THREADS)),
+                       dim3(CONV_THREADS), 0, (hipStream_t)stream, w, wp, A, Bd, T, mode, K, N, NT, total);
+    return stx_check_launch("conv3d_pack_weight");
+}
+
+// Number of workgroups (= rows of the `stats` partial slab) stx_conv3d_fwd launches per batch item.
+extern "C" int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo) {
+    return stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
+}
+extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) { return Di * stx_cdiv(Hi, 2) * stx_cdiv(Wi, 32); }
+
+extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
+                              const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout,
+                              int ks, int stride, int relu, void* stream) {
+    STX_REQUIRE(x && wp && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv3d_fwd: bad shape");
+    STX_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 128, "conv3d_fwd: Cin=%d (need %%8) Cout=%d (need <=128)", Cin, Cout);
+    STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1),
+                "conv3d_fwd: kernel %d stride %d unsupported", ks, stride);
+    ConvArgs a;
+    a.x = x; a.wp = wp; a.out = out; a.scale = scale; a.bias = bias; a.residual = residual; a.stats = stats;
+    a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    const int pad = ks / 2;
+    a.Do = (Di + 2 * pad - ks) / stride + 1;
+    a.Ho = (Hi + 2 * pad - ks) / stride + 1;
+    a.Wo = (Wi + 2 * pad - ks) / stride + 1;
+    a.nDt = stx_cdiv(a.Do, CONV_TD); a.nHt = stx_cdiv(a.Ho, CONV_TH); a.nWt = stx_cdiv(a.Wo, 32);
+    const int NT = conv_nt(Cout);
+    const int CK = conv_pick_ck(Cin);
+    dim3 grid(a.nDt * a.nHt * a.nWt, B);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (ks == 3 && stride == 1) rc = conv_dispatch<3, 1>(a, NT, CK, grid, st);
+    else if (ks == 3) rc = conv_dispatch<3, 2>(a, NT, CK, grid, st);
+    else rc = conv_dispatch<1, 1>(a, NT, CK, grid, st);
+    if (rc) return rc;
+    return stx_check_launch("conv3d_fwd");
+}
+
+extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
+                                const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout,
+                                int Do, int Ho, int Wo, int relu, void* stream) {
+    STX_REQUIRE(x && wp && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "deconv3d_fwd: bad shape");
+    STX_REQUIRE(Cin % 32 == 0 && Cout >= 1 && Cout <= 64, "deconv3d_fwd: Cin=%d (need %%32) Cout=%d (need <=64)", Cin, Cout);
+    STX_REQUIRE(Do <= 2 * Di && Do >= 2 * Di - 1 && Ho <= 2 * Hi && Ho >= 2 * Hi - 1 && Wo <= 2 * Wi && Wo >= 2 * Wi - 1,
+                "deconv3d_fwd: output dims must be 2*in or 2*in-1");
+    ConvArgs a;
+    a.x = x; a.wp = wp; a.out = out; a.scale = scale; a.bias = bias; a.residual = residual; a.stats = stats;
+    a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+    a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    a.nDt = Di; a.nHt = stx_cdiv(Hi, 2); a.nWt = stx_cdiv(Wi, 32);
+    const int NT = conv_nt(Cout);
+    dim3 grid(a.nDt * a.nHt * a.nWt, B);
+    size_t lds = (size_t)2 * 3 * 33 * 36 * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (NT == 1) launch_with_lds(deconv3d_igemm_kernel<1, 32>, grid, lds, st, a);
+    else launch_with_lds(deconv3d_igemm_kernel<2, 32>, grid, lds, st, a);
+    return stx_check_launch("deconv3d_fwd");
+}
+
+// Workgroups along the split-K axis for the weight gradient.
+static int wgrad_chunks(int ntiles, int npairs) {
+    int c = 1024 / npairs;
+    if (c < 1) c = 1;
+    if (c > ntiles) c = ntiles;
+    return c;
+}
+
+extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks,
+                                                       int stride) {
+    const int TH = 2, TW = (stride == 2) ? 16 : 32;
+    const int ntiles = B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW);
+    const int npairs = (CF / 32) * (CC / 32);
+    const int rows = (ks == 1) ? 4 : 27;
+    return (long long)npairs * wgrad_chunks(ntiles, npairs) * rows * 1024;
+}
+
+extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float* workspace, int B, int Df, int Hf,
+                                int Wf, int CF, int Dc, int Hc, int Wc, int CC, int ks, int stride, void* stream) {
+    STX_REQUIRE(f && c && dw && workspace && B > 0, "conv3d_wgrad: null operand");
+    STX_REQUIRE(CF % 32 == 0 && CC % 32 == 0, "conv3d_wgrad: channel counts (%d, %d) must be multiples of 32", CF, CC);
+    STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1), "conv3d_wgrad: ks/stride");
+    WgradArgs a;
+    a.f = f; a.c = c; a.slab = workspace;
+    a.B = B; a.Df = Df; a.Hf = Hf; a.Wf = Wf; a.CF = CF; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.CC = CC;
+    const int TH = 2, TW = (stride == 2) ? 16 : 32;
+    a.nHt = stx_cdiv(Hc, TH); a.nWt = stx_cdiv(Wc, TW);
+    a.ntiles = B * Dc * a.nHt * a.nWt;
+    const int npairs = (CF / 32) * (CC / 32);
+    const int nchunks = wgrad_chunks(a.ntiles, npairs);
+    dim3 grid(nchunks, npairs);
+    hipStream_t st = (hipStream_t)stream;
+    const int T = ks == 1 ? 1 : 27;
+    if (ks == 3 && stride == 1) {
+        const size_t lds = ((size_t)3 * 4 * 34 + 64) * 32 * 4;
+        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<3, 1, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<3, 1, 2, 32>), grid, dim3(CONV_THREADS), lds, st, a);
+    } else if (ks == 3) {
+        const size_t lds = ((size_t)3 * 5 * 34 + 32) * 32 * 4;
+        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<3, 2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<3, 2, 2, 16>), grid, dim3(CONV_THREADS), lds, st, a);
+    } else {
+        const size_t lds = ((size_t)2 * 32 + 64) * 32 * 4;
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<1, 1, 2, 32>), grid, dim3(CONV_THREADS), lds, st, a);
+    }
+    int rc = stx_check_launch("conv3d_wgrad");
+    if (rc) return rc;
+    const int total = npairs * T * 1024;
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(stx_cdiv(total, CONV_THREADS)), dim3(CONV_THREADS), 0, st,
+                       workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);
+    return stx_check_launch("conv3d_wgrad_reduce");
+}

@@ -1,0 +1,247 @@
+// Fused disparity-regression head for gfx950 and the stand-alone disparity estimators.
+//
+// Replaces (reference, /root/reference/stereo_toolbox):
+//   F.upsample(cost, [maxdisp,H,W], mode='trilinear') -> squeeze -> F.softmax(dim=1)
+//       -> disparity_regression           models/GwcNet/gwcnet.py:197-224,
+//                                         models/PSMNet/stackhourglass.py:139-153,
+//                                         models/ACVNet/acv.py:206-251
+//   disparity_regression(x, maxdisp)      models/GwcNet/submodule.py:23-27
+//   disparityregression(maxdisp)(x)       models/PSMNet/submodule.py:46-54
+//   softargmax_/argmax_disparity_estimator disparity_estimators/__init__.py:7-15
+//   F.softmax(att_weights, dim=2)         models/ACVNet/acv.py:196
+//
+// The reference chain materialises three [B,192,H,W] tensors (425 MB each at 576x960); the fused
+// kernel reads the quarter-resolution cost (6.6 MB) and writes the disparity map (2.2 MB):
+// algorithmic bytes 8 847 360.  Roofline: HBM (in practice latency/exp bound).
+//
+// Interpolation follows ATen's align_corners=False rule on all three axes:
+//   src = max(scale*(dst+0.5)-0.5, 0), i0 = floor(src), i1 = min(i0+1, n-1), t = src-i0.
+// One thread owns one output pixel: it walks the 192 output disparities once, advancing a
+// two-entry window of H/W-interpolated cost samples, with an online (running-max) softmax.
+#include "stx_common.h"
+
+namespace {
+
+constexpr int HD_THREADS = 256;
+constexpr int HB_TW = 16, HB_TH = 16;   // backward pixel tile
+
+struct Lerp { int i0, i1; float t; };
+
+__device__ __forceinline__ Lerp hd_src(int dst, float scale, int n) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    int i0 = (int)s;
+    if (i0 > n - 1) i0 = n - 1;
+    Lerp r;
+    r.i0 = i0;
+    r.i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    r.t = s - (float)i0;
+    return r;
+}
+
+__device__ __forceinline__ float hd_sample(const float* __restrict__ plane, int Wc, Lerp lh, Lerp lw) {
+    const float a = plane[lh.i0 * Wc + lw.i0], b = plane[lh.i0 * Wc + lw.i1];
+    const float c = plane[lh.i1 * Wc + lw.i0], d = plane[lh.i1 * Wc + lw.i1];
+    return (1.f - lh.t) * ((1.f - lw.t) * a + lw.t * b) + lh.t * ((1.f - lw.t) * c + lw.t * d);
+}
+
+__global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
+    const float* __restrict__ cost, float* __restrict__ disp, float* __restrict__ stats,
+    int Dc, int Hc, int Wc, int D, int H, int W) {
+    const int w = blockIdx.x * HD_THREADS + threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (w >= W) return;
+    const float rd = (float)Dc / (float)D, rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
+    const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
+    const float* cb = cost + (size_t)b * Dc * Hc * Wc;
+    const int plane = Hc * Wc;
+    int cur = 0;
+    float c0 = hd_sample(cb, Wc, lh, lw);
+    float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
+    float m = -3.0e38f, s = 0.f, t = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const Lerp ld = hd_src(d, rd, Dc);
+        while (cur < ld.i0) {
+            ++cur;
+            c0 = c1;
+            const int nx = cur + 1 < Dc ? cur + 1 : Dc - 1;
+            c1 = hd_sample(cb + (size_t)nx * plane, Wc, lh, lw);
+        }
+        const float hi = (ld.i1 == ld.i0) ? c0 : c1;
+        const float x = (1.f - ld.t) * c0 + ld.t * hi;
+        if (x > m) {
+            const float f = stx_exp(m - x);
+            s *= f;
+            t *= f;
+            m = x;
+        }
+        const float e = stx_exp(x - m);
+        s += e;
+        t = fmaf((float)d, e, t);
+    }
+    const size_t o = ((size_t)b * H + h) * W + w;
+    disp[o] = t / s;
+    if (stats) { stats[2 * o] = m; stats[2 * o + 1] = s; }
+}
+
+// Backward: dlogit_d = g * p_d * (d - disp); scattered back through the three lerps.  A
+// workgroup owns a 16x16 pixel tile, reduces into an LDS image of the cost cells it touches
+// (ds_add_f32) and flushes that image with one global atomic per cell.
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ cost, const float* __restrict__ disp,
+    const float* __restrict__ stats, float* __restrict__ gcost,
+    int Dc, int Hc, int Wc, int D, int H, int W, int FH, int FW) {
+    STX_DYN_SMEM(smem);
+    float* acc = reinterpret_cast<float*>(smem);            // [Dc][FH][FW]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int hbase = blockIdx.y * HB_TH, wbase = blockIdx.x * HB_TW;
+    const float rd = (float)Dc / (float)D, rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
+    const int hc_lo = hd_src(hbase, rh, Hc).i0, wc_lo = hd_src(wbase, rw, Wc).i0;
+    for (int i = tid; i < Dc * FH * FW; i += HD_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    const int h = hbase + tid / HB_TW, w = wbase + tid % HB_TW;
+    if (h < H && w < W) {
+        const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
+        const float* cb = cost + (size_t)b * Dc * Hc * Wc;
+        const int plane = Hc * Wc;
+        const size_t o = ((size_t)b * H + h) * W + w;
+        const float g = gout[o], dv = disp[o], m = stats[2 * o], inv_s = 1.f / stats[2 * o + 1];
+        const int r0 = (lh.i0 - hc_lo) * FW, r1 = (lh.i1 - hc_lo) * FW;
+        const int q0 = lw.i0 - wc_lo, q1 = lw.i1 - wc_lo;
+        const float k00 = (1.f - lh.t) * (1.f - lw.t), k01 = (1.f - lh.t) * lw.t;
+        const float k10 = lh.t * (1.f - lw.t), k11 = lh.t * lw.t;
+        int cur = 0;
+        float c0 = hd_sample(cb, Wc, lh, lw);
+        float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
+        float a0 = 0.f, a1 = 0.f;   // gradient wrt c0 / c1
+        for (int d = 0; d < D; ++d) {
+            const Lerp ld = hd_src(d, rd, Dc);
+            while (cur < ld.i0) {
+                float* cell = acc + cur * FH * FW;
+                atomicAdd(cell + r0 + q0, k00 * a0);
+                atomicAdd(cell + r0 + q1, k01 * a0);
+                atomicAdd(cell + r1 + q0, k10 * a0);
+                atomicAdd(cell + r1 + q1, k11 * a0);
+                ++cur;
+                c0 = c1; a0 = a1; a1 = 0.f;
+                const int nx = cur + 1 < Dc ? cur + 1 : Dc - 1;
+                c1 = hd_sample(cb + (size_t)nx * plane, Wc, lh, lw);
+            }
+            const bool same = ld.i1 == ld.i0;
+            const float hi = same ? c0 : c1;
+            const float x = (1.f - ld.t) * c0 + ld.t * hi;
+            const float p = stx_exp(x - m) * inv_s;
+            const float gl = g * p * ((float)d - dv);
+            if (same) a0 += gl; else { a0 = fmaf(1.f - ld.t, gl, a0); a1 = fmaf(ld.t, gl, a1); }
+        }
+        for (int k = 0; k < 2; ++k) {   // flush the last window entries (cur, cur+1)
+            const int dc = cur + k;
+            const float a = k ? a1 : a0;
+            if (dc < Dc && a != 0.f) {
+                float* cell = acc + dc * FH * FW;
+                atomicAdd(cell + r0 + q0, k00 * a);
+                atomicAdd(cell + r0 + q1, k01 * a);
+                atomicAdd(cell + r1 + q0, k10 * a);
+                atomicAdd(cell + r1 + q1, k11 * a);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < Dc * FH * FW; i += HD_THREADS) {
+        const float v = acc[i];
+        if (v != 0.f) {
+            const int dc = i / (FH * FW), r = (i / FW) % FH, q = i % FW;
+            const int hc = hc_lo + r, wc = wc_lo + q;
+            if (hc < Hc && wc < Wc) atomicAdd(gcost + (((size_t)b * Dc + dc) * Hc + hc) * Wc + wc, v);
+        }
+    }
+}
+
+// disp[b,h,w] = sum_d d * x[b,d,h,w]
+__global__ __launch_bounds__(HD_THREADS) void softargmax_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                 int D, int HW) {
+    const int i = blockIdx.x * HD_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    const float* p = x + (size_t)b * D * HW + i;
+    float a = 0.f;
+    for (int d = 0; d < D; ++d) a = fmaf((float)d, p[(size_t)d * HW], a);
+    out[(size_t)b * HW + i] = a;
+}
+
+__global__ __launch_bounds__(HD_THREADS) void argmax_kernel(const float* __restrict__ x, long long* __restrict__ out,
+                                                             int D, int HW) {
+    const int i = blockIdx.x * HD_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    const float* p = x + (size_t)b * D * HW + i;
+    float best = p[0];
+    int bi = 0;
+    for (int d = 1; d < D; ++d) {
+        const float v = p[(size_t)d * HW];
+        if (v > best) { best = v; bi = d; }   // first maximum wins, as torch.argmax
+    }
+    out[(size_t)b * HW + i] = bi;
+}
+
+// y[b,d,i] = softmax over d of x[b,d,i]
+__global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int D, int HW) {
+    const int i = blockIdx.x * HD_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    const float* p = x + (size_t)b * D * HW + i;
+    float* q = y + (size_t)b * D * HW + i;
+    float m = -3.0e38f;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, p[(size_t)d * HW]);
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s += stx_exp(p[(size_t)d * HW] - m);
+    const float inv = 1.f / s;
+    for (int d = 0; d < D; ++d) q[(size_t)d * HW] = stx_exp(p[(size_t)d * HW] - m) * inv;
+}
+
+}  // namespace
+
+extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D,
+                            int H, int W, void* stream) {
+    STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
+    dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
+    hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
+                       Wc, D, H, W);
+    return stx_check_launch("head_fwd");
+}
+
+extern "C" int stx_head_bwd(const float* gout, const float* cost, const float* disp, const float* stats,
+                            float* gcost, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
+    STX_REQUIRE(gout && cost && disp && stats && gcost && B > 0, "head_bwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(gcost, 0, (size_t)B * Dc * Hc * Wc * sizeof(float), st);
+    const int FH = (int)((double)HB_TH * Hc / H) + 3, FW = (int)((double)HB_TW * Wc / W) + 3;
+    const size_t lds = (size_t)Dc * FH * FW * sizeof(float);
+    STX_REQUIRE(lds <= 160 * 1024, "head_bwd: cost footprint too large for LDS (%zu B)", lds);
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(stx_cdiv(W, HB_TW), stx_cdiv(H, HB_TH), B);
+    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(HD_THREADS), lds, st, gout, cost, disp, stats, gcost, Dc, Hc, Wc,
+                       D, H, W, FH, FW);
+    return stx_check_launch("head_bwd");
+}
+
+extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {
+    STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "softargmax_fwd: bad shape");
+    hipLaunchKernelGGL(softargmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0,
+                       (hipStream_t)stream, x, out, D, HW);
+    return stx_check_launch("softargmax_fwd");
+}
+
+extern "C" int stx_argmax_fwd(const float* x, long long* out, int B, int D, int HW, void* stream) {
+    STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "argmax_fwd: bad shape");
+    hipLaunchKernelGGL(argmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0, (hipStream_t)stream, x,
+                       out, D, HW);
+    return stx_check_launch("argmax_fwd");
+}
+
+extern "C" int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream) {
+    STX_REQUIRE(x && y && B > 0 && D > 0 && HW > 0, "softmax_d_fwd: bad shape");
+    hipLaunchKernelGGL(softmax_d_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0, (hipStream_t)stream,
+                       x, y, D, HW);
+    return stx_check_launch("softmax_d_fwd");
+}

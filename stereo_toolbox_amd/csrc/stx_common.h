@@ -10,9 +10,11 @@
 #ifdef STX_HIPEMU
 #include "hipemu.h"
 #define STX_DYN_SMEM(name) char* name = hipemu::dyn_smem()
+#define stx_exp(x) expf(x)
 #else
 #include <hip/hip_runtime.h>
 #define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define stx_exp(x) __expf(x)
 #endif
 #include <stdint.h>
 

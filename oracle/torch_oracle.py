@@ -99,8 +99,9 @@ class Ctx:
 
     def bn(self, x, prefix):
         sd = self.sd
-        rm = sd[prefix + ".running_mean"].clone()
-        rv = sd[prefix + ".running_var"].clone()
+        # a layer called twice (left/right feature pass) chains its running-stat updates
+        rm = self.new_stats.get(prefix + ".running_mean", sd[prefix + ".running_mean"]).clone()
+        rv = self.new_stats.get(prefix + ".running_var", sd[prefix + ".running_var"]).clone()
         y = F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"], self.training, MOMENTUM, EPS)
         if self.training:
             self.new_stats[prefix + ".running_mean"] = rm

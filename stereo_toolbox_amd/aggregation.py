@@ -1,0 +1,133 @@
+"""Host-side orchestration of the Conv3d aggregation: maps the reference's module structure
+(`convbn_3d` = nn.Sequential(Conv3d, BatchNorm3d), ConvTranspose3d + BatchNorm3d, bare Conv3d) onto
+the fused HIP kernels.
+
+The nn.Conv3d / nn.BatchNorm3d objects are kept as *parameter containers* so that state-dict keys,
+DDP gradient hooks, SyncBatchNorm conversion and optimizers see exactly the reference's modules
+(SURVEY.md 8b); their own forward() is never called on the hot path.
+
+Three execution modes of one block  y = act(BN(conv(x)) [+ BN2(conv2(x2))] [+ residual]):
+  * inference (no grad, eval BN): BN folded into the conv epilogue, one kernel per conv;
+  * training  (train BN): conv emits raw z + batch-stat partials -> bn_finalize -> bn_apply;
+  * eval BN with autograd: as training but with the running statistics.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_FOLD_CACHE = {}
+
+
+def _is_transposed(conv):
+    return isinstance(conv, nn.ConvTranspose3d)
+
+
+def _conv_cfg(conv):
+    ks = conv.kernel_size[0]
+    stride = conv.stride[0]
+    if _is_transposed(conv):
+        if not (ks == 3 and stride == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 1):
+            raise ops.StxError("only ConvTranspose3d(k=3, s=2, p=1, op=1) is on the hot path")
+    else:
+        if not ((ks == 3 and conv.padding[0] == 1 and stride in (1, 2)) or (ks == 1 and conv.padding[0] == 0 and stride == 1)):
+            raise ops.StxError(f"unsupported Conv3d k={ks} s={stride} p={conv.padding}")
+    if conv.bias is not None or conv.groups != 1:
+        raise ops.StxError("hot-path convolutions are bias-free and dense")
+    return ks, stride
+
+
+def _fold(bn):
+    """Eval-mode BN as per-channel (scale, bias), cached on the parameter versions."""
+    key = (id(bn), bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr())
+    hit = _FOLD_CACHE.get(id(bn))
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    with torch.no_grad():
+        scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+        bias = (bn.bias - bn.running_mean * scale).contiguous()
+    _FOLD_CACHE[id(bn)] = (key, scale, bias)
+    return scale, bias
+
+
+def _needs_grad(*tensors_and_modules):
+    if not torch.is_grad_enabled():
+        return False
+    for t in tensors_and_modules:
+        if t is None:
+            continue
+        if isinstance(t, torch.Tensor):
+            if t.requires_grad:
+                return True
+        else:
+            if any(p.requires_grad for p in t.parameters()):
+                return True
+    return False
+
+
+def _infer_conv(x, conv, scale, bias, residual, relu):
+    ks, stride = _conv_cfg(conv)
+    if _is_transposed(conv):
+        wp = ops.pack_weight(conv.weight.detach(), 2, cache=True)
+        return ops.deconv3d_forward(x, wp, conv.weight.shape[1], scale=scale, bias=bias, residual=residual, relu=relu)[0]
+    wp = ops.pack_weight(conv.weight.detach(), 0, cache=True)
+    return ops.conv3d_forward(x, wp, conv.weight.shape[0], ks, stride, scale, bias, residual, relu)[0]
+
+
+def _bn_state(bn, partials, count):
+    training = bn.training
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    return {"training": training, "partials": partials, "count": count, "running_mean": bn.running_mean,
+            "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps}
+
+
+def conv_block(x, conv, bn=None, relu=False, second=None, residual=None):
+    """One fused block on NDHWC tensors.
+    second = (x2, conv2, bn2): adds BN2(conv2(x2)) before the activation (hourglass redir path).
+    residual: NDHWC tensor added before the activation."""
+    if second is not None and residual is not None:
+        raise ops.StxError("conv_block: `second` and `residual` are mutually exclusive")
+    mods = [conv, bn] + ([second[1], second[2]] if second is not None else [])
+    grad = _needs_grad(x, residual, *(m for m in mods if m is not None), *([second[0]] if second else []))
+    train_bn = (bn is not None and bn.training) or (second is not None and second[2].training)
+
+    if not grad and not train_bn:   # ---- inference: everything folded into conv epilogues
+        if second is not None:
+            s2, b2 = _fold(second[2])
+            residual = _infer_conv(second[0], second[1], s2, b2, None, False)
+        if bn is not None:
+            s1, b1 = _fold(bn)
+        else:
+            s1 = b1 = None
+        return _infer_conv(x, conv, s1, b1, residual, relu)
+
+    # ---- autograd path
+    ks, stride = _conv_cfg(conv)
+    want = bn is not None and bn.training
+    z1, part1 = ops.ConvRawFn.apply(x, conv.weight, ks, stride, _is_transposed(conv), want)
+    if bn is None:
+        y = z1
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if relu else y
+    count1 = z1.numel() // z1.shape[-1]
+    st1 = _bn_state(bn, part1 if want else None, count1)
+    if second is not None:
+        x2, conv2, bn2 = second
+        ks2, stride2 = _conv_cfg(conv2)
+        want2 = bn2.training
+        z2, part2 = ops.ConvRawFn.apply(x2, conv2.weight, ks2, stride2, _is_transposed(conv2), want2)
+        st2 = _bn_state(bn2, part2 if want2 else None, z2.numel() // z2.shape[-1])
+        return ops.BnActFn.apply(z1, bn.weight, bn.bias, z2, bn2.weight, bn2.bias, None, relu, st1, st2)
+    return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None)
+
+
+def convbn_block(x, seq, relu=False, second=None, residual=None):
+    """`seq` = nn.Sequential(conv, bn) as built by convbn_3d (or (ConvTranspose3d, BatchNorm3d))."""
+    sec = None
+    if second is not None:
+        sec = (second[0], second[1][0], second[1][1])
+    return conv_block(x, seq[0], seq[1], relu=relu, second=sec, residual=residual)

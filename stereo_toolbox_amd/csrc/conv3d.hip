@@ -472,6 +472,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_reduce_kernel(const
 
 template <typename K>
 int launch_with_lds(K kernel, dim3 grid, size_t lds, hipStream_t st, ConvArgs a) {
+    if (lds > 160 * 1024) return stx_set_error(STX_ERR_ARG, "conv3d: LDS tile of %zu B exceeds 160 KiB", lds);
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, grid, dim3(CONV_THREADS), lds, st, a);
@@ -546,7 +547,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     a.Wo = (Wi + 2 * pad - ks) / stride + 1;
     a.nDt = stx_cdiv(a.Do, CONV_TD); a.nHt = stx_cdiv(a.Ho, CONV_TH); a.nWt = stx_cdiv(a.Wo, 32);
     const int NT = conv_nt(Cout);
-    const int CK = conv_pick_ck(Cin);
+    // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: keep it to 8-channel K chunks (79 KB).
+    const int CK = (stride == 2) ? 8 : conv_pick_ck(Cin);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -573,8 +575,10 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     size_t lds = (size_t)2 * 3 * 33 * 36 * 4;
     hipStream_t st = (hipStream_t)stream;
-    if (NT == 1) launch_with_lds(deconv3d_igemm_kernel<1, 32>, grid, lds, st, a);
-    else launch_with_lds(deconv3d_igemm_kernel<2, 32>, grid, lds, st, a);
+    int rc;
+    if (NT == 1) rc = launch_with_lds(deconv3d_igemm_kernel<1, 32>, grid, lds, st, a);
+    else rc = launch_with_lds(deconv3d_igemm_kernel<2, 32>, grid, lds, st, a);
+    if (rc) return rc;
     return stx_check_launch("deconv3d_fwd");
 }
 

@@ -1,0 +1,425 @@
+"""Tensor-level host side of the HIP kernels: argument checking, workspaces, autograd.
+
+Everything here launches hand-written gfx950 kernels through the C-ABI (include/stx_hip.h) on the
+caller's current HIP stream.  There is no CPU or stock-torch fallback for these ops: tensors that
+are not fp32 on a ROCm device raise, and a missing library raises at first use.
+
+Activation convention inside the 3-D path: dense channels-last tensors of shape [B, D, H, W, C]
+("NDHWC").  `to_ncdhw` / `to_ndhwc` give zero-copy logical views for the public API.
+"""
+import ctypes
+
+import torch
+
+from ._capi import StxError, get_lib
+
+_P = ctypes.c_void_p
+
+
+# --------------------------------------------------------------------------------------- plumbing
+def _stream():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else _P(t.data_ptr())
+
+
+def _chk(t, name, dims=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise StxError(f"{name}: expected a ROCm device tensor, got {t.device} -- the cost-volume hot path has "
+                       "no CPU fallback (the CPU oracle lives in oracle/ and is test-only)")
+    if t.dtype != torch.float32:
+        raise StxError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise StxError(f"{name}: expected a dense contiguous tensor, strides {t.stride()}")
+    if dims is not None and t.dim() != dims:
+        raise StxError(f"{name}: expected {dims} dims, got shape {tuple(t.shape)}")
+
+
+def _call(name, *args):
+    get_lib().call(name, *args, _stream())
+
+
+def to_ncdhw(x):
+    """[B,D,H,W,C] dense -> logical [B,C,D,H,W] view (channels_last_3d strides, no copy)."""
+    return x.permute(0, 4, 1, 2, 3)
+
+
+def to_ndhwc(x):
+    """logical [B,C,D,H,W] (any strides) -> dense [B,D,H,W,C]."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class _Workspace:
+    """Grow-only scratch buffers per (device, tag): wgrad slabs, BN partial sums."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, tag, nfloats, device):
+        key = (device.index, tag)
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nfloats:
+            b = torch.empty(int(nfloats), dtype=torch.float32, device=device)
+            self.bufs[key] = b
+        return b
+
+
+_WS = _Workspace()
+_PACK_CACHE = {}
+
+
+def pack_weight(w, mode, cache=False):
+    """Device-side re-layout of a torch conv weight [A][B][k,k,k] into MFMA B-operand order.
+    mode 0: conv fwd / deconv dgrad;  1: stride-1 conv dgrad;  2: deconv fwd / stride-2 conv dgrad."""
+    _chk(w, "weight", 5)
+    key = None
+    if cache:
+        key = (w.data_ptr(), w._version, mode, tuple(w.shape))
+        hit = _PACK_CACHE.get(key)
+        if hit is not None:
+            return hit
+    A, Bd = w.shape[0], w.shape[1]
+    T = w.shape[2] * w.shape[3] * w.shape[4]
+    K, N = (Bd, A) if mode == 0 else (A, Bd)
+    n = get_lib().raw("stx_conv3d_packed_floats")(K, N, T)
+    wp = torch.empty(n, dtype=torch.float32, device=w.device)
+    _call("stx_conv3d_pack_weight", _p(w), _p(wp), A, Bd, T, mode)
+    if cache:
+        if len(_PACK_CACHE) > 512:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = wp
+    return wp
+
+
+def _pad_channels(t, C):
+    """Zero-pad the last (channel) axis of an NDHWC tensor / dim 0 or 1 of a weight."""
+    if t.shape[-1] == C:
+        return t
+    out = t.new_zeros(*t.shape[:-1], C)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+# --------------------------------------------------------------------------------------- raw convs
+def conv_out_dims(D, H, W, ks, stride):
+    pad = ks // 2
+    return tuple((d + 2 * pad - ks) // stride + 1 for d in (D, H, W))
+
+
+def conv3d_forward(x, wp, Cout, ks, stride, scale=None, bias=None, residual=None, relu=False, want_stats=False):
+    """out = act(conv(x) * scale + bias + residual); optional BN partial sums of the raw output."""
+    _chk(x, "x", 5)
+    B, D, H, W, Cin = x.shape
+    Do, Ho, Wo = conv_out_dims(D, H, W, ks, stride)
+    out = torch.empty(B, Do, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        nb = get_lib().raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+        stats = torch.empty(B * nb, 2, Cout, dtype=torch.float32, device=x.device)
+    _call("stx_conv3d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(bias), _p(residual), _p(stats), B, D, H, W, Cin,
+          Cout, ks, stride, int(relu))
+    return out, stats
+
+
+def deconv3d_forward(x, wp, Cout, out_dims=None, scale=None, bias=None, residual=None, relu=False, want_stats=False):
+    """ConvTranspose3d(k3, s2, p1, op1) (out = 2*in), same fused epilogue as conv3d_forward."""
+    _chk(x, "x", 5)
+    B, D, H, W, Cin = x.shape
+    Do, Ho, Wo = out_dims if out_dims is not None else (2 * D, 2 * H, 2 * W)
+    out = torch.empty(B, Do, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    stats = None
+    if want_stats:
+        nb = get_lib().raw("stx_deconv3d_fwd_blocks")(D, H, W)
+        stats = torch.empty(B * nb, 2, Cout, dtype=torch.float32, device=x.device)
+    _call("stx_deconv3d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(bias), _p(residual), _p(stats), B, D, H, W, Cin,
+          Cout, Do, Ho, Wo, int(relu))
+    return out, stats
+
+
+def conv3d_wgrad(fine, coarse, ks, stride):
+    """G[cc][cf][tap] = sum_o fine[S*o+tap-pad][cf] * coarse[o][cc] (see conv3d.hip)."""
+    B, Df, Hf, Wf, CF = fine.shape
+    _, Dc, Hc, Wc, CC = coarse.shape
+    n = get_lib().raw("stx_conv3d_wgrad_workspace_floats")(B, Dc, Hc, Wc, CF, CC, ks, stride)
+    ws = _WS.get("wgrad", n, fine.device)
+    dw = torch.empty(CC, CF, ks ** 3, dtype=torch.float32, device=fine.device)
+    _call("stx_conv3d_wgrad", _p(fine), _p(coarse), _p(dw), _p(ws), B, Df, Hf, Wf, CF, Dc, Hc, Wc, CC, ks, stride)
+    return dw
+
+
+class ConvRawFn(torch.autograd.Function):
+    """z = conv(x, w) (or transposed conv), raw output + BN partial sums; backward = dgrad + wgrad
+    on the same MFMA kernels with re-packed weights."""
+
+    @staticmethod
+    def forward(ctx, x, w, ks, stride, transposed, want_stats):
+        _chk(x, "x", 5)
+        if transposed:
+            Cout = w.shape[1]
+            z, stats = deconv3d_forward(x, pack_weight(w, 2), Cout, want_stats=want_stats)
+        else:
+            Cout = w.shape[0]
+            z, stats = conv3d_forward(x, pack_weight(w, 0), Cout, ks, stride, want_stats=want_stats)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (ks, stride, transposed)
+        if stats is None:
+            stats = x.new_empty(0)
+        ctx.mark_non_differentiable(stats)
+        return z, stats
+
+    @staticmethod
+    def backward(ctx, gz, _gstats):
+        x, w = ctx.saved_tensors
+        ks, stride, transposed = ctx.cfg
+        gz = gz.contiguous()
+        gx = gw = None
+        B, D, H, W, Cin = x.shape
+        if transposed:
+            Ci, Co = w.shape[0], w.shape[1]
+            if ctx.needs_input_grad[0]:   # stride-2 conv of gz with the deconv weight read as [Cout'][Cin']
+                gx, _ = conv3d_forward(gz, pack_weight(w, 0), Ci, 3, 2)
+            if ctx.needs_input_grad[1]:
+                gw = conv3d_wgrad(gz, x, 3, 2).view_as(w)
+        else:
+            Co, Ci = w.shape[0], w.shape[1]
+            gz_k, w_k = gz, w
+            if Co % 8 != 0:               # e.g. the classifier tail Conv3d(32 -> 1): pad GEMM-K to 8
+                Cp = (Co + 7) // 8 * 8
+                gz_k = _pad_channels(gz, Cp)
+                w_k = w.new_zeros(Cp, *w.shape[1:])
+                w_k[:Co] = w
+            if ctx.needs_input_grad[0]:
+                if stride == 1:
+                    gx, _ = conv3d_forward(gz_k, pack_weight(w_k, 1), Ci, ks, 1)
+                else:                     # stride-2 dgrad = transposed conv of gz
+                    gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W))
+            if ctx.needs_input_grad[1]:
+                gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
+                gw = conv3d_wgrad(x, gz_w, ks, stride)[:Co].reshape(w.shape)
+        return gx, gw, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------- batch norm
+def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps):
+    C = partials.shape[-1]
+    outs = [torch.empty(C, dtype=torch.float32, device=partials.device) for _ in range(4)]
+    lib = get_lib()
+    lib.call("stx_bn_finalize", _p(partials), partials.shape[0], C, float(count), _p(gamma), _p(beta),
+             _p(running_mean), _p(running_var), float(momentum), float(eps), *[_p(o) for o in outs], _stream())
+    return outs   # scale, shift, mean, invstd
+
+
+def bn_apply(z1, scale1, shift1, z2=None, scale2=None, shift2=None, relu=False):
+    out = torch.empty_like(z1)
+    C = z1.shape[-1]
+    _call("stx_bn_apply", _p(z1), _p(scale1), _p(shift1), _p(z2), _p(scale2), _p(shift2), _p(out), z1.numel() // C, C,
+          int(relu))
+    return out
+
+
+class BnActFn(torch.autograd.Function):
+    """y = act(BN1(z1) [+ BN2(z2)] [+ residual]) with batch statistics (train) or running statistics
+    (eval with grad).  `bn1`/`bn2` are dicts: gamma, beta, running_mean, running_var, momentum, eps,
+    training, partials (conv-epilogue sums) and count."""
+
+    @staticmethod
+    def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2):
+        def affine(z, gamma, beta, bn):
+            if bn["training"]:
+                return bn_finalize(bn["partials"], bn["count"], gamma, beta, bn["running_mean"], bn["running_var"],
+                                   bn["momentum"], bn["eps"])
+            invstd = torch.rsqrt(bn["running_var"] + bn["eps"])
+            scale = gamma * invstd
+            return scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd
+
+        sc1, sh1, m1, i1 = affine(z1, gamma1, beta1, bn1)
+        two = z2 is not None
+        if two:
+            sc2, sh2, m2, i2 = affine(z2, gamma2, beta2, bn2)
+            y = bn_apply(z1, sc1, sh1, z2, sc2, sh2, relu)
+        else:
+            sc2 = sh2 = m2 = i2 = None
+            y = bn_apply(z1, sc1, sh1, residual, None, None, relu)
+        ctx.relu, ctx.two, ctx.has_res = relu, two, residual is not None
+        ctx.train1 = bn1["training"]
+        ctx.train2 = bn2["training"] if two else False
+        ctx.save_for_backward(z1, gamma1, m1, i1, z2, gamma2, m2, i2, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z1, gamma1, m1, i1, z2, gamma2, m2, i2, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        C = z1.shape[-1]
+        nvox = z1.numel() // C
+        lib = get_lib()
+        NB = lib.raw("stx_bn_reduce_blocks")()
+        part = _WS.get("bnred", NB * 3 * C, z1.device)
+        sums = torch.empty(3, C, dtype=torch.float32, device=z1.device)
+        _call("stx_bn_bwd_reduce", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
+              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(part), _p(sums), nvox, C, int(ctx.relu))
+        dz1 = torch.empty_like(z1)
+        dz2 = torch.empty_like(z2) if ctx.two else None
+        gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
+        use = sums
+        if not ctx.train1 or (ctx.two and not ctx.train2):
+            # running-stat BN: no centering terms (mixed train/eval pairs are not used by these models)
+            use = torch.zeros_like(sums)
+        _call("stx_bn_bwd_apply", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(gamma1), _p(z2) if ctx.two else None,
+              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(gamma2) if ctx.two else None, _p(use),
+              _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu))
+        if ctx.has_res and not ctx.relu:
+            gres = gy
+        return (dz1, sums[1], sums[0], dz2, sums[2] if ctx.two else None, sums[0] if ctx.two else None, gres,
+                None, None, None)
+
+
+# --------------------------------------------------------------------------------------- cost volume
+def _cv_shapes(Lg, Lc, num_groups):
+    ref = Lg if Lg is not None else Lc
+    B, _, H, W = ref.shape
+    Cg = Lg.shape[1] if Lg is not None else 0
+    Cc = Lc.shape[1] if Lc is not None else 0
+    G = num_groups if Lg is not None else 0
+    return B, H, W, Cg, G, Cc
+
+
+def cost_volume_forward(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True, scale=None):
+    for n, t in (("ref gwc", Lg), ("tgt gwc", Rg), ("ref concat", Lc), ("tgt concat", Rc)):
+        _chk(t, n, 4)
+    B, H, W, Cg, G, Cc = _cv_shapes(Lg, Lc, num_groups)
+    if G:
+        assert Cg % G == 0   # reference models/GwcNet/submodule.py:46
+    vol = torch.empty(B, maxdisp, H, W, G + 2 * Cc, dtype=torch.float32, device=(Lg if Lg is not None else Lc).device)
+    _call("stx_cost_volume_fwd", _p(Lg), _p(Rg), Cg, G, _p(Lc), _p(Rc), Cc, _p(scale), _p(vol), B, H, W, maxdisp,
+          int(mask_left))
+    return vol
+
+
+class CostVolumeFn(torch.autograd.Function):
+    """Fused gwc + concat volume, NDHWC output [B, D, H, W, G + 2*Cc]."""
+
+    @staticmethod
+    def forward(ctx, Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left):
+        ctx.save_for_backward(Lg, Rg)
+        ctx.cfg = (maxdisp, num_groups, mask_left, None if Lc is None else Lc.shape)
+        return cost_volume_forward(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left)
+
+    @staticmethod
+    def backward(ctx, gvol):
+        Lg, Rg = ctx.saved_tensors
+        maxdisp, num_groups, mask_left, cshape = ctx.cfg
+        gvol = gvol.contiguous()
+        B, D, H, W, CT = gvol.shape
+        Cg = Lg.shape[1] if Lg is not None else 0
+        G = num_groups if Lg is not None else 0
+        Cc = cshape[1] if cshape is not None else 0
+        gLg = torch.empty_like(Lg) if G else None
+        gRg = torch.empty_like(Rg) if G else None
+        gLc = gvol.new_empty(cshape) if Cc else None
+        gRc = gvol.new_empty(cshape) if Cc else None
+        _call("stx_cost_volume_bwd", _p(gvol), _p(Lg), _p(Rg), Cg, G, Cc, _p(gLg), _p(gRg), _p(gLc), _p(gRc), B, H, W,
+              D, int(mask_left))
+        return gLg, gRg, gLc, gRc, None, None, None
+
+
+def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
+    ts = [t.contiguous() if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        return CostVolumeFn.apply(*ts, maxdisp, num_groups, mask_left)
+    return cost_volume_forward(*ts, maxdisp, num_groups, mask_left)
+
+
+# --------------------------------------------------------------------------------------- head
+class HeadFn(torch.autograd.Function):
+    """trilinear upsample -> softmax over D -> soft-argmin, fused. cost: [B, D', H', W'] dense."""
+
+    @staticmethod
+    def forward(ctx, cost, maxdisp, H, W):
+        _chk(cost, "cost", 4)
+        B, Dc, Hc, Wc = cost.shape
+        disp = torch.empty(B, H, W, dtype=torch.float32, device=cost.device)
+        stats = torch.empty(B, H, W, 2, dtype=torch.float32, device=cost.device)
+        _call("stx_head_fwd", _p(cost), _p(disp), _p(stats), B, Dc, Hc, Wc, maxdisp, H, W)
+        ctx.save_for_backward(cost, disp, stats)
+        ctx.cfg = (maxdisp, H, W)
+        return disp
+
+    @staticmethod
+    def backward(ctx, g):
+        cost, disp, stats = ctx.saved_tensors
+        maxdisp, H, W = ctx.cfg
+        B, Dc, Hc, Wc = cost.shape
+        gc = torch.empty_like(cost)
+        _call("stx_head_bwd", _p(g.contiguous()), _p(cost), _p(disp), _p(stats), _p(gc), B, Dc, Hc, Wc, maxdisp, H, W)
+        return gc, None, None, None
+
+
+def regression_head(cost, maxdisp, H, W):
+    """cost [B, D', H', W'] (or [B,1,D',H',W'] / NDHWC with C=1) -> disparity [B, H, W]."""
+    if cost.dim() == 5:
+        cost = cost.reshape(cost.shape[0], *_squeeze_c(cost))
+    return HeadFn.apply(cost.contiguous(), maxdisp, H, W)
+
+
+def _squeeze_c(cost):
+    """Shape of a 5-D single-channel cost ([B,1,D,H,W] or [B,D,H,W,1]) without the channel axis."""
+    if cost.shape[1] == 1:
+        return tuple(cost.shape[2:])
+    if cost.shape[-1] == 1:
+        return tuple(cost.shape[1:4])
+    raise StxError(f"regression_head: expected a single-channel cost, got {tuple(cost.shape)}")
+
+
+def softargmax(x, maxdisp, keepdim):
+    """sum_d d * x[b,d,h,w] (disparity_regression / disparityregression / softargmax estimator)."""
+    assert len(x.shape) == 4   # reference models/GwcNet/submodule.py:24
+    _chk(x.contiguous(), "x", 4)
+    x = x.contiguous()
+    B, D, H, W = x.shape
+    if D != maxdisp:
+        raise StxError(f"disparity_regression: volume has {D} disparities, maxdisp={maxdisp}")
+    if torch.is_grad_enabled() and x.requires_grad:
+        # linear map: gradient is d broadcast -- keep autograd simple with a tiny custom function
+        out = _SoftArgmaxFn.apply(x)
+    else:
+        out = torch.empty(B, H, W, dtype=torch.float32, device=x.device)
+        _call("stx_softargmax_fwd", _p(x), _p(out), B, D, H * W)
+    return out.unsqueeze(1) if keepdim else out
+
+
+class _SoftArgmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, D, H, W = x.shape
+        out = torch.empty(B, H, W, dtype=torch.float32, device=x.device)
+        _call("stx_softargmax_fwd", _p(x), _p(out), B, D, H * W)
+        ctx.D = D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d = torch.arange(ctx.D, dtype=g.dtype, device=g.device).view(1, ctx.D, 1, 1)
+        return g.unsqueeze(1) * d
+
+
+def argmax_disparity(x):
+    _chk(x.contiguous(), "x", 4)
+    x = x.contiguous()
+    B, D, H, W = x.shape
+    out = torch.empty(B, 1, H, W, dtype=torch.int64, device=x.device)
+    _call("stx_argmax_fwd", _p(x), _p(out), B, D, H * W)
+    return out
+
+
+def softmax_over_d(x):
+    """x [B, D, H, W] -> softmax over D."""
+    _chk(x, "x", 4)
+    B, D, H, W = x.shape
+    y = torch.empty_like(x)
+    _call("stx_softmax_d_fwd", _p(x), _p(y), B, D, H * W)
+    return y

@@ -1,0 +1,70 @@
+"""Small host utilities: deterministic synthetic weights/inputs (bit-identical on every machine,
+independent of torch's RNG) used by bench.py, smoke() and the golden fixtures."""
+import zlib
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def hash_uniform(seed, stream, n):
+    """n floats in [0,1): splitmix64 of (counter, seed, stream) -> top 24 bits."""
+    with np.errstate(over="ignore"):
+        x = np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        x = x + np.uint64(seed) * np.uint64(0xD1B54A32D192ED03) + np.uint64(stream) * np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return ((x >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / (1 << 24))
+
+
+def synthetic_tensor(shape, seed, stream=0, lo=-1.7320508, hi=1.7320508):
+    """Uniform tensor with (by default) zero mean and unit variance, like a normalised image."""
+    n = int(np.prod(shape))
+    u = hash_uniform(seed, stream, n)
+    return torch.from_numpy((u * np.float32(hi - lo) + np.float32(lo)).reshape(shape))
+
+
+def fill_state_dict(sd, seed=1234, head_gain=4.0, gain2d=0.5, gain3d=0.85):
+    """In-place deterministic fill of a model state-dict: He-like uniform conv/linear
+    weights, BN gamma in [0.5,1.5), beta / running_mean in +-0.1, running_var in [0.5,1.5).
+    `head_gain` scales the single-channel classifier convs (`classif*.2.weight`) so that the
+    softmax over disparities is moderately peaky (random nets otherwise regress ~ (D-1)/2
+    everywhere and hide errors; much larger gains turn the head into an argmax whose output flips
+    by whole bins on fp32 rounding noise)."""
+    for name in sorted(sd.keys()):
+        t = sd[name]
+        if name.endswith("num_batches_tracked"):
+            t.zero_()
+            continue
+        u = torch.from_numpy(hash_uniform(seed, zlib.crc32(name.encode()), t.numel())).view(t.shape)
+        if name.endswith("running_mean"):
+            v = 0.1 * (2 * u - 1)
+        elif name.endswith("running_var"):
+            v = 0.5 + u
+        elif t.dim() == 1 and name.endswith(".weight"):
+            v = 0.5 + u
+        elif t.dim() == 1:
+            v = 0.1 * (2 * u - 1)
+        else:
+            # gains chosen so that activations stay O(1) through the ~25 residual 2-D blocks and the
+            # ~30 3-D layers with these (un-calibrated) BN statistics
+            fan_in = t.numel() // t.shape[0]
+            bound = (6.0 / fan_in) ** 0.5 * (gain3d if t.dim() == 5 else gain2d)
+            v = bound * (2 * u - 1)
+            if t.dim() == 5 and t.shape[0] == 1:
+                v = v * head_gain
+        t.copy_(v.to(t.dtype))
+    return sd
+
+
+def state_dict_digest(sd):
+    """Order-independent CRC of all tensors (to check that two boxes filled identical weights)."""
+    c = 0
+    for name in sorted(sd.keys()):
+        c = zlib.crc32(name.encode(), c)
+        c = zlib.crc32(sd[name].detach().cpu().contiguous().numpy().tobytes(), c)
+    return c

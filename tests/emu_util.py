@@ -36,3 +36,30 @@ def ndhwc(t):
 def ncdhw(t):
     """dense [B,D,H,W,C] -> [B,C,D,H,W] contiguous copy."""
     return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+class emu_product_path:
+    """Context manager (tests only): run the *product* host code (ops.py / aggregation.py / models)
+    against the host-emulator build of the kernels with CPU tensors, by monkeypatching the three
+    device-specific hooks of stereo_toolbox_amd.ops.  Lets the whole autograd wiring be checked
+    against the oracle without a GPU.  Nothing in the product references this."""
+
+    def __enter__(self):
+        from stereo_toolbox_amd import ops
+        self.ops = ops
+        self.saved = (ops.get_lib, ops._chk, ops._stream)
+        lib = emu_lib()
+        ops.get_lib = lambda: lib
+
+        def chk(t, name, dims=None):
+            if t is None:
+                return
+            assert t.dtype == torch.float32 and t.is_contiguous(), name
+            assert dims is None or t.dim() == dims, name
+        ops._chk = chk
+        ops._stream = lambda: None
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.get_lib, self.ops._chk, self.ops._stream = self.saved
+        return False

@@ -214,6 +214,7 @@ inline void run_grid(dim3 grid, dim3 block, size_t shmem, F body) {
     const unsigned nt = block.x * block.y * block.z;
     const size_t STK = 256 * 1024;
     if (nt > 1024) { fprintf(stderr, "hipemu: block too large\n"); abort(); }
+    if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of dynamic LDS exceeds the 160 KiB of a gfx950 CU\n", shmem); abort(); }
     s.nthreads = nt;
     if (s.fibers.size() < nt) s.fibers.resize(nt);
     if (s.stacks.size() < nt * STK) s.stacks.resize(nt * STK);

@@ -1,0 +1,327 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle / stock fp32 torch ops.
+
+Runs on the host emulator build (CPU, default) and on the real gfx950 library (-m gpu).
+Tolerances: builders/estimators ~1e-6 (fp32 rounding only), MFMA convolutions 1e-4 relative to the
+output magnitude (K up to 27*128 fp32 products, different summation order than torch).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_oracle as O
+from tests.backends import be, ndhwc, ncdhw, ptr  # noqa: F401
+
+
+def _close(got, ref, rtol=1e-4, atol=1e-5):
+    err = (got.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= atol + rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------ cost volume
+CV_CASES = [
+    # B, Cg, G, Cc, H, W, D, mask_left
+    (2, 16, 4, 0, 3, 11, 6, 1),       # gwc only, tiny (SURVEY 8c fixture shape)
+    (1, 320, 40, 12, 2, 37, 20, 1),   # GwcNet_GC channel config, ragged W and D
+    (1, 0, 0, 32, 3, 21, 18, 1),      # PSMNet concat
+    (1, 0, 0, 32, 3, 21, 18, 0),      # ACVNet concat (left half unmasked)
+    (1, 64, 8, 4, 2, 40, 48, 1),      # D' = 48 > W tile
+]
+
+
+@pytest.mark.parametrize("case", CV_CASES)
+def test_cost_volume_fwd_bwd(be, case):
+    B, Cg, G, Cc, H, W, D, ml = case
+    torch.manual_seed(1)
+    Lg = torch.randn(B, Cg, H, W) if G else None
+    Rg = torch.randn(B, Cg, H, W) if G else None
+    Lc = torch.randn(B, Cc, H, W) if Cc else None
+    Rc = torch.randn(B, Cc, H, W) if Cc else None
+    CT = G + 2 * Cc
+    leaves = [t.clone().requires_grad_() if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    parts = []
+    if G:
+        parts.append(O.build_gwc_volume(leaves[0], leaves[1], D, G))
+    if Cc:
+        parts.append(O.build_concat_volume(leaves[2], leaves[3], D, mask_left=bool(ml)))
+    ref = torch.cat(parts, 1)
+    dLg, dRg, dLc, dRc = (be.dev(t) for t in (Lg, Rg, Lc, Rc))
+    vol = be.empty(B, D, H, W, CT)
+    be.call("stx_cost_volume_fwd", ptr(dLg), ptr(dRg), Cg, G, ptr(dLc), ptr(dRc), Cc, None, ptr(vol), B, H, W, D, ml)
+    _close(ncdhw(vol), ref.detach(), rtol=1e-6, atol=1e-6)
+
+    gv = torch.randn(B, D, H, W, CT)
+    ref.backward(ncdhw(gv))
+    dgv = be.dev(gv)
+    outs = [be.empty(*t.shape) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    be.call("stx_cost_volume_bwd", ptr(dgv), ptr(dLg), ptr(dRg), Cg, G, Cc, ptr(outs[0]), ptr(outs[1]),
+            ptr(outs[2]), ptr(outs[3]), B, H, W, D, ml)
+    for o, leaf in zip(outs, leaves):
+        if o is not None:
+            _close(o, leaf.grad, rtol=2e-6, atol=1e-5)
+
+
+def test_cost_volume_scale_operand(be):
+    """ACVNet/acv.py:196: softmax(att, dim=2) * concat_volume fused as the `scale` operand."""
+    torch.manual_seed(2)
+    B, Cc, H, W, D = 1, 8, 2, 19, 7
+    Lc, Rc = torch.randn(B, Cc, H, W), torch.randn(B, Cc, H, W)
+    att = torch.randn(B, 1, D, H, W)
+    ref = F.softmax(att, dim=2) * O.build_concat_volume(Lc, Rc, D, mask_left=False)
+    datt = be.dev(att)
+    prob = be.empty(B, D, H, W)
+    be.call("stx_softmax_d_fwd", ptr(datt), ptr(prob), B, D, H * W)
+    vol = be.empty(B, D, H, W, 2 * Cc)
+    be.call("stx_cost_volume_fwd", None, None, 0, 0, ptr(be.dev(Lc)), ptr(be.dev(Rc)), Cc, ptr(prob), ptr(vol),
+            B, H, W, D, 0)
+    _close(ncdhw(vol), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_cost_volume_rejects_bad_groups(be):
+    from stereo_toolbox_amd._capi import StxError
+    t = be.empty(1, 10, 2, 8, fill=0.0)
+    vol = be.empty(1, 4, 2, 8, 4)
+    with pytest.raises(StxError):   # C % num_groups != 0, reference assert GwcNet/submodule.py:46
+        be.call("stx_cost_volume_fwd", ptr(t), ptr(t), 10, 4, None, None, 0, None, ptr(vol), 1, 2, 8, 4, 1)
+
+
+# ------------------------------------------------------------------------------ head / estimators
+@pytest.mark.parametrize("case", [(1, 4, 5, 7, 16, 20, 28, 5.0), (2, 12, 6, 9, 48, 24, 36, 3.0), (1, 5, 4, 6, 17, 13, 22, 4.0)])
+def test_head_fwd_bwd(be, case):
+    B, Dc, Hc, Wc, D, H, W, gain = case
+    torch.manual_seed(3)
+    cost = (torch.randn(B, 1, Dc, Hc, Wc) * gain).requires_grad_()
+    ref = O.regression_head(cost, D, H, W)
+    dcost = be.dev(cost.detach())
+    disp, stats = be.empty(B, H, W), be.empty(B, H, W, 2)
+    be.call("stx_head_fwd", ptr(dcost), ptr(disp), ptr(stats), B, Dc, Hc, Wc, D, H, W)
+    assert (disp.cpu() - ref.detach()).abs().max().item() < 1e-4   # disparity parity bar is 1e-3
+    g = torch.randn(B, H, W)
+    ref.backward(g)
+    gc = be.empty(B, 1, Dc, Hc, Wc)
+    be.call("stx_head_bwd", ptr(be.dev(g)), ptr(dcost), ptr(disp), ptr(stats), ptr(gc), B, Dc, Hc, Wc, D, H, W)
+    _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_estimators(be):
+    torch.manual_seed(4)
+    x = torch.softmax(torch.randn(2, 16, 6, 10) * 3, 1)
+    flat = torch.full((2, 16, 6, 10), 1.0 / 16)
+    for t in (x, flat):
+        d = be.dev(t)
+        o = be.empty(2, 6, 10)
+        be.call("stx_softargmax_fwd", ptr(d), ptr(o), 2, 16, 60)
+        _close(o, O.disparity_regression(t, 16), rtol=1e-6, atol=1e-6)
+        a = be.empty(2, 6, 10, dtype=torch.int64)
+        be.call("stx_argmax_fwd", ptr(d), ptr(a), 2, 16, 60)
+        assert torch.equal(a.cpu(), O.argmax_disparity_estimator(t, 16).squeeze(1))
+    z = torch.randn(2, 16, 6, 10)
+    y = be.empty(2, 16, 6, 10)
+    be.call("stx_softmax_d_fwd", ptr(be.dev(z)), ptr(y), 2, 16, 60)
+    _close(y, torch.softmax(z, 1), rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------ convolutions
+def pack(be, w, mode):
+    A, Bd = w.shape[0], w.shape[1]
+    T = w[0, 0].numel()
+    K, N = (Bd, A) if mode == 0 else (A, Bd)
+    n = be.raw("stx_conv3d_packed_floats")(K, N, T)
+    wp = be.empty(n)
+    be.call("stx_conv3d_pack_weight", ptr(be.dev(w)), ptr(wp), A, Bd, T, mode)
+    return wp
+
+
+def run_conv(be, x, w, ks, stride, scale=None, bias=None, res=None, relu=0, stats=False, mode=0, cout=None):
+    B, Cin, D, H, W = x.shape
+    Cout = cout if cout is not None else w.shape[0]
+    wp = pack(be, w, mode)
+    pad = ks // 2
+    Do, Ho, Wo = [(d + 2 * pad - ks) // stride + 1 for d in (D, H, W)]
+    out = be.empty(B, Do, Ho, Wo, Cout)
+    nb = be.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+    st = be.empty(B * nb, 2, Cout) if stats else None
+    xl = be.dev(ndhwc(x))
+    rl = be.dev(ndhwc(res)) if res is not None else None
+    be.call("stx_conv3d_fwd", ptr(xl), ptr(wp), ptr(out), ptr(be.dev(scale)), ptr(be.dev(bias)), ptr(rl), ptr(st),
+            B, D, H, W, Cin, Cout, ks, stride, relu)
+    return ncdhw(out).cpu(), (st.cpu() if stats else None)
+
+
+CONV_CASES = [
+    # B, Cin, Cout, D, H, W, ks, stride
+    (1, 32, 32, 3, 5, 37, 3, 1),
+    (2, 32, 64, 4, 6, 40, 3, 2),
+    (1, 64, 32, 2, 3, 33, 3, 1),
+    (1, 40, 32, 2, 2, 20, 3, 1),     # ACVNet dres1_att_ (Cin=40 -> 8-channel K chunks)
+    (1, 32, 1, 2, 4, 35, 3, 1),      # classifier tail Conv3d(32->1)
+    (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
+    (1, 64, 128, 4, 4, 24, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_fwd(be, case):
+    B, Cin, Cout, D, H, W, ks, s = case
+    torch.manual_seed(5)
+    x = torch.randn(B, Cin, D, H, W)
+    w = torch.randn(Cout, Cin, ks, ks, ks) * 0.1
+    ref = F.conv3d(x, w, None, s, ks // 2)
+    got, st = run_conv(be, x, w, ks, s, stats=True)
+    _close(got, ref)
+    _close(st[:, 0].sum(0), ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    _close(st[:, 1].sum(0), (ref ** 2).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    sc, bs, res = torch.rand(Cout) + 0.5, torch.randn(Cout), torch.randn_like(ref)
+    got2, _ = run_conv(be, x, w, ks, s, sc, bs, res, 1)
+    ref2 = F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res)
+    _close(got2, ref2)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 32, 2, 3, 33), (2, 128, 64, 2, 4, 20), (1, 32, 32, 1, 2, 40)])
+def test_deconv3d_fwd(be, case):
+    B, Cin, Cout, D, H, W = case
+    torch.manual_seed(6)
+    x = torch.randn(B, Cin, D, H, W)
+    w = torch.randn(Cin, Cout, 3, 3, 3) * 0.1
+    ref = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    wp = pack(be, w, 2)
+    out = be.empty(B, 2 * D, 2 * H, 2 * W, Cout)
+    nb = be.raw("stx_deconv3d_fwd_blocks")(D, H, W)
+    st = be.empty(B * nb, 2, Cout)
+    xl = be.dev(ndhwc(x))
+    be.call("stx_deconv3d_fwd", ptr(xl), ptr(wp), ptr(out), None, None, None, ptr(st), B, D, H, W, Cin, Cout,
+            2 * D, 2 * H, 2 * W, 0)
+    _close(ncdhw(out), ref)
+    _close(st.cpu()[:, 0].sum(0), ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    sc, bs, res = torch.rand(Cout) + 0.5, torch.randn(Cout), torch.randn_like(ref)
+    rl = be.dev(ndhwc(res))
+    be.call("stx_deconv3d_fwd", ptr(xl), ptr(wp), ptr(out), ptr(be.dev(sc)), ptr(be.dev(bs)), ptr(rl), None,
+            B, D, H, W, Cin, Cout, 2 * D, 2 * H, 2 * W, 1)
+    _close(ncdhw(out), F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res))
+
+
+def test_dgrad_via_repacked_weights(be):
+    torch.manual_seed(7)
+    # stride-1 conv dgrad = stride-1 conv of dy with flipped/transposed weights (pack mode 1)
+    x = torch.randn(1, 32, 3, 4, 33, requires_grad=True)
+    w = torch.randn(64, 32, 3, 3, 3) * 0.1
+    y = F.conv3d(x, w, None, 1, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got, _ = run_conv(be, gy, w, 3, 1, mode=1, cout=32)
+    _close(got, x.grad)
+    # stride-2 conv dgrad = transposed-conv kernel on the conv weight (pack mode 2)
+    x = torch.randn(1, 32, 4, 4, 40, requires_grad=True)
+    y = F.conv3d(x, w, None, 2, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    wp = pack(be, w, 2)
+    out = be.empty(1, 4, 4, 40, 32)
+    be.call("stx_deconv3d_fwd", ptr(be.dev(ndhwc(gy))), ptr(wp), ptr(out), None, None, None, None, 1, 2, 2, 20, 64, 32,
+            4, 4, 40, 0)
+    _close(ncdhw(out), x.grad)
+    # transposed-conv dgrad = stride-2 conv of dy with the deconv weight read as [Cout'][Cin'] (mode 0)
+    x = torch.randn(1, 64, 2, 2, 20, requires_grad=True)
+    wt = torch.randn(64, 32, 3, 3, 3) * 0.1
+    y = F.conv_transpose3d(x, wt, None, stride=2, padding=1, output_padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got, _ = run_conv(be, gy, wt, 3, 2, mode=0, cout=64)
+    _close(got, x.grad)
+
+
+def run_wgrad(be, fine, coarse, ks, stride):
+    B, CF, Df, Hf, Wf = fine.shape
+    _, CC, Dc, Hc, Wc = coarse.shape
+    n = be.raw("stx_conv3d_wgrad_workspace_floats")(B, Dc, Hc, Wc, CF, CC, ks, stride)
+    ws = be.empty(n)
+    dw = be.empty(CC, CF, ks ** 3)
+    be.call("stx_conv3d_wgrad", ptr(be.dev(ndhwc(fine))), ptr(be.dev(ndhwc(coarse))), ptr(dw), ptr(ws), B, Df, Hf, Wf,
+            CF, Dc, Hc, Wc, CC, ks, stride)
+    return dw.cpu()
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1)])
+def test_conv3d_wgrad(be, case):
+    B, Cin, Cout, D, H, W, ks, s = case
+    torch.manual_seed(8)
+    x = torch.randn(B, Cin, D, H, W)
+    w = (torch.randn(Cout, Cin, ks, ks, ks) * 0.1).requires_grad_()
+    y = F.conv3d(x, w, None, s, ks // 2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _close(run_wgrad(be, x, gy, ks, s).view_as(w), w.grad)
+
+
+def test_deconv3d_wgrad(be):
+    torch.manual_seed(9)
+    x = torch.randn(1, 64, 2, 3, 20)
+    w = (torch.randn(64, 32, 3, 3, 3) * 0.1).requires_grad_()
+    y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    _close(run_wgrad(be, gy, x, 3, 2).view_as(w), w.grad)
+
+
+# ------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("case", [(1000, 32, False, True, False), (777, 64, True, True, False),
+                                  (500, 32, False, False, True), (640, 128, False, True, True)])
+def test_bn_train_fwd_bwd(be, case):
+    nvox, C, two, relu, resid = case
+    torch.manual_seed(10)
+    z1 = (torch.randn(nvox, C) * 2 + 1).requires_grad_()
+    z2 = (torch.randn(nvox, C) + 0.5).requires_grad_() if (two or resid) else None
+    g1, b1 = (torch.rand(C) + 0.5).requires_grad_(), torch.randn(C).requires_grad_()
+    g2, b2 = (torch.rand(C) + 0.5).requires_grad_(), torch.randn(C).requires_grad_()
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.batch_norm(z1, rm_ref, rv_ref, g1, b1, True, 0.1, 1e-5)
+    if two:
+        yr = yr + F.batch_norm(z2, None, None, g2, b2, True, 0.1, 1e-5)
+    elif resid:
+        yr = yr + z2
+    if relu:
+        yr = F.relu(yr)
+
+    def fin(z, g, b, rmd, rvd):
+        chunks = z.detach().chunk(7)
+        part = be.dev(torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks]))
+        outs = [be.empty(C) for _ in range(4)]
+        be.call("stx_bn_finalize", ptr(part), len(chunks), C, float(nvox), ptr(be.dev(g.detach())),
+                ptr(be.dev(b.detach())), ptr(rmd), ptr(rvd), 0.1, 1e-5, *[ptr(o) for o in outs])
+        return outs
+
+    drm, drv = be.dev(rm), be.dev(rv)
+    sc1, sh1, m1, i1 = fin(z1, g1, b1, drm, drv)
+    if two:
+        sc2, sh2, m2, i2 = fin(z2, g2, b2, None, None)
+    dz1_in = be.dev(z1.detach())
+    dz2_in = be.dev(z2.detach()) if z2 is not None else None
+    out = be.empty(nvox, C)
+    be.call("stx_bn_apply", ptr(dz1_in), ptr(sc1), ptr(sh1), ptr(dz2_in), ptr(sc2) if two else None,
+            ptr(sh2) if two else None, ptr(out), nvox, C, int(relu))
+    _close(out, yr.detach(), rtol=1e-5, atol=1e-5)
+    _close(drm, rm_ref, rtol=1e-5, atol=1e-6)
+    _close(drv, rv_ref, rtol=1e-5, atol=1e-6)
+
+    gy = torch.randn(nvox, C)
+    yr.backward(gy)
+    dgy = be.dev(gy)
+    NB = be.raw("stx_bn_reduce_blocks")()
+    part, sums = be.empty(NB, 3, C), be.empty(3, C)
+    be.call("stx_bn_bwd_reduce", ptr(dgy), ptr(out), ptr(dz1_in), ptr(m1), ptr(i1), ptr(dz2_in) if two else None,
+            ptr(m2) if two else None, ptr(i2) if two else None, ptr(part), ptr(sums), nvox, C, int(relu))
+    dz1 = be.empty(nvox, C)
+    dz2 = be.empty(nvox, C) if two else None
+    gout = be.empty(nvox, C) if resid else None
+    be.call("stx_bn_bwd_apply", ptr(dgy), ptr(out), ptr(dz1_in), ptr(m1), ptr(i1), ptr(be.dev(g1.detach())),
+            ptr(dz2_in) if two else None, ptr(m2) if two else None, ptr(i2) if two else None,
+            ptr(be.dev(g2.detach())) if two else None, ptr(sums), ptr(dz1), ptr(dz2), ptr(gout), nvox, C, int(relu))
+    _close(dz1, z1.grad, rtol=1e-4, atol=1e-5)
+    _close(sums[1], g1.grad, rtol=1e-4, atol=1e-4)
+    _close(sums[0], b1.grad, rtol=1e-4, atol=1e-4)
+    if two:
+        _close(dz2, z2.grad, rtol=1e-4, atol=1e-5)
+        _close(sums[2], g2.grad, rtol=1e-4, atol=1e-4)
+    if resid:
+        _close(gout, z2.grad, rtol=1e-6, atol=1e-6)

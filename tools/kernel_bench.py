@@ -1,0 +1,167 @@
+"""Per-kernel timing of the C-ABI entry points at the GwcNet_GC 576x960, D=192 shapes (MI355X only).
+
+python tools/kernel_bench.py [--iters N] [--only substr] -> one JSON line per kernel with ms,
+TFLOP/s (true MACs x2) or GB/s (algorithmic bytes).  Used for profiling; bench.py is the contract.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereo_toolbox_amd._capi import get_lib  # noqa: E402
+
+lib = get_lib()
+dev = torch.device("cuda:0")
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def report(name, ms, flops=None, nbytes=None):
+    r = {"kernel": name, "ms": round(ms, 4)}
+    if flops:
+        r["TFLOPs"] = round(flops / ms / 1e9, 2)
+        r["mfma_frac"] = round(flops / ms / 1e9 / 157.3, 3)
+    if nbytes:
+        r["GBs"] = round(nbytes / ms / 1e6, 1)
+        r["hbm_frac"] = round(nbytes / ms / 1e6 / 8000.0, 3)
+    print(json.dumps(r), flush=True)
+
+
+def pack(w, mode):
+    A, Bd = w.shape[0], w.shape[1]
+    T = w[0, 0].numel()
+    K, N = (Bd, A) if mode == 0 else (A, Bd)
+    wp = torch.empty(lib.raw("stx_conv3d_packed_floats")(K, N, T), device=dev)
+    lib.call("stx_conv3d_pack_weight", P(w), P(wp), A, Bd, T, mode, stream())
+    return wp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--H", type=int, default=576)
+    ap.add_argument("--W", type=int, default=960)
+    ap.add_argument("--D", type=int, default=192)
+    a = ap.parse_args()
+    B, H4, W4, D4 = 1, a.H // 4, a.W // 4, a.D // 4
+    L = {0: (D4, H4, W4), 1: (D4 // 2, H4 // 2, W4 // 2), 2: (D4 // 4, H4 // 4, W4 // 4)}
+    it = a.iters
+
+    def want(n):
+        return a.only in n
+
+    if want("cost_volume"):
+        Lg, Rg = torch.randn(B, 320, H4, W4, device=dev), torch.randn(B, 320, H4, W4, device=dev)
+        Lc, Rc = torch.randn(B, 12, H4, W4, device=dev), torch.randn(B, 12, H4, W4, device=dev)
+        vol = torch.empty(B, D4, H4, W4, 64, device=dev)
+        nb = (Lg.numel() * 2 + Lc.numel() * 2 + vol.numel()) * 4
+        ms = timeit(lambda: lib.call("stx_cost_volume_fwd", P(Lg), P(Rg), 320, 40, P(Lc), P(Rc), 12, None, P(vol),
+                                     B, H4, W4, D4, 1, stream()), it)
+        report("cost_volume_fwd_gwcgc", ms, nbytes=nb)
+        g = [torch.empty_like(t) for t in (Lg, Rg, Lc, Rc)]
+        ms = timeit(lambda: lib.call("stx_cost_volume_bwd", P(vol), P(Lg), P(Rg), 320, 40, 12, P(g[0]), P(g[1]), P(g[2]),
+                                     P(g[3]), B, H4, W4, D4, 1, stream()), it)
+        report("cost_volume_bwd_gwcgc", ms, nbytes=nb + Lg.numel() * 8)
+        Lp, Rp = torch.randn(B, 32, H4, W4, device=dev), torch.randn(B, 32, H4, W4, device=dev)
+        ms = timeit(lambda: lib.call("stx_cost_volume_fwd", None, None, 0, 0, P(Lp), P(Rp), 32, None, P(vol), B, H4, W4,
+                                     D4, 1, stream()), it)
+        report("cost_volume_fwd_psm_concat", ms, nbytes=(Lp.numel() * 2 + vol.numel()) * 4)
+        del Lg, Rg, vol, g
+
+    convs = [  # name, level_in, Cin, Cout, ks, stride
+        ("conv_64_32_L0", 0, 64, 32, 3, 1), ("conv_32_32_L0", 0, 32, 32, 3, 1), ("conv_32_64_s2_L0", 0, 32, 64, 3, 2),
+        ("conv_64_64_L1", 1, 64, 64, 3, 1), ("conv_64_128_s2_L1", 1, 64, 128, 3, 2), ("conv_128_128_L2", 2, 128, 128, 3, 1),
+        ("conv1x1_64_64_L1", 1, 64, 64, 1, 1), ("conv1x1_32_32_L0", 0, 32, 32, 1, 1), ("conv_32_1_L0", 0, 32, 1, 3, 1),
+    ]
+    for name, lv, Cin, Cout, ks, s in convs:
+        if not want(name):
+            continue
+        D, Hh, Ww = L[lv]
+        x = torch.randn(B, D, Hh, Ww, Cin, device=dev)
+        w = torch.randn(Cout, Cin, ks, ks, ks, device=dev) * 0.05
+        wp = pack(w, 0)
+        Do, Ho, Wo = [(d + 2 * (ks // 2) - ks) // s + 1 for d in (D, Hh, Ww)]
+        out = torch.empty(B, Do, Ho, Wo, Cout, device=dev)
+        nblk = lib.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+        st = torch.empty(B * nblk, 2, Cout, device=dev)
+        fl = 2.0 * B * Do * Ho * Wo * Cout * Cin * ks ** 3
+        ms = timeit(lambda: lib.call("stx_conv3d_fwd", P(x), P(wp), P(out), None, None, None, P(st), B, D, Hh, Ww, Cin,
+                                     Cout, ks, s, 0, stream()), it)
+        report(name + "_fwd", ms, flops=fl)
+        if Cout % 32 == 0 and Cin % 32 == 0:
+            n = lib.raw("stx_conv3d_wgrad_workspace_floats")(B, Do, Ho, Wo, Cin, Cout, ks, s)
+            ws = torch.empty(n, device=dev)
+            dw = torch.empty(Cout, Cin, ks ** 3, device=dev)
+            ms = timeit(lambda: lib.call("stx_conv3d_wgrad", P(x), P(out), P(dw), P(ws), B, D, Hh, Ww, Cin, Do, Ho, Wo,
+                                         Cout, ks, s, stream()), it)
+            report(name + "_wgrad", ms, flops=fl)
+        del x, out
+
+    for name, lv, Cin, Cout in [("deconv_128_64_L2", 2, 128, 64), ("deconv_64_32_L1", 1, 64, 32)]:
+        if not want(name):
+            continue
+        D, Hh, Ww = L[lv]
+        x = torch.randn(B, D, Hh, Ww, Cin, device=dev)
+        w = torch.randn(Cin, Cout, 3, 3, 3, device=dev) * 0.05
+        wp = pack(w, 2)
+        out = torch.empty(B, 2 * D, 2 * Hh, 2 * Ww, Cout, device=dev)
+        fl = 2.0 * B * D * Hh * Ww * Cout * Cin * 27
+        ms = timeit(lambda: lib.call("stx_deconv3d_fwd", P(x), P(wp), P(out), None, None, None, None, B, D, Hh, Ww, Cin,
+                                     Cout, 2 * D, 2 * Hh, 2 * Ww, 0, stream()), it)
+        report(name + "_fwd", ms, flops=fl)
+
+    if want("bn"):
+        D, Hh, Ww = L[0]
+        nvox, C = B * D * Hh * Ww, 32
+        z = torch.randn(nvox, C, device=dev)
+        y = torch.empty_like(z)
+        sc, sh = torch.rand(C, device=dev), torch.rand(C, device=dev)
+        ms = timeit(lambda: lib.call("stx_bn_apply", P(z), P(sc), P(sh), None, None, None, P(y), nvox, C, 1, stream()), it)
+        report("bn_apply_L0", ms, nbytes=z.numel() * 8)
+        NB = lib.raw("stx_bn_reduce_blocks")()
+        part, sums = torch.empty(NB, 3, C, device=dev), torch.empty(3, C, device=dev)
+        ms = timeit(lambda: lib.call("stx_bn_bwd_reduce", P(z), P(y), P(z), P(sc), P(sh), None, None, None, P(part),
+                                     P(sums), nvox, C, 1, stream()), it)
+        report("bn_bwd_reduce_L0", ms, nbytes=z.numel() * 12)
+        dz = torch.empty_like(z)
+        ms = timeit(lambda: lib.call("stx_bn_bwd_apply", P(z), P(y), P(z), P(sc), P(sh), P(sc), None, None, None, None,
+                                     P(sums), P(dz), None, None, nvox, C, 1, stream()), it)
+        report("bn_bwd_apply_L0", ms, nbytes=z.numel() * 16)
+
+    if want("head"):
+        cost = torch.randn(B, D4, H4, W4, device=dev) * 3
+        disp, stats = torch.empty(B, a.H, a.W, device=dev), torch.empty(B, a.H, a.W, 2, device=dev)
+        ms = timeit(lambda: lib.call("stx_head_fwd", P(cost), P(disp), P(stats), B, D4, H4, W4, a.D, a.H, a.W, stream()), it)
+        report("head_fwd", ms, nbytes=(cost.numel() + disp.numel()) * 4)
+        g, gc = torch.randn_like(disp), torch.empty_like(cost)
+        ms = timeit(lambda: lib.call("stx_head_bwd", P(g), P(cost), P(disp), P(stats), P(gc), B, D4, H4, W4, a.D, a.H,
+                                     a.W, stream()), it)
+        report("head_bwd", ms, nbytes=(cost.numel() * 2 + disp.numel() * 4) * 4)
+
+
+if __name__ == "__main__":
+    main()

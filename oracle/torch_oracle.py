@@ -285,6 +285,13 @@ def psmnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):
     cx = Ctx(sd, training)
     fl = features_psm(cx, left)
     fr = features_psm(cx, right)
+    out = psmnet_aggregate(cx, fl, fr, maxdisp, left.shape[2], left.shape[3])
+    return (out, cx) if return_ctx else out
+
+
+def psmnet_aggregate(cx, fl, fr, maxdisp, H, W):
+    """PSMNet/stackhourglass.py:111-161 from the 32-channel features onwards."""
+    training = cx.training
     cost = build_concat_volume(fl, fr, maxdisp // 4)
     cost0 = dres0(cx, cost)
     cost0 = dres1(cx, cost0) + cost0
@@ -297,14 +304,12 @@ def psmnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):
     cost1 = classif(cx, out1, "classif1")
     cost2 = classif(cx, out2, "classif2") + cost1
     cost3 = classif(cx, out3, "classif3") + cost2
-    H, W = left.shape[2], left.shape[3]
     pred3 = regression_head(cost3, maxdisp, H, W, keepdim=True)
     if training:
         pred1 = regression_head(cost1, maxdisp, H, W, keepdim=True)
         pred2 = regression_head(cost2, maxdisp, H, W, keepdim=True)
-        out = [pred1, pred2, pred3]
-        return (out, cx) if return_ctx else out
-    return (pred3, cx) if return_ctx else pred3
+        return [pred1, pred2, pred3]
+    return pred3
 
 
 def acv_patch_volume(sd, gwc_volume):

@@ -200,11 +200,13 @@ int bn_grid(size_t nquads) {
 
 }  // namespace
 
-extern "C" int stx_bn_reduce_blocks(void) { return BN_RED_BLOCKS; }
+extern "C" int stx_bn_reduce_blocks(void) {
+    stx_begin(); return BN_RED_BLOCKS; }
 
 extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    stx_begin();
     STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
                        gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
@@ -214,6 +216,7 @@ extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double c
 extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2,
                             const float* scale2, const float* shift2, float* out, long long nvox, int C, int relu,
                             void* stream) {
+    stx_begin();
     STX_REQUIRE(z1 && scale1 && shift1 && out && nvox > 0 && C > 0 && C % 4 == 0, "bn_apply: bad args (C=%d)", C);
     STX_REQUIRE(!scale2 || (z2 && shift2), "bn_apply: second affine needs z2 and shift2");
     const size_t nquads = (size_t)nvox * (C / 4);
@@ -225,6 +228,7 @@ extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* s
 extern "C" int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1,
                                  const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
                                  float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
+    stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && partials && sums && nvox > 0, "bn_bwd_reduce: null operand");
     STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
     STX_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
@@ -241,6 +245,7 @@ extern "C" int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1
                                 const float* invstd1, const float* gamma1, const float* z2, const float* mean2,
                                 const float* invstd2, const float* gamma2, const float* sums, float* dz1, float* dz2,
                                 float* gout, long long nvox, int C, int relu, void* stream) {
+    stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
     STX_REQUIRE(!relu || y, "bn_bwd_apply: relu mask needs y");
     const size_t nquads = (size_t)nvox * (C / 4);

@@ -514,6 +514,7 @@ extern "C" long long stx_conv3d_packed_floats(int K, int N, int T) {
 }
 
 extern "C" int stx_conv3d_pack_weight(const float* w, float* wp, int A, int Bd, int T, int mode, void* stream) {
+    stx_begin();
     STX_REQUIRE(w && wp && A > 0 && Bd > 0 && (T == 1 || T == 27), "conv3d_pack_weight: bad args");
     STX_REQUIRE(mode >= 0 && mode <= 2, "conv3d_pack_weight: mode %d", mode);
     const int K = (mode == 0) ? Bd : A, N = (mode == 0) ? A : Bd;
@@ -527,13 +528,16 @@ extern "C" int stx_conv3d_pack_weight(const float* w, float* wp, int A, int Bd, 
 
 // Number of workgroups (= rows of the `stats` partial slab) stx_conv3d_fwd launches per batch item.
 extern "C" int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo) {
+    stx_begin();
     return stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
 }
-extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) { return Di * stx_cdiv(Hi, 2) * stx_cdiv(Wi, 32); }
+extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) {
+    stx_begin(); return Di * stx_cdiv(Hi, 2) * stx_cdiv(Wi, 32); }
 
 extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
                               const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout,
                               int ks, int stride, int relu, void* stream) {
+    stx_begin();
     STX_REQUIRE(x && wp && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv3d_fwd: bad shape");
     STX_REQUIRE(Cin % 8 == 0 && Cout >= 1 && Cout <= 128, "conv3d_fwd: Cin=%d (need %%8) Cout=%d (need <=128)", Cin, Cout);
     STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1),
@@ -562,6 +566,7 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
 extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
                                 const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout,
                                 int Do, int Ho, int Wo, int relu, void* stream) {
+    stx_begin();
     STX_REQUIRE(x && wp && out && B > 0 && Di > 0 && Hi > 0 && Wi > 0, "deconv3d_fwd: bad shape");
     STX_REQUIRE(Cin % 32 == 0 && Cout >= 1 && Cout <= 64, "deconv3d_fwd: Cin=%d (need %%32) Cout=%d (need <=64)", Cin, Cout);
     STX_REQUIRE(Do <= 2 * Di && Do >= 2 * Di - 1 && Ho <= 2 * Hi && Ho >= 2 * Hi - 1 && Wo <= 2 * Wi && Wo >= 2 * Wi - 1,
@@ -601,6 +606,7 @@ extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, in
 
 extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float* workspace, int B, int Df, int Hf,
                                 int Wf, int CF, int Dc, int Hc, int Wc, int CC, int ks, int stride, void* stream) {
+    stx_begin();
     STX_REQUIRE(f && c && dw && workspace && B > 0, "conv3d_wgrad: null operand");
     STX_REQUIRE(CF % 32 == 0 && CC % 32 == 0, "conv3d_wgrad: channel counts (%d, %d) must be multiples of 32", CF, CC);
     STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1), "conv3d_wgrad: ks/stride");

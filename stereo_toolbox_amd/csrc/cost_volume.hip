@@ -253,6 +253,7 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
 extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc,
                                    const float* Rc, int Cc, const float* scale, float* vol, int B, int H,
                                    int W, int D, int mask_left, void* stream) {
+    stx_begin();
     STX_REQUIRE(vol && B > 0 && H > 0 && W > 0 && D > 0, "cost_volume_fwd: bad shape B=%d H=%d W=%d D=%d", B, H, W, D);
     STX_REQUIRE(G >= 0 && Cc >= 0 && (G + Cc) > 0, "cost_volume_fwd: need G>0 or Cc>0");
     STX_REQUIRE(G % 4 == 0 && Cc % 4 == 0, "cost_volume_fwd: G (%d) and Cc (%d) must be multiples of 4", G, Cc);
@@ -286,6 +287,7 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
 extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc,
                                    float* gLg, float* gRg, float* gLc, float* gRc, int B, int H, int W, int D,
                                    int mask_left, void* stream) {
+    stx_begin();
     STX_REQUIRE(gvol && B > 0 && H > 0 && W > 0 && D > 0, "cost_volume_bwd: bad shape");
     STX_REQUIRE(G % 4 == 0 && Cc % 4 == 0 && (G + Cc) > 0, "cost_volume_bwd: bad channel counts");
     if (G) STX_REQUIRE(Lg && Rg && gLg && gRg && Cg % G == 0, "cost_volume_bwd: gwc operands missing");

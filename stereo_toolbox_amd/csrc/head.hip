@@ -202,6 +202,7 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 
 extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D,
                             int H, int W, void* stream) {
+    stx_begin();
     STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
     dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
     hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
@@ -211,6 +212,7 @@ extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B,
 
 extern "C" int stx_head_bwd(const float* gout, const float* cost, const float* disp, const float* stats,
                             float* gcost, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
+    stx_begin();
     STX_REQUIRE(gout && cost && disp && stats && gcost && B > 0, "head_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
     hipMemsetAsync(gcost, 0, (size_t)B * Dc * Hc * Wc * sizeof(float), st);
@@ -226,6 +228,7 @@ extern "C" int stx_head_bwd(const float* gout, const float* cost, const float* d
 }
 
 extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {
+    stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "softargmax_fwd: bad shape");
     hipLaunchKernelGGL(softargmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0,
                        (hipStream_t)stream, x, out, D, HW);
@@ -233,6 +236,7 @@ extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int 
 }
 
 extern "C" int stx_argmax_fwd(const float* x, long long* out, int B, int D, int HW, void* stream) {
+    stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "argmax_fwd: bad shape");
     hipLaunchKernelGGL(argmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0, (hipStream_t)stream, x,
                        out, D, HW);
@@ -240,6 +244,7 @@ extern "C" int stx_argmax_fwd(const float* x, long long* out, int B, int D, int 
 }
 
 extern "C" int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream) {
+    stx_begin();
     STX_REQUIRE(x && y && B > 0 && D > 0 && HW > 0, "softmax_d_fwd: bad shape");
     hipLaunchKernelGGL(softmax_d_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0, (hipStream_t)stream,
                        x, y, D, HW);

@@ -28,6 +28,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Records the message returned by stx_last_error() (thread local) and returns `code`.
 int stx_set_error(int code, const char* fmt, ...);
 int stx_check_launch(const char* what);
+// Drops any stale (sticky) HIP error left by other users of the runtime in this thread, so that
+// stx_check_launch reports only errors of the launch it follows.
+static inline void stx_begin() { (void)hipGetLastError(); }
 
 #define STX_REQUIRE(cond, ...)                                   \
     do {                                                         \

@@ -67,6 +67,10 @@ class PSMNet(nn.Module):
 
     def forward(self, left, right):
         fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+
+    def aggregate(self, fl, fr, H, W):
+        """Hot path: 32-channel features at 1/4 resolution -> disparity at (H, W)."""
         # concat volume built inline in the reference (stackhourglass.py:111-120)
         cost = ops.cost_volume(None, None, fl, fr, self.maxdisp // 4, 0, mask_left=True)
         cost0 = convbn_block(cost, self.dres0[0], relu=True)
@@ -79,7 +83,6 @@ class PSMNet(nn.Module):
         cost1 = _run_classifier(self.classif1, out1)
         cost2 = _run_classifier(self.classif2, out2, add=cost1)
         cost3 = _run_classifier(self.classif3, out3, add=cost2)
-        H, W = left.shape[2], left.shape[3]
         pred3 = ops.regression_head(cost3, self.maxdisp, H, W).unsqueeze(1)
         if self.training:
             pred1 = ops.regression_head(cost1, self.maxdisp, H, W).unsqueeze(1)

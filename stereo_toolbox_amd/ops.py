@@ -355,7 +355,8 @@ class HeadFn(torch.autograd.Function):
         maxdisp, H, W = ctx.cfg
         B, Dc, Hc, Wc = cost.shape
         gc = torch.empty_like(cost)
-        _call("stx_head_bwd", _p(g.contiguous()), _p(cost), _p(disp), _p(stats), _p(gc), B, Dc, Hc, Wc, maxdisp, H, W)
+        g = g.contiguous()      # keep the dense copy alive across the launch
+        _call("stx_head_bwd", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), B, Dc, Hc, Wc, maxdisp, H, W)
         return gc, None, None, None
 
 

@@ -21,9 +21,10 @@ def build_emu(force=False, verbose=False):
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(HERE, "hipemu.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs.append(os.path.join(HERE, "hipemu_impl.cpp"))
     objs, jobs = [], []
     for s in srcs:
-        o = os.path.join(OUT, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(OUT, os.path.splitext(os.path.basename(s))[0] + ".o")
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in [s] + deps)
         if force or not os.path.exists(o) or os.path.getmtime(o) < newest:

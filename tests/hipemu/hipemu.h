@@ -17,7 +17,6 @@
 // The product never loads the emulator build: stereo_toolbox_amd/_capi.py only
 // opens the gfx950 shared object. Only tests/ open libstx_emu.so.
 #pragma once
-#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -54,14 +53,18 @@ static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; 
 
 namespace hipemu {
 
+// Minimal x86-64 SysV context switch (tests/hipemu/hipemu_impl.cpp): saves the callee-saved
+// registers on the current stack, stores its stack pointer to *save_sp and resumes load_sp.
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;
     bool done = false;
     unsigned tid = 0;
 };
 
 struct State {
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
     std::vector<char> stacks;
     unsigned nthreads = 0;
@@ -82,12 +85,13 @@ extern "C" inline void hipemu_trampoline() {
     s.entry();
     s.fibers[s.cur].done = true;
     s.live--;
-    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+    hipemu_switch(&s.fibers[s.cur].sp, s.sched_sp);
+    abort();   // a finished fiber is never resumed
 }
 
 inline void yield_() {
     State& s = S();
-    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+    hipemu_switch(&s.fibers[s.cur].sp, s.sched_sp);
 }
 
 inline char* dyn_smem() { return S().dyn.data(); }
@@ -231,11 +235,13 @@ inline void run_grid(dim3 grid, dim3 block, size_t shmem, F body) {
         for (unsigned t = 0; t < nt; ++t) {
             Fiber& f = s.fibers[t];
             f.done = false; f.tid = t;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)t * STK;
-            f.ctx.uc_stack.ss_size = STK;
-            f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, (void (*)())hipemu_trampoline, 0);
+            uintptr_t top = (uintptr_t)(s.stacks.data() + (size_t)(t + 1) * STK);
+            top &= ~(uintptr_t)15;
+            void** sp = (void**)top;
+            *--sp = nullptr;                              // fake return address of the trampoline
+            *--sp = (void*)hipemu_trampoline;             // popped by hipemu_switch's `ret`
+            for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+            f.sp = (void*)sp;
         }
         unsigned remaining = nt;
         while (remaining) {
@@ -248,7 +254,7 @@ inline void run_grid(dim3 grid, dim3 block, size_t shmem, F body) {
                 threadIdx.y = (t / block.x) % block.y;
                 threadIdx.z = t / (block.x * block.y);
                 blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
-                swapcontext(&s.sched, &f.ctx);
+                hipemu_switch(&s.sched_sp, f.sp);
                 if (!f.done) remaining++;
             }
         }

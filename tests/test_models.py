@@ -1,0 +1,200 @@
+"""Model-level parity of the drop-in modules against the CPU oracle.
+
+* emu  (CPU, `-m "not gpu"`): the product host code (ops/aggregation/models, autograd wiring) driving
+  the host-emulator build of the kernels at tiny shapes;
+* hip  (`-m gpu`): the same modules on the real gfx950 library at 64x128 / 256x512.
+Tolerance on disparities: 1e-3 max-abs (BASELINE.json); gradients: 2e-3 of the tensor's max.
+"""
+import contextlib
+
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
+
+LOSS_W = (0.5, 0.5, 0.7, 1.0)
+
+
+class Env:
+    def __init__(self, name):
+        self.name = name
+        if name == "hip":
+            if not torch.cuda.is_available():
+                pytest.skip("no ROCm device")
+            self.device = torch.device("cuda:0")
+        else:
+            self.device = torch.device("cpu")
+
+    def ctx(self):
+        if self.name == "emu":
+            from tests.emu_util import emu_product_path
+            return emu_product_path()
+        return contextlib.nullcontext()
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def env(request):
+    return Env(request.param)
+
+
+def _filled(ctor, *a, **k):
+    m = ctor(*a, **k)
+    sd = m.state_dict()
+    fill_state_dict(sd)
+    m.load_state_dict(sd)
+    return m, {k_: v.clone() for k_, v in sd.items()}
+
+
+def _shape(env):
+    # (H, W, maxdisp, B)
+    return (16, 64, 32, 1) if env.name == "emu" else (64, 128, 64, 2)
+
+
+@pytest.mark.parametrize("concat", [True, False])
+def test_gwcnet_eval_parity(env, concat):
+    from stereo_toolbox_amd.models import GwcNet
+    H, W, D, B = _shape(env)
+    if env.name == "emu" and not concat:
+        pytest.skip("GwcNet_G differs from _GC only in the volume channels; covered on the GPU")
+    m, sd = _filled(GwcNet, D, concat)
+    m = m.to(env.device).eval()
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    with env.ctx(), torch.no_grad():
+        got = m(left.to(env.device), right.to(env.device)).cpu()
+    with torch.no_grad():
+        ref = O.gwcnet_forward(sd, left, right, D, concat)
+    assert got.shape == ref.shape == (B, H, W)
+    assert ref.std() > 0.5, "degenerate test output"
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def _check_grads(model, ref_sd, rtol=2e-3):
+    worst = 0.0
+    n = 0
+    for k, p in model.named_parameters():
+        r = ref_sd[k].grad
+        assert p.grad is not None and r is not None, k
+        err = (p.grad.cpu() - r).abs().max().item()
+        scale = r.abs().max().item()
+        worst = max(worst, err / (scale + 1e-8))
+        assert err <= rtol * scale + 1e-6, f"{k}: grad err {err:.3e} vs scale {scale:.3e}"
+        n += 1
+    return n, worst
+
+
+def test_gwcnet_gc_train_parity(env):
+    from stereo_toolbox_amd.models import GwcNet_GC
+    H, W, D, B = _shape(env)
+    m, sd = _filled(GwcNet_GC, D)
+    m = m.to(env.device).train()
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    gt = synthetic_tensor((B, H, W), 3, lo=0.0, hi=float(D - 2))
+    with env.ctx():
+        preds = m(left.to(env.device), right.to(env.device))
+        loss = O.smooth_l1_multi(preds, gt.to(env.device), D, LOSS_W)
+        loss.backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    rp, cx = O.gwcnet_forward(ref_sd, left, right, D, True, training=True, return_ctx=True)
+    rl = O.smooth_l1_multi(rp, gt, D, LOSS_W)
+    rl.backward()
+    assert isinstance(preds, list) and len(preds) == 4
+    # Train-mode BatchNorm re-normalises every layer with batch statistics, which amplifies fp32
+    # rounding differences between two correct implementations.  Calibrate the tolerance with an
+    # fp64 evaluation of the oracle: the product must be as close to it as the fp32 oracle is
+    # (x3 slack), and never worse than 5e-3 px; the eval-mode bar stays 1e-3 (test above).
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    with torch.no_grad():
+        rp64 = O.gwcnet_forward(sd64, left.double(), right.double(), D, True, training=True)
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c).abs().max().item()
+        e_orc = (b.detach().double() - c).abs().max().item()
+        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+    assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
+    n, worst = _check_grads(m, ref_sd)
+    assert n > 250
+    msd = m.state_dict()
+    for k, v in cx.new_stats.items():   # BN running statistics updated like torch's
+        assert (msd[k].cpu() - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item()), k
+    assert int(msd["dres0.0.1.num_batches_tracked"]) == 1
+
+
+def test_psmnet_aggregation_parity(env):
+    """PSMNet's 3-D path (PSM-style hourglasses with pre/post skips, cumulative heads) from
+    synthetic 32-channel features; eval and train."""
+    from stereo_toolbox_amd.models import PSMNet
+    D = 32 if env.name == "emu" else 64
+    h4, w4 = (8, 16) if env.name == "emu" else (16, 32)   # >= 16 voxels/channel at the 1/16 level for BN
+    m, sd = _filled(PSMNet, D)
+    m = m.to(env.device)
+    fl, fr = synthetic_tensor((1, 32, h4, w4), 5), synthetic_tensor((1, 32, h4, w4), 6)
+    m.eval()
+    with env.ctx(), torch.no_grad():
+        got = m.aggregate(fl.to(env.device), fr.to(env.device), 4 * h4, 4 * w4).cpu()
+    with torch.no_grad():
+        ref = O.psmnet_aggregate(O.Ctx(sd, False), fl, fr, D, 4 * h4, 4 * w4)
+    assert got.shape == ref.shape == (1, 1, 4 * h4, 4 * w4)
+    assert (got - ref).abs().max().item() < 1e-3
+    m.train()
+    with env.ctx():
+        preds = m.aggregate(fl.to(env.device), fr.to(env.device), 4 * h4, 4 * w4)
+        sum(p.sum() * w for p, w in zip(preds, (0.5, 0.7, 1.0))).backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    rp = O.psmnet_aggregate(O.Ctx(ref_sd, True), fl, fr, D, 4 * h4, 4 * w4)
+    sum(p.sum() * w for p, w in zip(rp, (0.5, 0.7, 1.0))).backward()
+    for a, b in zip(preds, rp):
+        assert (a.detach().cpu() - b.detach()).abs().max().item() < 1e-3
+    for k, p in m.named_parameters():
+        if k.startswith("feature_extraction"):
+            continue
+        r = ref_sd[k].grad
+        assert (p.grad.cpu() - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 1e-6, k
+
+
+@pytest.mark.gpu
+def test_psmnet_config1_eval():
+    """BASELINE.json configs[0]: PSMNet forward on one 256x512 pair, D=64 (minimum legal PSMNet input)."""
+    from stereo_toolbox_amd.models import PSMNet
+    m, sd = _filled(PSMNet, 64)
+    m = m.cuda().eval()
+    left, right = synthetic_tensor((1, 3, 256, 512), 1), synthetic_tensor((1, 3, 256, 512), 2)
+    with torch.no_grad():
+        got = m(left.cuda(), right.cuda()).cpu()
+        ref = O.psmnet_forward(sd, left, right, 64)
+    assert got.shape == (1, 1, 256, 512)
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_functional_api(env):
+    """Drop-in functions of models/GwcNet/submodule.py and disparity_estimators."""
+    from stereo_toolbox_amd.disparity_estimators import argmax_disparity_estimator, softargmax_disparity_estimator
+    from stereo_toolbox_amd.models.GwcNet.submodule import (build_concat_volume, build_gwc_volume,
+                                                            disparity_regression, groupwise_correlation)
+    a, b = synthetic_tensor((2, 16, 5, 11), 7), synthetic_tensor((2, 16, 5, 11), 8)
+    da, db = a.to(env.device), b.to(env.device)
+    with env.ctx():
+        g = build_gwc_volume(da, db, 6, 4)
+        c = build_concat_volume(da, db, 6)
+        gc = groupwise_correlation(da, db, 4)
+        x = torch.softmax(synthetic_tensor((2, 16, 6, 10), 9) * 3, 1)
+        dr = disparity_regression(x.to(env.device), 16)
+        sa = softargmax_disparity_estimator(x.to(env.device), 16)
+        am = argmax_disparity_estimator(x.to(env.device), 16)
+    assert g.shape == (2, 4, 6, 5, 11) and c.shape == (2, 32, 6, 5, 11) and gc.shape == (2, 4, 5, 11)
+    assert (g.cpu() - O.build_gwc_volume(a, b, 6, 4)).abs().max().item() < 1e-6
+    assert torch.equal(c.cpu(), O.build_concat_volume(a, b, 6))
+    assert (gc.cpu() - O.groupwise_correlation(a, b, 4)).abs().max().item() < 1e-6
+    assert dr.shape == (2, 6, 10) and sa.shape == (2, 1, 6, 10) and am.shape == (2, 1, 6, 10)
+    assert (dr.cpu() - O.disparity_regression(x, 16)).abs().max().item() < 1e-5
+    assert torch.equal(am.cpu(), O.argmax_disparity_estimator(x, 16))
+    with pytest.raises(AssertionError):
+        with env.ctx():
+            build_gwc_volume(da, db, 6, 5)      # C % num_groups != 0 (reference submodule.py:46)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """On CPU tensors the product ops must fail loudly rather than fall back."""
+    from stereo_toolbox_amd import ops
+    from stereo_toolbox_amd._capi import StxError
+    with pytest.raises(StxError):
+        ops.cost_volume(torch.zeros(1, 8, 2, 4), torch.zeros(1, 8, 2, 4), None, None, 2, 2)

@@ -1,0 +1,144 @@
+"""Pins the CPU oracle (oracle/torch_oracle.py) to the golden vectors that tests/golden/make_golden.py
+produced by running the REFERENCE's own files (the reference ships no golden vectors for this path).
+Builders/estimators: bitwise.  Conv/BN stacks: 1e-5 relative (CPU <-> CPU, same torch build).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as O
+from stereo_toolbox_amd.utils import fill_state_dict, state_dict_digest, synthetic_tensor
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, name)).items()}
+
+
+def close(a, b, rtol=1e-5):
+    err = (a - b).abs().max().item()
+    assert err <= rtol * max(1.0, b.abs().max().item()), err
+
+
+def filled_sd(ctor, *a, **k):
+    m = ctor(*a, **k)
+    sd = m.state_dict()
+    fill_state_dict(sd)
+    return sd
+
+
+def test_state_dict_keys_match_reference():
+    """Drop-in boundary: same parameter/buffer names, order and shapes as the reference modules."""
+    from stereo_toolbox_amd import models
+    with open(os.path.join(G, "state_dict_keys.json")) as f:
+        ref = json.load(f)
+    ctors = {"PSMNet": lambda: models.PSMNet(64), "GwcNet_G": lambda: models.GwcNet_G(64),
+             "GwcNet_GC": lambda: models.GwcNet_GC(64)}
+    if hasattr(models, "ACVNet"):
+        ctors["ACVNet"] = lambda: models.ACVNet(64)
+    for name, ctor in ctors.items():
+        mine = [[k, list(v.shape)] for k, v in ctor().state_dict().items()]
+        assert mine == ref[name], name
+
+
+def test_builders_bitwise():
+    g = load("builders.npz")
+    for tag, (B, C, Gn, H, W, D) in (("small", (2, 16, 4, 5, 11, 6)), ("gwc320", (1, 320, 40, 8, 24, 12))):
+        a, b = synthetic_tensor((B, C, H, W), 11), synthetic_tensor((B, C, H, W), 12)
+        assert torch.equal(O.build_concat_volume(a, b, D), g[f"{tag}_concat"])
+        assert torch.equal(O.build_concat_volume(a, b, D, mask_left=False), g[f"{tag}_concat_acv"])
+        close(O.build_gwc_volume(a, b, D, Gn), g[f"{tag}_gwc"], 1e-6)
+        close(O.groupwise_correlation(a, b, Gn), g[f"{tag}_gcorr"], 1e-6)
+        # the two concat semantics differ exactly in the left half where w < d
+        diff = (g[f"{tag}_concat"] != g[f"{tag}_concat_acv"]).nonzero()
+        assert (diff[:, 1] < C).all() and (diff[:, 4] < diff[:, 2]).all()
+
+
+def test_estimators_and_head():
+    g = load("estimators.npz")
+    peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
+    flat = torch.softmax(synthetic_tensor((2, 16, 6, 10), 14) * 0.01, 1)
+    assert torch.equal(O.disparity_regression(peaky, 16), g["dr_peaky"])
+    assert torch.equal(O.disparity_regression(flat, 16), g["dr_flat"])
+    assert torch.equal(O.disparity_regression(peaky, 16, keepdim=True), g["drmod_peaky"])
+    assert torch.equal(O.disparity_regression(peaky, 16, keepdim=True), g["softargmax_peaky"])
+    assert torch.equal(O.argmax_disparity_estimator(peaky, 16), g["argmax_peaky"])
+    assert torch.equal(O.argmax_disparity_estimator(flat, 16), g["argmax_flat"])
+    cost = synthetic_tensor((1, 1, 4, 5, 7), 15) * 5
+    close(O.regression_head(cost, 16, 20, 28), g["head"], 1e-6)
+
+
+def test_blocks():
+    g = load("blocks.npz")
+    x = synthetic_tensor((1, 32, 8, 8, 12), 16)
+    from stereo_toolbox_amd.models.GwcNet.gwcnet import hourglass as HG
+    from stereo_toolbox_amd.models.GwcNet.submodule import convbn_3d
+    from stereo_toolbox_amd.models.PSMNet.stackhourglass import hourglass as HP
+    for tag, args, stride, pad in (("s1", (32, 32, 3, 1, 1), 1, 1), ("s2", (32, 64, 3, 2, 1), 2, 1),
+                                   ("k1", (32, 32, 1, 1, 0), 1, 0)):
+        sd = {"p." + k: v for k, v in filled_sd(convbn_3d, *args).items()}
+        close(O.convbn_3d(O.Ctx(sd, False), x, "p", stride, pad), g[f"convbn_{tag}_eval"])
+        cx = O.Ctx(sd, True)
+        close(O.convbn_3d(cx, x, "p", stride, pad), g[f"convbn_{tag}_train"])
+        close(cx.new_stats["p.1.running_mean"], g[f"convbn_{tag}_rm"])
+        close(cx.new_stats["p.1.running_var"], g[f"convbn_{tag}_rv"])
+    sd = {"h." + k: v for k, v in filled_sd(HG, 32).items()}
+    close(O.hourglass_gwc(O.Ctx(sd, False), x, "h"), g["hg_gwc_eval"])
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    xg = x.clone().requires_grad_()
+    y = O.hourglass_gwc(O.Ctx(sdg, True), xg, "h")
+    close(y.detach(), g["hg_gwc_train"])
+    y.square().mean().backward()
+    close(xg.grad, g["hg_gwc_train_gx"], 1e-4)
+    close(sdg["h.conv1.0.0.weight"].grad, g["hg_gwc_train_gw_conv1"], 1e-4)
+    close(sdg["h.conv5.0.weight"].grad, g["hg_gwc_train_gw_conv5"], 1e-4)
+    close(sdg["h.redir2.0.weight"].grad, g["hg_gwc_train_gw_redir2"], 1e-4)
+    sd = {"h." + k: v for k, v in filled_sd(HP, 32).items()}
+    cx = O.Ctx(sd, False)
+    o, pre, post = O.hourglass_psm(cx, x, None, None, "h")
+    o2, _, _ = O.hourglass_psm(cx, x, pre, post, "h")
+    for got, key in ((o, "out"), (pre, "pre"), (post, "post"), (o2, "out2")):
+        close(got, g[f"hg_psm_eval_{key}"])
+
+
+def test_models_eval():
+    from stereo_toolbox_amd import models
+    g = load("models_eval.npz")
+    left, right = synthetic_tensor((1, 3, 64, 128), 1), synthetic_tensor((1, 3, 64, 128), 2)
+    with torch.no_grad():
+        for tag, ctor, concat in (("gwc_gc", models.GwcNet_GC, True), ("gwc_g", models.GwcNet_G, False)):
+            sd = filled_sd(ctor, 64)
+            assert state_dict_digest(sd) == int(g[f"{tag}_digest"]), "filler produced different weights"
+            close(O.gwcnet_forward(sd, left, right, 64, concat), g[f"{tag}_eval"], 1e-5)
+        lp, rp = synthetic_tensor((1, 3, 256, 512), 1), synthetic_tensor((1, 3, 256, 512), 2)
+        sd = filled_sd(models.PSMNet, 64)
+        assert state_dict_digest(sd) == int(g["psm_digest"])
+        close(O.psmnet_forward(sd, lp, rp, 64), g["psm_eval"], 1e-5)
+        if hasattr(models, "ACVNet"):
+            for tag, kw in (("acv", {}), ("acv_attn_only", {"attn_weights_only": True})):
+                sd = filled_sd(models.ACVNet, 64, **kw)
+                assert state_dict_digest(sd) == int(g[f"{tag}_digest"])
+                close(O.acvnet_forward(sd, left, right, 64, **kw), g[f"{tag}_eval"], 1e-5)
+
+
+def test_gwc_gc_train_step():
+    from stereo_toolbox_amd import models
+    g = load("gwc_gc_train.npz")
+    sd = filled_sd(models.GwcNet_GC, 64)
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    l2, r2 = synthetic_tensor((2, 3, 64, 128), 1), synthetic_tensor((2, 3, 64, 128), 2)
+    gt = synthetic_tensor((2, 64, 128), 3, lo=0.0, hi=62.0)
+    preds, cx = O.gwcnet_forward(sd, l2, r2, 64, True, training=True, return_ctx=True)
+    loss = O.smooth_l1_multi(preds, gt, 64, (0.5, 0.5, 0.7, 1.0))
+    loss.backward()
+    for i, p in enumerate(preds):
+        close(p.detach(), g[f"pred{i}"], 1e-5)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for k, v in g.items():
+        if k.startswith("grad:"):
+            close(sd[k[5:]].grad, v, 1e-4)
+    close(cx.new_stats["dres2.conv4.0.1.running_mean"], g["rm:dres2.conv4.0.1"])

@@ -1,0 +1,66 @@
+"""Summarise a rocprofv3 --kernel-trace --stats output directory (csv or rocpd sqlite) into a
+per-kernel table: calls, total ms, avg us, share.  usage: rocprof_summary.py <dir>"""
+import csv
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def from_csv(d):
+    rows = defaultdict(lambda: [0, 0.0])
+    files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                n = r.get("Kernel_Name") or r.get("kernel_name")
+                dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                rows[n][0] += 1
+                rows[n][1] += dt
+    return rows if files else None
+
+
+def from_db(d):
+    files = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    if not files:
+        return None
+    rows = defaultdict(lambda: [0, 0.0])
+    for f in files:
+        con = sqlite3.connect(f)
+        cur = con.cursor()
+        tabs = [t[0] for t in cur.execute("select name from sqlite_master where type in ('table','view')")]
+        view = [t for t in tabs if t == "kernels"] or [t for t in tabs if "kernel_dispatch" in t]
+        if not view:
+            continue
+        t = view[0]
+        cols = [c[1] for c in cur.execute(f"pragma table_info({t})")]
+        if t == "kernels":
+            name_c = "name" if "name" in cols else cols[0]
+            for n, s, e in cur.execute(f"select {name_c}, start, end from {t}"):
+                rows[n][0] += 1
+                rows[n][1] += (e - s) / 1e6
+        else:
+            sym = [x for x in tabs if "kernel_symbol" in x][0]
+            q = (f"select s.kernel_name, d.start, d.end from {t} d join {sym} s on d.kernel_id = s.id")
+            for n, s, e in cur.execute(q):
+                rows[n][0] += 1
+                rows[n][1] += (e - s) / 1e6
+    return rows
+
+
+def main():
+    d = sys.argv[1]
+    rows = from_csv(d) or from_db(d)
+    if not rows:
+        print("no kernel trace found in", d)
+        return
+    tot = sum(v[1] for v in rows.values())
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'share':>6}  kernel")
+    for n, (c, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+        print(f"{c:7d} {ms:10.3f} {ms / c * 1e3:10.1f} {ms / tot * 100:5.1f}%  {n[:150]}")
+    print(f"total kernel time {tot:.3f} ms")
+
+
+if __name__ == "__main__":
+    main()

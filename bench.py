@@ -142,10 +142,11 @@ def main():
     timer.install()
 
     def step():
-        sync.zero_grad()
+        sync.detach_grads()
         preds = model(left, right)
         loss = smooth_l1_multi(preds, gt, args.maxdisp)
         loss.backward()
+        sync.pack()
         sync.all_reduce()
         opt.step()
 

@@ -1,0 +1,118 @@
+/* stx_hip.h -- C-ABI of libstx_hip.so: the MI355X (gfx950) cost-volume hot path of
+ * xxxupeng/stereo_toolbox (PSMNet / GwcNet / ACVNet).
+ *
+ * The reference is 100 % Python/PyTorch and has no FFI of its own; each entry point below replaces a
+ * *torch-op sequence* of the reference (file:line relative to /root/reference/stereo_toolbox).  This
+ * is the boundary a maintainer binds (ctypes stub in INTEGRATION.md; stereo_toolbox_amd/_capi.py is
+ * the binding this repo ships).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to dense fp32 data unless noted; `stream` is a hipStream_t
+ *     (NULL = default stream); calls are asynchronous on that stream, never synchronise, never
+ *     allocate; all scratch memory is passed in by the caller;
+ *   - 2-D features are NCHW [B][C][H][W]; 3-D activations are channels-last [B][D][H][W][C];
+ *   - return value 0 = OK; 1 = invalid argument; 2 = launch failure; stx_last_error() gives the
+ *     message of the last failure on the calling thread;
+ *   - re-entrant: no global mutable state, safe from several host threads / one process per GPU.
+ */
+#ifndef STX_HIP_H
+#define STX_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* stx_last_error(void);
+const char* stx_build_info(void);
+
+/* ---- cost-volume builders ------------------------------------------------------------------
+ * build_gwc_volume / groupwise_correlation  models/GwcNet/submodule.py:44-63 (dup ACVNet/submodule.py:209-238)
+ * build_concat_volume                       models/GwcNet/submodule.py:30-41, PSMNet/stackhourglass.py:111-120
+ *                                           (mask_left=1), ACVNet/submodule.py:180-191 (mask_left=0)
+ * torch.cat((gwc, concat), 1)               models/GwcNet/gwcnet.py:180 (fused)
+ * softmax(att, dim=2) * concat_volume       models/ACVNet/acv.py:196 (`scale` = softmax probabilities [B][D][H][W], or NULL)
+ * vol: [B][D][H][W][G + 2*Cc].  Lg/Rg: [B][Cg][H][W] (NULL when G == 0); Lc/Rc: [B][Cc][H][W] (NULL when Cc == 0).
+ * Requires Cg % G == 0 (reference assert submodule.py:46), Cg/G in {4,8,16}, G % 4 == 0, Cc % 4 == 0. */
+int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc, const float* Rc, int Cc,
+                        const float* scale, float* vol, int B, int H, int W, int D, int mask_left, void* stream);
+/* autograd backward of the above (no `scale`): gvol [B][D][H][W][G+2Cc] -> gLg,gRg [B][Cg][H][W], gLc,gRc [B][Cc][H][W] */
+int stx_cost_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc, float* gLg,
+                        float* gRg, float* gLc, float* gRc, int B, int H, int W, int D, int mask_left, void* stream);
+
+/* ---- regression head and disparity estimators ---------------------------------------------------
+ * F.upsample(trilinear) -> squeeze -> F.softmax(dim=1) -> disparity_regression, fused:
+ *   models/GwcNet/gwcnet.py:197-224, models/PSMNet/stackhourglass.py:139-153, models/ACVNet/acv.py:206-251.
+ * cost [B][Dc][Hc][Wc] -> disp [B][H][W]; stats [B][H][W][2] (per-pixel max and sum-exp, kept for backward; may be NULL). */
+int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                 void* stream);
+int stx_head_bwd(const float* gdisp, const float* cost, const float* disp, const float* stats, float* gcost, int B,
+                 int Dc, int Hc, int Wc, int D, int H, int W, void* stream);
+/* disparity_regression (GwcNet/submodule.py:23-27), disparityregression (PSMNet/submodule.py:46-54),
+ * softargmax_disparity_estimator (disparity_estimators/__init__.py:7-10): out[b][hw] = sum_d d * x[b][d][hw] */
+int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
+/* argmax_disparity_estimator (disparity_estimators/__init__.py:13-15): out int64 [B][HW], first maximum */
+int stx_argmax_fwd(const float* x, long long* out, int B, int D, int HW, void* stream);
+/* F.softmax over the disparity axis of [B][D][HW] (ACVNet attention weights, acv.py:196) */
+int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream);
+
+/* ---- Conv3d / ConvTranspose3d aggregation (fp32 MFMA implicit GEMM) ---------------------------------
+ * nn.Conv3d(k=3,p=1,s=1|2, bias=False), nn.Conv3d(k=1), nn.ConvTranspose3d(k=3,s=2,p=1,op=1, bias=False) of
+ * convbn_3d / hourglass / dres / classif: models/GwcNet/gwcnet.py:68-153, models/GwcNet/submodule.py:17-20,
+ * models/PSMNet/stackhourglass.py:10-84, models/ACVNet/acv.py:56-144.
+ * Weights are first re-laid-out on the device into MFMA operand order (w: torch layout [A][B][T], T = k^3):
+ *   mode 0: conv forward (w = [Cout][Cin][T]) and ConvTranspose dgrad;  1: stride-1 conv dgrad;
+ *   mode 2: ConvTranspose forward (w = [Cin][Cout][T]) and stride-2 conv dgrad. */
+long long stx_conv3d_packed_floats(int K, int N, int T);
+int stx_conv3d_pack_weight(const float* w, float* wp, int A, int B, int T, int mode, void* stream);
+/* out = act(conv(x) * scale[c] + bias[c] + residual); scale/bias/residual may be NULL; if `stats` != NULL the
+ * per-workgroup (sum, sum of squares) of the RAW conv output are written to stats[B*blocks][2][Cout]
+ * (blocks = stx_conv3d_fwd_blocks(Do,Ho,Wo)) for train-mode BatchNorm. Cin % 8 == 0, Cout <= 128. */
+int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo);
+int stx_conv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
+                   const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout, int ks,
+                   int stride, int relu, void* stream);
+int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi);
+int stx_deconv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
+                     const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout, int Do,
+                     int Ho, int Wo, int relu, void* stream);
+/* weight gradient dW[cc][cf][T] = sum_o fine[S*o+tap-pad][cf] * coarse[o][cc]
+ *   conv: fine = layer input, coarse = grad of output;  ConvTranspose: fine = grad of output, coarse = layer input.
+ * workspace: stx_conv3d_wgrad_workspace_floats(...) floats. CF % 32 == 0, CC % 32 == 0. */
+long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks, int stride);
+int stx_conv3d_wgrad(const float* fine, const float* coarse, float* dw, float* workspace, int B, int Df, int Hf, int Wf,
+                     int CF, int Dc, int Hc, int Wc, int CC, int ks, int stride, void* stream);
+
+/* Classifier tail Conv3d(Cin, 1, k=3, p=1, bias=False) (GwcNet/gwcnet.py:139-153, PSMNet/stackhourglass.py:74-84):
+ * N = 1 is not GEMM-shaped, so it gets VALU kernels. w: torch layout [1][Cin][27]; out/residual/gy: [B][D][H][W].
+ * Cin % 16 == 0 (wgrad: Cin <= 64). dgrad uses stx_conv3d_fwd with the weight zero-padded to 8 output channels. */
+int stx_conv3d_c1_fwd(const float* x, const float* w, const float* residual, float* out, int B, int D, int H, int W,
+                      int Cin, void* stream);
+long long stx_conv3d_c1_wgrad_workspace_floats(int Cin);
+int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, float* workspace, int B, int D, int H, int W,
+                        int Cin, void* stream);
+
+/* ---- train-mode BatchNorm3d (+ReLU / residual) around the convolutions ---------------------------------
+ * nn.BatchNorm3d of convbn_3d (models/GwcNet/submodule.py:17-20) in train() mode and the adds/ReLUs that follow it
+ * (GwcNet/gwcnet.py:96-103,185; PSMNet/stackhourglass.py:31-48). */
+int stx_bn_reduce_blocks(void);
+/* partials [nrows][2][C] (from the conv epilogue) -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
+ * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance, like torch. */
+int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                    float* mean, float* invstd, void* stream);
+/* out = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + z2 when scale2 == NULL]) over [nvox][C] */
+int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2, const float* scale2,
+                 const float* shift2, float* out, long long nvox, int C, int relu, void* stream);
+/* sums[3][C] = sum g, sum g*xhat1, sum g*xhat2 with g = gy*[y>0]; partials: scratch of stx_bn_reduce_blocks()*3*C floats */
+int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
+                      const float* z2, const float* mean2, const float* invstd2, float* partials, float* sums,
+                      long long nvox, int C, int relu, void* stream);
+/* dz_k = gamma_k*invstd_k*(g - sums[0]/N - xhat_k*sums[k]/N); gout (may be NULL) receives g for a plain residual branch */
+int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
+                     const float* gamma1, const float* z2, const float* mean2, const float* invstd2,
+                     const float* gamma2, const float* sums, float* dz1, float* dz2, float* gout, long long nvox, int C,
+                     int relu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

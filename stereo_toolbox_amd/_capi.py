@@ -9,6 +9,11 @@ import ctypes
 import os
 import threading
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be the one already
+# mapped when libstx_hip.so is dlopen'ed, otherwise the loader pulls a second runtime from /opt/rocm
+# and launches fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401  (side effect: loads torch's HIP runtime first)
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
@@ -34,6 +39,10 @@ SIGNATURES = {
     "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_wgrad_workspace_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
     "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    # conv_c1.hip
+    "stx_conv3d_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "stx_conv3d_c1_wgrad_workspace_floats": [_I],
+    "stx_conv3d_c1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # bn.hip
     "stx_bn_reduce_blocks": [],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],

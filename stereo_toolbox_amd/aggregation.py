@@ -71,6 +71,8 @@ def _infer_conv(x, conv, scale, bias, residual, relu):
     if _is_transposed(conv):
         wp = ops.pack_weight(conv.weight.detach(), 2, cache=True)
         return ops.deconv3d_forward(x, wp, conv.weight.shape[1], scale=scale, bias=bias, residual=residual, relu=relu)[0]
+    if ops._is_c1(conv.weight, ks, stride, False) and scale is None and bias is None and not relu:
+        return ops.conv3d_c1_forward(x, conv.weight.detach().contiguous(), residual)
     wp = ops.pack_weight(conv.weight.detach(), 0, cache=True)
     return ops.conv3d_forward(x, wp, conv.weight.shape[0], ks, stride, scale, bias, residual, relu)[0]
 

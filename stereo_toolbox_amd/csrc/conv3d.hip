@@ -28,6 +28,7 @@
 // per-workgroup sum / sum-of-squares partials of the raw conv output for train-mode BatchNorm
 // statistics (finalised by stx_bn_finalize; deterministic, no atomics).
 #include "stx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,6 +47,17 @@ struct ConvArgs {
     int relu;
     int nDt, nHt, nWt;
 };
+
+// XCD-aware workgroup remap (guide T1): the dispatcher places workgroup b on XCD b % 8, each XCD has
+// its own 4 MiB L2.  Give every XCD a contiguous run of tiles so that neighbouring tiles (which share
+// halo voxels and, along W/H, whole input rows) hit the same L2.  Bijective for any grid size; only
+// speed depends on the placement assumption.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -125,11 +137,12 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
-    const int bid = blockIdx.x, b = blockIdx.y;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), b = blockIdx.y;
     const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
     const int od0 = dt * TD, oh0 = ht * TH, ow0 = wt * 32;
     const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
     const int NQ = a.Cin / 8;
+    constexpr int T = KS * KS * KS, NQC = CK / 8;
 
     f32x16 acc[MT][NT];
     int abase[MT];
@@ -155,29 +168,44 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
             stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val);
         }
         __syncthreads();
+        // B operand (packed weights, L2-resident) is register double-buffered one tap ahead so that
+        // its ~L2 latency hides under the current tap's 16*MT*NT MFMAs.
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        for (int tap = 0; tap < KS * KS * KS; ++tap) {
+        float4 bcur[NQC][NT], bnxt[NQC][NT];
+#pragma unroll
+        for (int q = 0; q < NQC; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = stx_ld4(wq + (size_t)(q * NT + nt) * 256);
+        for (int tap = 0; tap < T; ++tap) {
             const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
             const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
                                       : ((kd * EH + kh) * EWS + kw) * VS;
-            const float* wtap = wq + (size_t)tap * NQ * NT * 256;
+            const int tn = tap + 1 < T ? tap + 1 : tap;
+            const float* wnext = wq + (size_t)tn * NQ * NT * 256;
 #pragma unroll
-            for (int q = 0; q < CK / 8; ++q) {
-                float4 av[MT], bv[NT];
+            for (int q = 0; q < NQC; ++q)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = stx_ld4(tile + abase[m] + toff + q * 8);
+                for (int nt = 0; nt < NT; ++nt) bnxt[q][nt] = stx_ld4(wnext + (size_t)(q * NT + nt) * 256);
+            float4 av[NQC][MT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+            for (int q = 0; q < NQC; ++q)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
+#pragma unroll
+            for (int q = 0; q < NQC; ++q)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].x, bv[nt].x, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].y, bv[nt].y, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].z, bv[nt].z, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m].w, bv[nt].w, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
                     }
-            }
+#pragma unroll
+            for (int q = 0; q < NQC; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
         }
     }
 
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
-    const int bid = blockIdx.x, b = blockIdx.y;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x), b = blockIdx.y;
     const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
     const int md0 = dt, mh0 = ht * TH, mw0 = wt * 32;
     const int NQ = a.Cin / 8;
@@ -354,14 +382,15 @@ struct WgradArgs {
     int nHt, nWt, ntiles;
 };
 
-template <int KS, int S, int TH, int TW>
-__global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a) {
+template <int KS, int S, int TH, int TW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
+    constexpr int NTHR = NW * 64;
     constexpr int PAD = KS / 2;
     constexpr int T = KS * KS * KS;
     constexpr int ED = KS, EH = (TH - 1) * S + KS, EW = (TW - 1) * S + KS;
     constexpr int EWH = (EW + 1) / 2;
     constexpr int EWS = (S == 2) ? 2 * EWH : EW;
-    constexpr int NTAP = (T + 3) / 4;               // taps per wave (KS=3: 7)
+    constexpr int NTAP = (T + NW - 1) / NW;         // taps per wave (KS=3: 7 with 4 waves, 4 with 8)
     constexpr int NV = TH * TW;                     // coarse voxels per tile
     STX_DYN_SMEM(smem);
     float* ftile = reinterpret_cast<float*>(smem);          // [ED*EH*EWS][32]
@@ -385,7 +414,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
         const int oh0 = ht * TH, ow0 = wt * TW;
         const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
         __syncthreads();
-        for (int idx = tid; idx < ED * EH * EW * 8; idx += CONV_THREADS) {
+        for (int idx = tid; idx < ED * EH * EW * 8; idx += NTHR) {
             const int v = idx >> 3, f = idx & 7;
             const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
             const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
             const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
             stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, val);
         }
-        for (int idx = tid; idx < NV * 8; idx += CONV_THREADS) {
+        for (int idx = tid; idx < NV * 8; idx += NTHR) {
             const int v = idx >> 3, f = idx & 7;
             const int ow = ow0 + v % TW, oh = oh0 + v / TW;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -406,7 +435,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
         __syncthreads();
         if (KS == 1) {
             // waves split the voxel pairs
-            for (int p = wave; p < NV / 2; p += 4) {
+            for (int p = wave; p < NV / 2; p += NW) {
                 const int v = 2 * p + half;
                 const int lw = v % TW, lh = v / TW;
                 const float bv = ctile[v * 32 + i];
@@ -420,7 +449,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
                 const float bv = ctile[v * 32 + i];
 #pragma unroll
                 for (int t = 0; t < NTAP; ++t) {
-                    const int tap = t * 4 + wave;
+                    const int tap = t * NW + wave;
                     if (tap < T) {
                         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                         const int wx = lw * S + kw, hy = lh * S + kh;
@@ -433,11 +462,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
         }
     }
     // partial slab: KS=3: [blockIdx.y][blockIdx.x][tap][cf 32][cc 32]; KS=1: [..][wave][32][32]
-    constexpr int ROWS = (KS == 1) ? 4 : T;
+    constexpr int ROWS = (KS == 1) ? NW : T;
     float* dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ROWS * 1024;
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
-        const int row = (KS == 1) ? wave : t * 4 + wave;
+        const int row = (KS == 1) ? wave : t * NW + wave;
         if (KS == 1 ? (t == 0) : (row < T)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -448,26 +477,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_kernel(WgradArgs a)
     }
 }
 
-// dW[cc][cf][tap] = sum over chunks (and waves for KS=1) of the slab.
+// dW[cc][cf][tap] = sum over chunks (and waves for KS=1) of the slab, in a fixed order.
+// A workgroup reduces 64 consecutive outputs; its 4 waves take every 4th slab row and meet in LDS.
 __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slab,
                                                                            float* __restrict__ dw, int CF, int CC,
                                                                            int T, int nchunks, int rows_per_chunk) {
-    const int idx = blockIdx.x * CONV_THREADS + threadIdx.x;      // over [pair][tap][cf32][cc32]
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + lane;                        // over [pair][tap][cf32][cc32]
     const int ncf = CF / 32;
-    const int total = (CF / 32) * (CC / 32) * T * 1024;
-    if (idx >= total) return;
     const int cc_l = idx & 31, cf_l = (idx >> 5) & 31;
     const int tap = (idx >> 10) % T, pair = (idx >> 10) / T;
     const int cfb = pair % ncf, ccb = pair / ncf;
     float s = 0.f;
     if (rows_per_chunk == T) {
         const float* p = slab + ((size_t)pair * nchunks * T + tap) * 1024 + cf_l * 32 + cc_l;
-        for (int c = 0; c < nchunks; ++c) s += p[(size_t)c * T * 1024];
-    } else {  // KS=1: 4 wave rows per chunk
-        const float* p = slab + ((size_t)pair * nchunks * 4) * 1024 + cf_l * 32 + cc_l;
-        for (int c = 0; c < nchunks * 4; ++c) s += p[(size_t)c * 1024];
+        for (int c = wave; c < nchunks; c += 4) s += p[(size_t)c * T * 1024];
+    } else {  // KS=1: one slab row per wave of the producer
+        const float* p = slab + ((size_t)pair * nchunks * rows_per_chunk) * 1024 + cf_l * 32 + cc_l;
+        for (int c = wave; c < nchunks * rows_per_chunk; c += 4) s += p[(size_t)c * 1024];
     }
-    dw[((size_t)(ccb * 32 + cc_l) * CF + cfb * 32 + cf_l) * T + tap] = s;
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0)
+        dw[((size_t)(ccb * 32 + cc_l) * CF + cfb * 32 + cf_l) * T + tap] =
+            (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 template <typename K>
@@ -497,6 +531,7 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
     if (NT == NT_ && CK == CK_)                                                                                    \
         return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, grid, lds, st, a);
     CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32)
+    CONV_CASE(1, 16) CONV_CASE(2, 16) CONV_CASE(4, 16)
     CONV_CASE(1, 8) CONV_CASE(2, 8) CONV_CASE(4, 8)
 #undef CONV_CASE
     return stx_set_error(STX_ERR_ARG, "conv3d: unsupported NT=%d CK=%d", NT, CK);
@@ -504,8 +539,12 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
 
 }  // namespace
 
-// Cin chunk used by the kernels for a given Cin (multiple of 8).
-static int conv_pick_ck(int Cin) { return (Cin % 32 == 0) ? 32 : 8; }
+// Cin chunk used by the kernels for a given Cin (multiple of 8).  STX_CONV_CK overrides (tuning).
+static int conv_pick_ck(int Cin) {
+    static const int env = getenv("STX_CONV_CK") ? atoi(getenv("STX_CONV_CK")) : 0;
+    if (env && Cin % env == 0) return env;
+    return (Cin % 32 == 0) ? 32 : 8;
+}
 // 32-wide MFMA column blocks used for N output channels (1, 2 or 4).
 static int conv_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
@@ -589,7 +628,7 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
 
 // Workgroups along the split-K axis for the weight gradient.
 static int wgrad_chunks(int ntiles, int npairs) {
-    int c = 1024 / npairs;
+    int c = 512 / npairs;      // ~2 resident workgroups per CU in total
     if (c < 1) c = 1;
     if (c > ntiles) c = ntiles;
     return c;
@@ -600,7 +639,7 @@ extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, in
     const int TH = 2, TW = (stride == 2) ? 16 : 32;
     const int ntiles = B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW);
     const int npairs = (CF / 32) * (CC / 32);
-    const int rows = (ks == 1) ? 4 : 27;
+    const int rows = (ks == 1) ? 8 : 27;
     return (long long)npairs * wgrad_chunks(ntiles, npairs) * rows * 1024;
 }
 
@@ -621,22 +660,29 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     dim3 grid(nchunks, npairs);
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
-    if (ks == 3 && stride == 1) {
-        const size_t lds = ((size_t)3 * 4 * 34 + 64) * 32 * 4;
-        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<3, 1, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<3, 1, 2, 32>), grid, dim3(CONV_THREADS), lds, st, a);
-    } else if (ks == 3) {
-        const size_t lds = ((size_t)3 * 5 * 34 + 32) * 32 * 4;
-        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<3, 2, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<3, 2, 2, 16>), grid, dim3(CONV_THREADS), lds, st, a);
-    } else {
-        const size_t lds = ((size_t)2 * 32 + 64) * 32 * 4;
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<1, 1, 2, 32>), grid, dim3(CONV_THREADS), lds, st, a);
+    static const int nw_env = getenv("STX_WGRAD_WAVES") ? atoi(getenv("STX_WGRAD_WAVES")) : 0;
+    const int NW = (nw_env == 4 || nw_env == 8) ? nw_env : 4;
+#define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, LDS_)                                                                   \
+    {                                                                                                             \
+        const size_t lds = (LDS_);                                                                                \
+        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_>,                             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_>), grid, dim3(NW_ * 64), lds, st, a);      \
     }
+    if (ks == 3 && stride == 1) {
+        if (NW == 8) WG_LAUNCH(3, 1, 2, 32, 8, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
+        else WG_LAUNCH(3, 1, 2, 32, 4, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
+    } else if (ks == 3) {
+        if (NW == 8) WG_LAUNCH(3, 2, 2, 16, 8, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+        else WG_LAUNCH(3, 2, 2, 16, 4, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+    } else {
+        WG_LAUNCH(1, 1, 2, 32, 4, ((size_t)2 * 32 + 64) * 32 * 4)
+    }
+#undef WG_LAUNCH
     int rc = stx_check_launch("conv3d_wgrad");
     if (rc) return rc;
     const int total = npairs * T * 1024;
-    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(stx_cdiv(total, CONV_THREADS)), dim3(CONV_THREADS), 0, st,
-                       workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);
+    hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st,
+                       workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);   // KS=1 producer uses 4 waves
     return stx_check_launch("conv3d_wgrad_reduce");
 }

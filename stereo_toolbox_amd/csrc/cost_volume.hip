@@ -30,29 +30,38 @@
 namespace {
 
 constexpr int CV_WT = 16;       // output columns per workgroup
-constexpr int CV_DC = 16;       // disparities per workgroup
 constexpr int CV_THREADS = 256;
+constexpr int CV_MAX_DC = 32;   // disparities per workgroup (runtime DC <= this)
 
-// Transposing stage of `ncols` columns x `C` channels from an NCHW row into lds[col][C+4].
-// Lane l of a wave covers column (l>>2)&7 and channel (l&3)+4*(l>>5) of an 8x8 patch:
-// 32 B contiguous per channel row from global, 32 distinct banks per half-wave into LDS.
+// Stage `ncols` columns x `C` channels of one NCHW feature row into lds[col][C+4] (transposed).
+// Lanes run along the image row, so every global load instruction reads contiguous 64..256-B row
+// segments; PER rows share one instruction when the segment is short.  The transposing 4-byte LDS
+// writes land on 8 banks x 4 lanes (row stride C+4 dwords == 4 mod 32): 2x the conflict-free
+// cost, which is noise next to the 16-byte operand reads the layout is built for.
+template <int PER>   // rows per wave-instruction: 64/PER lanes per row
 __device__ __forceinline__ void cv_stage_rows(const float* __restrict__ src,  // &F[b][0][h][0]
                                               int C, int HW, int W, int x_first, int ncols,
                                               float* lds, int tid) {
+    constexpr int LPR = 64 / PER;
+    constexpr int BATCH = 8;          // independent global loads in flight per lane (latency hiding)
     const int lane = tid & 63, wave = tid >> 6, nwaves = CV_THREADS >> 6;
-    const int cl = (lane & 3) + 4 * (lane >> 5);
-    const int xl = (lane >> 2) & 7;
+    const int r = lane / LPR, xl = lane % LPR;
     const int RS = C + 4;
-    const int ncol8 = (ncols + 7) >> 3;
-    const int nc8 = (C + 7) >> 3;
-    for (int p = wave; p < ncol8 * nc8; p += nwaves) {
-        const int c = (p / ncol8) * 8 + cl;
-        const int col = (p % ncol8) * 8 + xl;
+    for (int col = xl; col < ncols; col += LPR) {
         const int x = x_first + col;
-        if (c < C && col < ncols) {
-            float v = 0.f;
-            if (x >= 0 && x < W) v = src[(size_t)c * HW + x];
-            lds[col * RS + c] = v;
+        const bool xin = x >= 0 && x < W;
+        for (int c0 = wave * PER * BATCH; c0 < C; c0 += nwaves * PER * BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int c = c0 + k * PER + r;
+                v[k] = (xin && c < C) ? src[(size_t)c * HW + x] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int c = c0 + k * PER + r;
+                if (c < C) lds[col * RS + c] = v[k];
+            }
         }
     }
 }
@@ -62,19 +71,19 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
     const float* __restrict__ Lg, const float* __restrict__ Rg, int Cg, int G,
     const float* __restrict__ Lc, const float* __restrict__ Rc, int Cc,
     const float* __restrict__ scale, float* __restrict__ vol,
-    int H, int W, int D, int mask_left) {
+    int H, int W, int D, int DC, int mask_left) {
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int w0 = blockIdx.x * CV_WT;
-    const int d0 = blockIdx.y * CV_DC;
+    const int d0 = blockIdx.y * DC;
     const int bh = blockIdx.z;
     const int b = bh / H, h = bh % H;
     const int HW = H * W;
     const int CT = G + 2 * Cc;
     const int Q = CT >> 2, GQ = G >> 2, CQ = Cc >> 2;
     const int RSg = Cg + 4, RSc = Cc + 4;
-    const int NR = CV_WT + CV_DC - 1;                 // right-feature columns kept in LDS
-    const int x_first = w0 - d0 - (CV_DC - 1);        // image column of LDS column 0
+    const int NR = CV_WT + DC - 1;                 // right-feature columns kept in LDS
+    const int x_first = w0 - d0 - (DC - 1);        // image column of LDS column 0
 
     float* Lg_s = reinterpret_cast<float*>(smem);
     float* Rg_s = Lg_s + (G ? CV_WT * RSg : 0);
@@ -82,16 +91,16 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
     float* Rc_s = Lc_s + (Cc ? CV_WT * RSc : 0);
 
     if (G) {
-        cv_stage_rows(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, Lg_s, tid);
-        cv_stage_rows(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, Rg_s, tid);
+        cv_stage_rows<4>(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, Lg_s, tid);
+        cv_stage_rows<1>(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, Rg_s, tid);
     }
     if (Cc) {
-        cv_stage_rows(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, Lc_s, tid);
-        cv_stage_rows(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, Rc_s, tid);
+        cv_stage_rows<4>(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, Lc_s, tid);
+        cv_stage_rows<1>(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, Rc_s, tid);
     }
     __syncthreads();
 
-    const int dend = (d0 + CV_DC < D) ? CV_DC : (D - d0);
+    const int dend = (d0 + DC < D) ? DC : (D - d0);
     const float inv = 1.0f / (float)CPG;
     for (int item = tid; item < CV_WT * Q; item += CV_THREADS) {
         const int wl = item / Q, q = item - wl * Q;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
             for (int dd = 0; dd < dend; ++dd) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (w >= d0 + dd) {
-                    const float* r = Rg_s + (wl + CV_DC - 1 - dd) * RSg + q * 4 * CPG;
+                    const float* r = Rg_s + (wl + DC - 1 - dd) * RSg + q * 4 * CPG;
                     float acc[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
             for (int dd = 0; dd < dend; ++dd) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (w >= d0 + dd) {
-                    o = stx_ld4(Rc_s + (wl + CV_DC - 1 - dd) * RSc + 4 * (q - GQ - CQ));
+                    o = stx_ld4(Rc_s + (wl + DC - 1 - dd) * RSc + 4 * (q - GQ - CQ));
                     if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
                 }
                 stx_st4(out + dd * dstride, o);
@@ -153,14 +162,21 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward of the builders (scatter-free): one workgroup owns (b, h, 16 columns, channel chunk).
-//   gLg[c][w] = 1/cpg * sum_{d<=w}      gvol[d][w][g(c)]     * Rg[c][w-d]
-//   gRg[c][x] = 1/cpg * sum_{d, x+d<W}  gvol[d][x+d][g(c)]   * Lg[c][x+d]
-//   gLc[c][w] =         sum_{d<=w or !mask_left} gvol[d][w][G+c]
-//   gRc[c][x] =         sum_{d, x+d<W}  gvol[d][x+d][G+Cc+c]
-// Work item = (column, channel); results are transposed through LDS so the NCHW rows are
-// written 16 consecutive columns at a time.
-constexpr int CVB_CH = 64;   // feature channels per pass
+// Backward of the builders, scatter-free (no atomics).  blockIdx.y selects the side:
+//   LEFT : gLg[c][t] = 1/cpg * sum_d gvol[d][t][g(c)]     * Rg[c][t-d]   (t >= d)
+//          gLc[c][t] =         sum_d gvol[d][t][G+c]                     (t >= d or !mask_left)
+//   RIGHT: gRg[c][t] = 1/cpg * sum_d gvol[d][t+d][g(c)]   * Lg[c][t+d]   (t+d < W)
+//          gRc[c][t] =         sum_d gvol[d][t+d][G+Cc+c]                (t+d < W)
+// A workgroup owns (b, h, 16 columns t) and walks channel chunks x disparity chunks.  Per
+// (chunk, 16 disparities) it stages the needed slice of gvol ([dd][t][groups], 16-byte coalesced
+// loads) and the D-shifted feature tile ([col][ch], transposed) into LDS -- out-of-range entries are
+// staged as zeros so the inner loop is branch-free: 2 ds_read_b32 + 1 FMA per (item, disparity).
+// A work item is (column, channel) with the channel fastest, so feature reads are conflict-free and
+// the 8 lanes of a group broadcast-read the same gvol value.  Results leave through an LDS
+// transpose as 64-byte NCHW row segments.
+constexpr int CVB_CH = 160;    // gwc feature channels per pass (multiple of every supported cpg)
+constexpr int CVB_DC = 16;     // disparities per staged slice
+constexpr int CVB_ITEMS = CV_WT * CVB_CH / CV_THREADS;   // 10 accumulators per thread
 
 __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     const float* __restrict__ gvol, const float* __restrict__ Lg, const float* __restrict__ Rg,
@@ -168,82 +184,121 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     float* __restrict__ gLc, float* __restrict__ gRc, int H, int W, int D, int mask_left) {
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * CV_WT;
+    const int t0 = blockIdx.x * CV_WT;
+    const bool right = blockIdx.y != 0;
     const int bh = blockIdx.z;
     const int b = bh / H, h = bh % H;
     const int HW = H * W;
     const int CT = G + 2 * Cc;
     const int cpg = G ? Cg / G : 1;
     const float inv = 1.0f / (float)cpg;
-    const int NC = CV_WT + D - 1;            // columns of the shifted operand
-    const int RS = CVB_CH + 4;
-    float* Ls = reinterpret_cast<float*>(smem);          // Lg[c][w0 .. w0+NC)      -> for gR
-    float* Rs = Ls + NC * RS;                            // Rg[c][w0-D+1 .. w0+WT)  -> for gL
-    float* Ts = Rs + NC * RS;                            // [2][CVB_CH][WT+1] transpose buffer
+    constexpr int NCOL = CV_WT + CVB_DC - 1;       // 31 feature columns per slice
+    constexpr int RS = CVB_CH + 4;
+    float* gvs = reinterpret_cast<float*>(smem);           // [CVB_DC][CV_WT][GS] (GS = groups or channels)
+    float* fs = gvs + CVB_DC * CV_WT * 40;                 // [NCOL][RS]
+    float* ts = fs + NCOL * RS;                            // [CVB_CH][CV_WT + 1]
     const size_t dstride = (size_t)H * W * CT;
     const float* gv_row = gvol + (((size_t)b * D) * H + h) * W * CT;
+    const float* feat = right ? Lg : Rg;
+    float* gout = right ? gRg : gLg;
 
+    // ---- gwc channels
     for (int c0 = 0; c0 < Cg; c0 += CVB_CH) {
         const int nch = (Cg - c0 < CVB_CH) ? (Cg - c0) : CVB_CH;
-        __syncthreads();
-        // stage the chunk's channels, transposed to [col][ch]
-        {
-            const int lane = tid & 63, wave = tid >> 6;
-            const int cl = (lane & 3) + 4 * (lane >> 5), xl = (lane >> 2) & 7;
-            const int ncol8 = (NC + 7) >> 3, nc8 = (nch + 7) >> 3;
-            for (int p = wave; p < ncol8 * nc8; p += 4) {
-                const int c = (p / ncol8) * 8 + cl, col = (p % ncol8) * 8 + xl;
-                if (c < nch && col < NC) {
-                    const size_t base = (((size_t)b * Cg + c0 + c) * H + h) * W;
-                    const int xl_ = w0 + col, xr_ = w0 - (D - 1) + col;
-                    Ls[col * RS + c] = (xl_ < W) ? Lg[base + xl_] : 0.f;
-                    Rs[col * RS + c] = (xr_ >= 0 && xr_ < W) ? Rg[base + xr_] : 0.f;
+        const int g0 = c0 / cpg, ng = nch / cpg;           // groups of this pass (ng <= 40)
+        float acc[CVB_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CVB_ITEMS; ++k) acc[k] = 0.f;
+        for (int d0 = 0; d0 < D; d0 += CVB_DC) {
+            __syncthreads();
+            // gvol slice: gvs[dd][tl][j] = gvol[d0+dd][voxel column][g0+j], zero outside the image / D
+            for (int idx = tid; idx < CVB_DC * CV_WT * (ng >> 2); idx += CV_THREADS) {
+                const int f = idx % (ng >> 2), v = idx / (ng >> 2);
+                const int tl = v % CV_WT, dd = v / CV_WT;
+                const int d = d0 + dd, wv = right ? t0 + tl + d : t0 + tl;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (d < D && wv < W) val = stx_ld4(gv_row + d * dstride + (size_t)wv * CT + g0 + 4 * f);
+                stx_st4(gvs + (dd * CV_WT + tl) * ng + 4 * f, val);
+            }
+            // feature tile: column col <-> image column fc;  LEFT: fc = t0 + tl - d  -> col = tl - dd + 15
+            //                                               RIGHT: fc = t0 + tl + d -> col = tl + dd
+            {
+                const int fc0 = right ? t0 + d0 : t0 - d0 - (CVB_DC - 1);
+                const int lane = tid & 63, wave = tid >> 6;
+                const int r = lane >> 5, xl = lane & 31;       // 2 channel rows x 32 columns per instruction
+                const int fc = fc0 + xl;
+                const bool ok = xl < NCOL && fc >= 0 && fc < W;
+                const float* src = feat + (((size_t)b * Cg + c0) * H + h) * W;
+                for (int cb = wave * 16; cb < nch; cb += 64) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int c = cb + 2 * k + r;
+                        v[k] = (ok && c < nch) ? src[(size_t)c * HW + fc] : 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int c = cb + 2 * k + r;
+                        if (xl < NCOL && c < nch) fs[xl * RS + c] = v[k];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CVB_ITEMS; ++k) {
+                const int item = tid + k * CV_THREADS;
+                const int c = item % CVB_CH, tl = item / CVB_CH;
+                if (c < nch) {
+                    const int gl = c / cpg;
+                    const float* gp = gvs + tl * ng + gl;
+                    const float* fp = fs + c + (right ? tl : tl + CVB_DC - 1) * RS;
+                    float a = acc[k];
+#pragma unroll
+                    for (int dd = 0; dd < CVB_DC; ++dd)
+                        a = fmaf(gp[dd * CV_WT * ng], right ? fp[dd * RS] : fp[-dd * RS], a);
+                    acc[k] = a;
                 }
             }
         }
         __syncthreads();
-        for (int item = tid; item < CV_WT * nch; item += CV_THREADS) {
-            const int wl = item / nch, c = item - wl * nch;
-            const int w = w0 + wl;
-            const int g = (c0 + c) / cpg;
-            float aL = 0.f, aR = 0.f;
-            if (w < W) {
-                for (int d = 0; d < D; ++d) {
-                    // gL: voxel (d, w), right column w-d -> Rs col = wl + D-1-d
-                    if (w >= d) aL = fmaf(gv_row[d * dstride + (size_t)w * CT + g], Rs[(wl + D - 1 - d) * RS + c], aL);
-                    // gR: here w plays x; voxel (d, x+d), left column x+d -> Ls col = wl + d
-                    if (w + d < W) aR = fmaf(gv_row[d * dstride + (size_t)(w + d) * CT + g], Ls[(wl + d) * RS + c], aR);
-                }
-            }
-            Ts[c * (CV_WT + 1) + wl] = aL * inv;
-            Ts[(CVB_CH + c) * (CV_WT + 1) + wl] = aR * inv;
+#pragma unroll
+        for (int k = 0; k < CVB_ITEMS; ++k) {
+            const int item = tid + k * CV_THREADS;
+            const int c = item % CVB_CH, tl = item / CVB_CH;
+            if (c < nch) ts[c * (CV_WT + 1) + tl] = acc[k] * inv;
         }
         __syncthreads();
-        for (int item = tid; item < 2 * nch * CV_WT; item += CV_THREADS) {
-            const int wl = item % CV_WT, r = item / CV_WT;
-            const int which = r / nch, c = r - which * nch;
-            const int w = w0 + wl;
-            if (w < W) {
-                float* dst = which ? gRg : gLg;
-                dst[(((size_t)b * Cg + c0 + c) * H + h) * W + w] = Ts[(which * CVB_CH + c) * (CV_WT + 1) + wl];
-            }
+        for (int idx = tid; idx < nch * CV_WT; idx += CV_THREADS) {
+            const int tl = idx % CV_WT, c = idx / CV_WT;
+            if (t0 + tl < W) gout[(((size_t)b * Cg + c0 + c) * H + h) * W + t0 + tl] = ts[c * (CV_WT + 1) + tl];
         }
     }
-    // concat halves: plain disparity sums
-    for (int item = tid; item < 2 * Cc * CV_WT; item += CV_THREADS) {
-        const int wl = item % CV_WT, r = item / CV_WT;
-        const int which = r / Cc, c = r - which * Cc;
-        const int w = w0 + wl;
-        if (w >= W) continue;
-        float a = 0.f;
-        if (!which) {
-            for (int d = 0; d < D; ++d)
-                if (!mask_left || w >= d) a += gv_row[d * dstride + (size_t)w * CT + G + c];
-            gLc[(((size_t)b * Cc + c) * H + h) * W + w] = a;
-        } else {
-            for (int d = 0; d < D; ++d)
-                if (w + d < W) a += gv_row[d * dstride + (size_t)(w + d) * CT + G + Cc + c];
-            gRc[(((size_t)b * Cc + c) * H + h) * W + w] = a;
+
+    // ---- concat channels: plain disparity sums of the matching gvol channels
+    if (Cc) {
+        float* cout = right ? gRc : gLc;
+        const int coff = right ? G + Cc : G;
+        for (int idx = tid; idx < Cc * CV_WT; idx += CV_THREADS) {
+            const int c = idx % Cc, tl = idx / Cc;       // channel fastest: 4*Cc-byte contiguous gvol reads
+            const int t = t0 + tl;
+            if (t >= W) continue;
+            float a0 = 0.f, a1 = 0.f;
+            int d = 0;
+            for (; d + 1 < D; d += 2) {
+                const int w0_ = right ? t + d : t, w1_ = right ? t + d + 1 : t;
+                const bool v0 = right ? (w0_ < W) : (!mask_left || t >= d);
+                const bool v1 = right ? (w1_ < W) : (!mask_left || t >= d + 1);
+                const float x0 = v0 ? gv_row[d * dstride + (size_t)w0_ * CT + coff + c] : 0.f;
+                const float x1 = v1 ? gv_row[(d + 1) * dstride + (size_t)w1_ * CT + coff + c] : 0.f;
+                a0 += x0;
+                a1 += x1;
+            }
+            if (d < D) {
+                const int w0_ = right ? t + d : t;
+                const bool v0 = right ? (w0_ < W) : (!mask_left || t >= d);
+                if (v0) a0 += gv_row[d * dstride + (size_t)w0_ * CT + coff + c];
+            }
+            cout[(((size_t)b * Cc + c) * H + h) * W + t] = a0 + a1;
         }
     }
 }
@@ -264,12 +319,21 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     if (Cc) STX_REQUIRE(Lc && Rc, "cost_volume_fwd: concat features missing");
     const int cpg = G ? Cg / G : 4;
     STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, "cost_volume_fwd: channels per group %d not in {4,8,16}", cpg);
-    const int NR = CV_WT + CV_DC - 1;
+    // disparities per workgroup: split D evenly into chunks of <= 24 (two workgroups per CU for the
+    // 320-channel gwc features: (16 + 16+24-1) columns x 1296 B = 71 KB of LDS each)
+    const int nchunk = stx_cdiv(D, 24);
+    int DC = stx_cdiv(D, nchunk);
     size_t lds = 0;
-    if (G) lds += (size_t)(CV_WT + NR) * (Cg + 4) * 4;
-    if (Cc) lds += (size_t)(CV_WT + NR) * (Cc + 4) * 4;
-    STX_REQUIRE(lds <= 160 * 1024, "cost_volume_fwd: feature tile (%zu B) exceeds LDS", lds);
-    dim3 grid(stx_cdiv(W, CV_WT), stx_cdiv(D, CV_DC), B * H);
+    for (;;) {
+        const int NR = CV_WT + DC - 1;
+        lds = 0;
+        if (G) lds += (size_t)(CV_WT + NR) * (Cg + 4) * 4;
+        if (Cc) lds += (size_t)(CV_WT + NR) * (Cc + 4) * 4;
+        if (lds <= 160 * 1024 || DC == 1) break;
+        DC = (DC + 1) / 2;
+    }
+    STX_REQUIRE(lds <= 160 * 1024 && DC <= CV_MAX_DC, "cost_volume_fwd: feature tile (%zu B) exceeds LDS", lds);
+    dim3 grid(stx_cdiv(W, CV_WT), stx_cdiv(D, DC), B * H);
     hipStream_t st = (hipStream_t)stream;
 #define CV_LAUNCH(CPG_)                                                                                       \
     {                                                                                                         \
@@ -277,7 +341,7 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
             hipFuncSetAttribute((const void*)cost_volume_fwd_kernel<CPG_>,                                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
         hipLaunchKernelGGL(cost_volume_fwd_kernel<CPG_>, grid, dim3(CV_THREADS), lds, st, Lg, Rg, Cg, G, Lc, \
-                           Rc, Cc, scale, vol, H, W, D, mask_left);                                           \
+                           Rc, Cc, scale, vol, H, W, D, DC, mask_left);                                       \
     }
     if (cpg == 4) CV_LAUNCH(4) else if (cpg == 8) CV_LAUNCH(8) else CV_LAUNCH(16)
 #undef CV_LAUNCH
@@ -290,14 +354,16 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
     stx_begin();
     STX_REQUIRE(gvol && B > 0 && H > 0 && W > 0 && D > 0, "cost_volume_bwd: bad shape");
     STX_REQUIRE(G % 4 == 0 && Cc % 4 == 0 && (G + Cc) > 0, "cost_volume_bwd: bad channel counts");
-    if (G) STX_REQUIRE(Lg && Rg && gLg && gRg && Cg % G == 0, "cost_volume_bwd: gwc operands missing");
+    if (G) {
+        STX_REQUIRE(Lg && Rg && gLg && gRg && Cg % G == 0, "cost_volume_bwd: gwc operands missing");
+        const int cpg = Cg / G;
+        STX_REQUIRE(CVB_CH % cpg == 0 && (CVB_CH / cpg) % 4 == 0 && (Cg % CVB_CH) % (4 * cpg) == 0,
+                    "cost_volume_bwd: channels per group %d unsupported", cpg);
+    }
     if (Cc) STX_REQUIRE(gLc && gRc, "cost_volume_bwd: concat outputs missing");
-    const int NC = CV_WT + D - 1;
-    const size_t lds = ((size_t)2 * NC * (CVB_CH + 4) + 2 * CVB_CH * (CV_WT + 1)) * 4;
-    STX_REQUIRE(lds <= 160 * 1024, "cost_volume_bwd: D=%d too large for the LDS tile", D);
-    dim3 grid(stx_cdiv(W, CV_WT), 1, B * H);
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void*)cost_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = ((size_t)CVB_DC * CV_WT * 40 + (size_t)(CV_WT + CVB_DC - 1) * (CVB_CH + 4) +
+                        (size_t)CVB_CH * (CV_WT + 1)) * 4;
+    dim3 grid(stx_cdiv(W, CV_WT), 2, B * H);
     hipLaunchKernelGGL(cost_volume_bwd_kernel, grid, dim3(CV_THREADS), lds, (hipStream_t)stream, gvol, Lg, Rg,
                        G ? Cg : 0, G, Cc, gLg, gRg, gLc, gRc, H, W, D, mask_left);
     return stx_check_launch("cost_volume_bwd");

@@ -18,15 +18,41 @@ class FlatGradSync:
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
         self.world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def zero_grad(self):
-        """Zero the bucket in place (keeps the .grad views alive; do not call model.zero_grad(set_to_none=True))."""
+        """Zero the bucket in place (keeps the .grad views alive; do not call model.zero_grad(set_to_none=True)).
+        backward() then accumulates straight into the bucket (one small add kernel per parameter)."""
         self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def detach_grads(self):
+        """Alternative to zero_grad(): drop the .grad views so that backward() *assigns* fresh gradients
+        (no per-parameter accumulate kernels); pack() then gathers them into the bucket with one
+        fused multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def pack(self):
+        grads, views = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                grads.append(p.grad)
+                views.append(v)
+        if grads:
+            torch._foreach_copy_(views, grads)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce(self, async_op=False):
         """Average gradients over ranks with a single collective; returns the work handle if async."""

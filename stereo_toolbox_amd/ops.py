@@ -151,6 +151,29 @@ def conv3d_wgrad(fine, coarse, ks, stride):
     return dw
 
 
+def _is_c1(w, ks, stride, transposed):
+    """Classifier tail Conv3d(Cin, 1, 3, padding=1): served by the VALU kernels of conv_c1.hip."""
+    return (not transposed) and ks == 3 and stride == 1 and w.shape[0] == 1 and w.shape[1] % 16 == 0 and w.shape[1] <= 64
+
+
+def conv3d_c1_forward(x, w, residual=None):
+    """x [B,D,H,W,Cin], w [1,Cin,3,3,3] -> [B,D,H,W,1] (+ residual [B,D,H,W,1])."""
+    _chk(x, "x", 5)
+    _chk(w, "weight", 5)
+    B, D, H, W, Cin = x.shape
+    out = torch.empty(B, D, H, W, 1, dtype=torch.float32, device=x.device)
+    _call("stx_conv3d_c1_fwd", _p(x), _p(w), _p(residual), _p(out), B, D, H, W, Cin)
+    return out
+
+
+def conv3d_c1_wgrad(x, gy):
+    B, D, H, W, Cin = x.shape
+    ws = _WS.get("c1wgrad", get_lib().raw("stx_conv3d_c1_wgrad_workspace_floats")(Cin), x.device)
+    dw = torch.empty(1, Cin, 3, 3, 3, dtype=torch.float32, device=x.device)
+    _call("stx_conv3d_c1_wgrad", _p(x), _p(gy), _p(dw), _p(ws), B, D, H, W, Cin)
+    return dw
+
+
 class ConvRawFn(torch.autograd.Function):
     """z = conv(x, w) (or transposed conv), raw output + BN partial sums; backward = dgrad + wgrad
     on the same MFMA kernels with re-packed weights."""
@@ -158,7 +181,9 @@ class ConvRawFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, ks, stride, transposed, want_stats):
         _chk(x, "x", 5)
-        if transposed:
+        if _is_c1(w, ks, stride, transposed) and not want_stats:
+            z, stats = conv3d_c1_forward(x, w.contiguous()), None
+        elif transposed:
             Cout = w.shape[1]
             z, stats = deconv3d_forward(x, pack_weight(w, 2), Cout, want_stats=want_stats)
         else:
@@ -198,8 +223,12 @@ class ConvRawFn(torch.autograd.Function):
                 else:                     # stride-2 dgrad = transposed conv of gz
                     gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W))
             if ctx.needs_input_grad[1]:
-                gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
-                gw = conv3d_wgrad(x, gz_w, ks, stride)[:Co].reshape(w.shape)
+                if _is_c1(w, ks, stride, transposed):
+                    gw = conv3d_c1_wgrad(x, gz)
+                else:
+                    gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
+                    x_w = x if Ci % 32 == 0 else _pad_channels(x, (Ci + 31) // 32 * 32)
+                    gw = conv3d_wgrad(x_w, gz_w, ks, stride)[:Co, :Ci].reshape(w.shape)
         return gx, gw, None, None, None, None
 
 

@@ -263,6 +263,29 @@ def test_deconv3d_wgrad(be):
     _close(run_wgrad(be, gy, x, 3, 2).view_as(w), w.grad)
 
 
+@pytest.mark.parametrize("case", [(1, 32, 3, 5, 37), (2, 16, 2, 4, 32), (1, 64, 2, 9, 40)])
+def test_conv3d_c1_fwd_wgrad(be, case):
+    """Classifier tail Conv3d(Cin, 1, 3, padding=1) on the dedicated VALU kernels."""
+    B, Cin, D, H, W = case
+    torch.manual_seed(11)
+    x = torch.randn(B, Cin, D, H, W)
+    w = (torch.randn(1, Cin, 3, 3, 3) * 0.1).requires_grad_()
+    res = torch.randn(B, 1, D, H, W)
+    y = F.conv3d(x, w, None, 1, 1)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xl = be.dev(ndhwc(x))
+    out = be.empty(B, D, H, W)
+    be.call("stx_conv3d_c1_fwd", ptr(xl), ptr(be.dev(w.detach())), None, ptr(out), B, D, H, W, Cin)
+    _close(out, y.detach().squeeze(1))
+    be.call("stx_conv3d_c1_fwd", ptr(xl), ptr(be.dev(w.detach())), ptr(be.dev(res)), ptr(out), B, D, H, W, Cin)
+    _close(out, (y.detach() + res).squeeze(1))
+    ws = be.empty(be.raw("stx_conv3d_c1_wgrad_workspace_floats")(Cin))
+    dw = be.empty(1, Cin, 27)
+    be.call("stx_conv3d_c1_wgrad", ptr(xl), ptr(be.dev(gy)), ptr(dw), ptr(ws), B, D, H, W, Cin)
+    _close(dw.view_as(w), w.grad)
+
+
 # ------------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("case", [(1000, 32, False, True, False), (777, 64, True, True, False),
                                   (500, 32, False, False, True), (640, 128, False, True, True)])

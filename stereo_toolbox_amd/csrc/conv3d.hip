@@ -168,44 +168,47 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
             stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val);
         }
         __syncthreads();
-        // B operand (packed weights, L2-resident) is register double-buffered one tap ahead so that
-        // its ~L2 latency hides under the current tap's 16*MT*NT MFMAs.
+        // Both operands are register double-buffered one tap ahead (A from the LDS tile, B = packed
+        // weights from L2); the scheduling fences keep "issue next tap's loads, then this tap's
+        // MFMAs" -- otherwise hipcc sinks the loads next to their use and every tap eats an L2 round trip.
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        float4 bcur[NQC][NT], bnxt[NQC][NT];
-#pragma unroll
-        for (int q = 0; q < NQC; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = stx_ld4(wq + (size_t)(q * NT + nt) * 256);
-        for (int tap = 0; tap < T; ++tap) {
+        float4 bcur[NQC][NT], bnxt[NQC][NT], acur[NQC][MT], anxt[NQC][MT];
+        auto load_tap = [&](int tap, float4 (&av)[NQC][MT], float4 (&bv)[NQC][NT]) {
             const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
             const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
                                       : ((kd * EH + kh) * EWS + kw) * VS;
-            const int tn = tap + 1 < T ? tap + 1 : tap;
-            const float* wnext = wq + (size_t)tn * NQ * NT * 256;
+            const float* wtap = wq + (size_t)tap * NQ * NT * 256;
 #pragma unroll
-            for (int q = 0; q < NQC; ++q)
+            for (int q = 0; q < NQC; ++q) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bnxt[q][nt] = stx_ld4(wnext + (size_t)(q * NT + nt) * 256);
-            float4 av[NQC][MT];
-#pragma unroll
-            for (int q = 0; q < NQC; ++q)
+                for (int nt = 0; nt < NT; ++nt) bv[q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
+            }
+        };
+        load_tap(0, acur, bcur);
+        for (int tap = 0; tap < T; ++tap) {
+            if (tap + 1 < T) load_tap(tap + 1, anxt, bnxt);
+            STX_SCHED_BARRIER();
 #pragma unroll
             for (int q = 0; q < NQC; ++q)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
                     }
+            STX_SCHED_BARRIER();
 #pragma unroll
-            for (int q = 0; q < NQC; ++q)
+            for (int q = 0; q < NQC; ++q) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acur[q][m] = anxt[q][m];
+            }
         }
     }
 
@@ -228,6 +231,214 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
         }
     }
     if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 convolution with Cin = 32, software-pipelined along D ("march" kernel).
+//
+// conv3d_igemm_kernel above stages a tile, computes, stages the next: co-resident workgroups run in
+// lock-step, so the matrix pipe idles while they all wait for their halo tiles (measured: MFMA busy
+// 60 %, rocprofv3 PMC, profiles/r01_pmc_conv_32_32_L0.txt).  Here a workgroup (8 waves) owns a column
+// of 4 x 32 output voxels and marches through a segment of output planes d.  LDS holds a ring of
+// three input planes (6 x 34 voxels x 36 dwords = 29 KB each).  While plane d is being multiplied,
+// input plane d+2 is already in flight into registers (4 float4 per lane); it is written into the
+// ring slot of plane d-1 once every wave has finished with it.  Each input voxel is staged
+// 6*34/(4*32) = 1.6 x instead of 4.25 x, and the loads are always a full plane ahead of their use.
+// Two waves share one 32-voxel row block and split GEMM-K by channel halves (2 of the 4 8-channel
+// K steps of every tap each = 216 MFMAs per plane per wave); they exchange half of their 32x32
+// accumulator through LDS and each finishes 16 of the rows (epilogue as above).
+constexpr int MARCH_TH = 4, MARCH_EH = 6, MARCH_EW = 34, MARCH_VS = 36;
+constexpr int MARCH_SLOT = MARCH_EH * MARCH_EW * MARCH_VS;      // floats per ring slot
+constexpr int MARCH_THREADS = 512;
+constexpr int MARCH_NF4 = (MARCH_EH * MARCH_EW * 8 + MARCH_THREADS - 1) / MARCH_THREADS;   // 4
+
+struct MarchArgs {
+    ConvArgs c;
+    int nseg, dseg;      // D segments per column and planes per segment
+};
+
+template <int NT>
+__global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs ma) {
+    const ConvArgs& a = ma.c;
+    STX_DYN_SMEM(smem);
+    float* ring = reinterpret_cast<float*>(smem);                       // [3][MARCH_SLOT]
+    float* xch = ring + 3 * MARCH_SLOT;                                  // [4 rows][2][NT][8][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int th = wave & 3, kh2 = wave >> 2;                            // row block, K half
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int wt = bid % a.nWt; bid /= a.nWt;
+    const int ht = bid % a.nHt; bid /= a.nHt;
+    const int seg = bid % ma.nseg;
+    const int b = bid / ma.nseg;
+    const int oh0 = ht * MARCH_TH, ow0 = wt * 32;
+    const int d_lo = seg * ma.dseg;
+    const int d_hi = (d_lo + ma.dseg < a.Do) ? d_lo + ma.dseg : a.Do;    // output planes [d_lo, d_hi)
+
+    // per-lane staging assignment: float4 number idx = tid + k*512 of a plane (voxel v = idx/8, chunk f = idx%8)
+    float4 stg[MARCH_NF4];
+    auto load_plane = [&](int pd) {
+#pragma unroll
+        for (int k = 0; k < MARCH_NF4; ++k) {
+            const int idx = tid + k * MARCH_THREADS;
+            const int v = idx >> 3, f = idx & 7;
+            const int wx = v % MARCH_EW, hy = v / MARCH_EW;
+            const int gh = oh0 - 1 + hy, gw = ow0 - 1 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < MARCH_EH * MARCH_EW && pd >= 0 && pd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * 32 + 4 * f);
+            stg[k] = val;
+        }
+    };
+    auto store_plane = [&](int pd) {
+        float* slot = ring + ((pd + 3) % 3) * MARCH_SLOT;
+#pragma unroll
+        for (int k = 0; k < MARCH_NF4; ++k) {
+            const int idx = tid + k * MARCH_THREADS;
+            const int v = idx >> 3, f = idx & 7;
+            if (v < MARCH_EH * MARCH_EW) stx_st4(slot + v * MARCH_VS + 4 * f, stg[k]);
+        }
+    };
+
+    load_plane(d_lo - 1);
+    store_plane(d_lo - 1);
+    load_plane(d_lo);
+    store_plane(d_lo);
+    load_plane(d_lo + 1);
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    const int abase = (th * MARCH_EW + i) * MARCH_VS + 4 * half + 16 * kh2;
+    // packed weights of my K half (q = 2*kh2, 2*kh2+1): wave-uniform base (provably: readfirstlane) +
+    // a 32-bit per-lane offset, so every tap's load is `global_load v, v_off, s[base] offset:imm`
+    // instead of 54 precomputed 64-bit address pairs.
+    const int kh2u = __builtin_amdgcn_readfirstlane(kh2);
+    const float* wq = a.wp + (size_t)(2 * kh2u) * NT * 256;
+    const unsigned wlane = (unsigned)lane * 4u;
+
+    for (int d = d_lo; d < d_hi; ++d) {
+        store_plane(d + 1);                 // slot of plane d-2: free since the barrier ending iteration d-1
+        __syncthreads();
+        if (d + 2 <= d_hi) load_plane(d + 2);
+
+        // Two independent accumulator chains per column block (one per K step of the tap): a single
+        // chain of dependent fp32 MFMAs does not keep the matrix pipe full.
+        f32x16 acc2[2][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { acc2[0][nt] = zero16(); acc2[1][nt] = zero16(); }
+        // Operand ping-pong, one tap ahead.  sched_barrier pins "issue the next tap's loads, THEN the
+        // current tap's MFMAs": left alone, hipcc sinks the weight loads next to their use and every
+        // tap waits a full L2 round trip (s_waitcnt vmcnt right in front of the MFMAs: 60 % MFMA busy).
+        // The 27 taps are fully unrolled: every LDS / weight offset is an immediate, so a tap costs
+        // 2 ds_read_b128 + 2*NT global_load_dwordx4 + 8*NT MFMAs and almost no address arithmetic
+        // (a clump of scalar/vector address code between MFMA groups leaves the matrix pipe idle: an
+        // in-order wave can only hide a handful of instructions behind each 64-cycle MFMA).
+        // The fence after each tap keeps the NEXT tap's loads at least one tap ahead of their use while
+        // still letting the scheduler interleave them with this tap's MFMAs.
+        float4 av[2][2], bv[2][2][NT];
+        const float* slotp[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) slotp[kd] = ring + ((d - 1 + kd + 3) % 3) * MARCH_SLOT + abase;
+        auto load_tap = [&](int tap, int buf) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const float* sl = slotp[kd] + (kh * MARCH_EW + kw) * MARCH_VS;
+            av[buf][0] = stx_ld4(sl);
+            av[buf][1] = stx_ld4(sl + 8);
+            unsigned wl = wlane;
+            STX_OPAQUE_VGPR(wl);     // keep the 54 per-tap weight addresses out of (spilled) registers
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bv[buf][q][nt] = stx_ld4((wq + (size_t)(tap * 4 * NT * 256 + (q * NT + nt) * 256)) + wl);
+        };
+        auto mma_tap = [&](int buf) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc2[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][0].x, bv[buf][0][nt].x, acc2[0][nt], 0, 0, 0);
+                acc2[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][1].x, bv[buf][1][nt].x, acc2[1][nt], 0, 0, 0);
+                acc2[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][0].y, bv[buf][0][nt].y, acc2[0][nt], 0, 0, 0);
+                acc2[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][1].y, bv[buf][1][nt].y, acc2[1][nt], 0, 0, 0);
+                acc2[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][0].z, bv[buf][0][nt].z, acc2[0][nt], 0, 0, 0);
+                acc2[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][1].z, bv[buf][1][nt].z, acc2[1][nt], 0, 0, 0);
+                acc2[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][0].w, bv[buf][0][nt].w, acc2[0][nt], 0, 0, 0);
+                acc2[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][1].w, bv[buf][1][nt].w, acc2[1][nt], 0, 0, 0);
+            }
+        };
+        load_tap(0, 0);
+        STX_SCHED_BARRIER();
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) load_tap(tap + 1, (tap + 1) & 1);
+            mma_tap(tap & 1);
+            STX_SCHED_BARRIER();
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = acc2[0][nt] + acc2[1][nt];
+        // exchange: K-half 0 keeps accumulator regs 0..7 (rows 0-3, 8-11 (+4*half)), K-half 1 keeps 8..15
+        float* mine = xch + (((th * 2 + kh2) * NT) * 8) * 64;
+        float* theirs = xch + (((th * 2 + (kh2 ^ 1)) * NT) * 8) * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) mine[(nt * 8 + r) * 64 + lane] = acc[nt][kh2 ? r : 8 + r];
+        __syncthreads();                    // also: every wave is done reading ring slot (d-1)%3
+        const int oh = oh0 + th;
+        int nrows = (oh < a.Ho) ? (a.Wo - ow0) : 0;
+        nrows = nrows > 32 ? 32 : nrows;
+        const size_t vox0 = (((size_t)b * a.Do + d) * a.Ho + oh) * a.Wo + ow0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i;
+            const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+            const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int rr = kh2 ? 8 + r : r;
+                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+                if (row < nrows && n < a.Cout) {
+                    const size_t idx = (vox0 + row) * a.Cout + n;
+                    float v = acc[nt][rr] + theirs[(nt * 8 + r) * 64 + lane];
+                    s1[nt] += v;
+                    s2[nt] = fmaf(v, v, s2[nt]);
+                    v = fmaf(v, sc, bs);
+                    if (a.residual) v += a.residual[idx];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    a.out[idx] = v;
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        // 8 waves: reduce through the (now idle) ring
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            s1[nt] += __shfl_xor(s1[nt], 32);
+            s2[nt] += __shfl_xor(s2[nt], 32);
+        }
+        __syncthreads();
+        if (lane < 32) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                ring[((wave * NT + nt) * 32 + lane) * 2 + 0] = s1[nt];
+                ring[((wave * NT + nt) * 32 + lane) * 2 + 1] = s2[nt];
+            }
+        }
+        __syncthreads();
+        if (tid < NT * 32 && tid < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                t1 += ring[((w * NT) * 32 + tid) * 2 + 0];
+                t2 += ring[((w * NT) * 32 + tid) * 2 + 1];
+            }
+            const size_t slab = (size_t)blockIdx.x;
+            a.stats[slab * 2 * a.Cout + tid] = t1;
+            a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,10 +776,33 @@ extern "C" int stx_conv3d_pack_weight(const float* w, float* wp, int A, int Bd, 
     return stx_check_launch("conv3d_pack_weight");
 }
 
-// Number of workgroups (= rows of the `stats` partial slab) stx_conv3d_fwd launches per batch item.
+// D segmentation of the march kernel: enough workgroups for 256 CUs (1 resident workgroup each)
+// with little tail, but segments long enough to amortise the 2-plane prologue.
+static int march_nseg(int B, int D, int H, int W) {
+    const int cols = B * stx_cdiv(H, MARCH_TH) * stx_cdiv(W, 32);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int nseg = 1; nseg <= D; ++nseg) {
+        const int dseg = stx_cdiv(D, nseg);
+        if (dseg < 3 && nseg > 1) break;
+        const double rounds = (double)stx_cdiv(cols * stx_cdiv(D, dseg), 256);
+        const double cost = rounds * (dseg + 0.6);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = nseg; }
+    }
+    return best;
+}
+static bool use_march(int Cin, int Cout, int ks, int stride) {
+    static const int off = getenv("STX_NO_MARCH") ? 1 : 0;
+    return !off && ks == 3 && stride == 1 && Cin == 32 && Cout <= 64;
+}
+
+// Rows of the `stats` partial slab stx_conv3d_fwd writes per batch item (>= its workgroup count / B;
+// unused rows are zero-filled).
 extern "C" int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo) {
     stx_begin();
-    return stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
+    const int a = stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
+    const int m = Do * stx_cdiv(Ho, MARCH_TH) * stx_cdiv(Wo, 32);     // upper bound for the march kernel
+    return a > m ? a : m;
 }
 extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) {
     stx_begin(); return Di * stx_cdiv(Hi, 2) * stx_cdiv(Wi, 32); }
@@ -590,6 +824,29 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     a.Wo = (Wi + 2 * pad - ks) / stride + 1;
     a.nDt = stx_cdiv(a.Do, CONV_TD); a.nHt = stx_cdiv(a.Ho, CONV_TH); a.nWt = stx_cdiv(a.Wo, 32);
     const int NT = conv_nt(Cout);
+    // the slab has stx_conv3d_fwd_blocks() rows per batch item; rows no workgroup writes must read 0
+    if (stats)
+        hipMemsetAsync(stats, 0, (size_t)B * stx_conv3d_fwd_blocks(a.Do, a.Ho, a.Wo) * 2 * Cout * 4, (hipStream_t)stream);
+    if (use_march(Cin, Cout, ks, stride)) {
+        MarchArgs ma;
+        ma.c = a;
+        ma.c.nHt = stx_cdiv(a.Ho, MARCH_TH);
+        ma.c.nWt = stx_cdiv(a.Wo, 32);
+        ma.nseg = march_nseg(B, a.Do, a.Ho, a.Wo);
+        ma.dseg = stx_cdiv(a.Do, ma.nseg);
+        ma.nseg = stx_cdiv(a.Do, ma.dseg);
+        const int nblk = B * ma.nseg * ma.c.nHt * ma.c.nWt;
+        const size_t lds = ((size_t)3 * MARCH_SLOT + (size_t)4 * 2 * NT * 8 * 64) * 4;
+        hipStream_t st = (hipStream_t)stream;
+        if (NT == 1) {
+            hipFuncSetAttribute((const void*)conv3d_march_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(conv3d_march_kernel<1>, dim3(nblk), dim3(MARCH_THREADS), lds, st, ma);
+        } else {
+            hipFuncSetAttribute((const void*)conv3d_march_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(conv3d_march_kernel<2>, dim3(nblk), dim3(MARCH_THREADS), lds, st, ma);
+        }
+        return stx_check_launch("conv3d_fwd(march)");
+    }
     // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: keep it to 8-channel K chunks (79 KB).
     const int CK = (stride == 2) ? 8 : conv_pick_ck(Cin);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
@@ -661,7 +918,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
     static const int nw_env = getenv("STX_WGRAD_WAVES") ? atoi(getenv("STX_WGRAD_WAVES")) : 0;
-    const int NW = (nw_env == 4 || nw_env == 8) ? nw_env : 4;
+    const int NW = (nw_env == 4 || nw_env == 8) ? nw_env : 8;   // 8 waves: 4 taps (64 acc regs) per wave, measured +22 % over 4 waves
 #define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, LDS_)                                                                   \
     {                                                                                                             \
         const size_t lds = (LDS_);                                                                                \

@@ -33,35 +33,48 @@ constexpr int CV_WT = 16;       // output columns per workgroup
 constexpr int CV_THREADS = 256;
 constexpr int CV_MAX_DC = 32;   // disparities per workgroup (runtime DC <= this)
 
+// LDS image of a feature tile: [column][C+4 dwords].  A gwc work item (column, quad q) reads the NJ
+// 16-byte chunks of its 4*CPG channels; with the plain layout quads 2 apart (NJ=8) land on the same
+// 16-B slot of the 256-B bank row (3-way conflicts).  The chunks of quad q are therefore rotated by
+// (q / (16/NJ)) inside the quad: slot(column, q, j) covers all 16 slots across the lanes of a
+// ds_read_b128 group.  NJ = 0 (concat features) keeps the plain layout.
+template <int NJ>
+__device__ __forceinline__ int cv_phys_channel(int c) {
+    if constexpr (NJ == 0) {
+        return c;
+    } else {
+        constexpr int P = (NJ >= 16) ? 1 : 16 / NJ;
+        const int q = c / (4 * NJ), j = (c / 4) % NJ, e = c & 3;
+        return q * 4 * NJ + 4 * ((j + q / P) % NJ) + e;
+    }
+}
+
 // Stage `ncols` columns x `C` channels of one NCHW feature row into lds[col][C+4] (transposed).
-// Lanes run along the image row, so every global load instruction reads contiguous 64..256-B row
-// segments; PER rows share one instruction when the segment is short.  The transposing 4-byte LDS
-// writes land on 8 banks x 4 lanes (row stride C+4 dwords == 4 mod 32): 2x the conflict-free
-// cost, which is noise next to the 16-byte operand reads the layout is built for.
-template <int PER>   // rows per wave-instruction: 64/PER lanes per row
+// Work is flattened over (channel, column) so all 64 lanes stay busy for any tile width, and every
+// lane keeps BATCH independent global loads in flight before the first LDS write (the tile is read
+// once per workgroup: latency, not bandwidth, is what this loop has to hide).  Lanes run along the
+// image row, so a wave reads contiguous row segments.
+template <int NJ>
 __device__ __forceinline__ void cv_stage_rows(const float* __restrict__ src,  // &F[b][0][h][0]
                                               int C, int HW, int W, int x_first, int ncols,
                                               float* lds, int tid) {
-    constexpr int LPR = 64 / PER;
-    constexpr int BATCH = 8;          // independent global loads in flight per lane (latency hiding)
-    const int lane = tid & 63, wave = tid >> 6, nwaves = CV_THREADS >> 6;
-    const int r = lane / LPR, xl = lane % LPR;
+    constexpr int BATCH = 16;
     const int RS = C + 4;
-    for (int col = xl; col < ncols; col += LPR) {
-        const int x = x_first + col;
-        const bool xin = x >= 0 && x < W;
-        for (int c0 = wave * PER * BATCH; c0 < C; c0 += nwaves * PER * BATCH) {
-            float v[BATCH];
+    const int total = C * ncols;
+    for (int e0 = tid; e0 < total; e0 += CV_THREADS * BATCH) {
+        float v[BATCH];
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int c = c0 + k * PER + r;
-                v[k] = (xin && c < C) ? src[(size_t)c * HW + x] : 0.f;
-            }
+        for (int k = 0; k < BATCH; ++k) {
+            const int e = e0 + k * CV_THREADS;
+            const int c = e / ncols, col = e - c * ncols;
+            const int x = x_first + col;
+            v[k] = (e < total && x >= 0 && x < W) ? src[(size_t)c * HW + x] : 0.f;
+        }
 #pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int c = c0 + k * PER + r;
-                if (c < C) lds[col * RS + c] = v[k];
-            }
+        for (int k = 0; k < BATCH; ++k) {
+            const int e = e0 + k * CV_THREADS;
+            const int c = e / ncols, col = e - c * ncols;
+            if (e < total) lds[col * RS + cv_phys_channel<NJ>(c)] = v[k];
         }
     }
 }
@@ -91,12 +104,12 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
     float* Rc_s = Lc_s + (Cc ? CV_WT * RSc : 0);
 
     if (G) {
-        cv_stage_rows<4>(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, Lg_s, tid);
-        cv_stage_rows<1>(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, Rg_s, tid);
+        cv_stage_rows<CPG>(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, Lg_s, tid);
+        cv_stage_rows<CPG>(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, Rg_s, tid);
     }
     if (Cc) {
-        cv_stage_rows<4>(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, Lc_s, tid);
-        cv_stage_rows<1>(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, Rc_s, tid);
+        cv_stage_rows<0>(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, Lc_s, tid);
+        cv_stage_rows<0>(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, Rc_s, tid);
     }
     __syncthreads();
 
@@ -111,9 +124,11 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
         const float* sc = scale ? scale + (((size_t)b * D + d0) * H + h) * W + w : nullptr;
         if (q < GQ) {
             // 4 groups x CPG channels of the left feature stay in registers.
+            constexpr int P = (CPG >= 16) ? 1 : 16 / CPG;
+            const int rot = q / P;                   // chunk rotation of this quad (cv_phys_channel)
             float4 l[CPG];
 #pragma unroll
-            for (int j = 0; j < CPG; ++j) l[j] = stx_ld4(Lg_s + wl * RSg + q * 4 * CPG + 4 * j);
+            for (int j = 0; j < CPG; ++j) l[j] = stx_ld4(Lg_s + wl * RSg + q * 4 * CPG + 4 * ((j + rot) % CPG));
             for (int dd = 0; dd < dend; ++dd) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (w >= d0 + dd) {
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
 #pragma unroll
                         for (int j = 0; j < CPG / 4; ++j) {
                             const float4 a = l[g * (CPG / 4) + j];
-                            const float4 v = stx_ld4(r + (g * (CPG / 4) + j) * 4);
+                            const float4 v = stx_ld4(r + ((g * (CPG / 4) + j + rot) % CPG) * 4);
                             s = fmaf(a.x, v.x, s);
                             s = fmaf(a.y, v.y, s);
                             s = fmaf(a.z, v.z, s);

@@ -11,10 +11,17 @@
 #include "hipemu.h"
 #define STX_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define stx_exp(x) expf(x)
+#define STX_SCHED_BARRIER() ((void)0)
+#define STX_OPAQUE_VGPR(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define stx_exp(x) __expf(x)
+// Instruction-scheduling fence (guide 5.4 rule 18 / T19): nothing moves across it.
+#define STX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Makes a VGPR value opaque to the optimiser at this point (blocks hoisting of address math that
+// would otherwise be precomputed into dozens of live registers; guide 5.7 item 3).
+#define STX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
 #include <stdint.h>
 

@@ -69,29 +69,28 @@ class _Workspace:
 
 
 _WS = _Workspace()
-_PACK_CACHE = {}
 
 
-def pack_weight(w, mode, cache=False):
+def pack_weight(w, mode, owner=None):
     """Device-side re-layout of a torch conv weight [A][B][k,k,k] into MFMA B-operand order.
-    mode 0: conv fwd / deconv dgrad;  1: stride-1 conv dgrad;  2: deconv fwd / stride-2 conv dgrad."""
+    mode 0: conv fwd / deconv dgrad;  1: stride-1 conv dgrad;  2: deconv fwd / stride-2 conv dgrad.
+    `owner` (the nn.Parameter) enables caching for inference: the packed copy is stored ON the
+    parameter object (so it dies with it -- a dict keyed by data_ptr would hand stale weights to a
+    new model whose storage reuses the address) and is refreshed when the version counter moves."""
     _chk(w, "weight", 5)
-    key = None
-    if cache:
-        key = (w.data_ptr(), w._version, mode, tuple(w.shape))
-        hit = _PACK_CACHE.get(key)
-        if hit is not None:
-            return hit
+    if owner is not None:
+        cache = owner.__dict__.setdefault("_stx_packed", {})
+        hit = cache.get(mode)
+        if hit is not None and hit[0] == (owner._version, owner.data_ptr()):
+            return hit[1]
     A, Bd = w.shape[0], w.shape[1]
     T = w.shape[2] * w.shape[3] * w.shape[4]
     K, N = (Bd, A) if mode == 0 else (A, Bd)
     n = get_lib().raw("stx_conv3d_packed_floats")(K, N, T)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("stx_conv3d_pack_weight", _p(w), _p(wp), A, Bd, T, mode)
-    if cache:
-        if len(_PACK_CACHE) > 512:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = wp
+    if owner is not None:
+        cache[mode] = ((owner._version, owner.data_ptr()), wp)
     return wp
 
 

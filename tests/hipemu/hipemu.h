@@ -201,7 +201,7 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
-static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values
 
 namespace hipemu {
 

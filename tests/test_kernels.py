@@ -157,6 +157,8 @@ CONV_CASES = [
     (1, 32, 1, 2, 4, 35, 3, 1),      # classifier tail Conv3d(32->1)
     (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
     (1, 64, 128, 4, 4, 24, 3, 2),
+    (2, 32, 64, 7, 6, 40, 3, 1),     # march kernel, 2 column blocks (NT=2), ragged H/W, several D segments
+    (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 3 tiles
 ]
 
 

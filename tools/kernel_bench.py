@@ -62,7 +62,8 @@ def pack(w, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--only", default="")
+    ap.add_argument("--only", default="", help="substring filter on kernel names")
+    ap.add_argument("--skip-wgrad", action="store_true")
     ap.add_argument("--H", type=int, default=576)
     ap.add_argument("--W", type=int, default=960)
     ap.add_argument("--D", type=int, default=192)
@@ -98,7 +99,7 @@ def main():
         ("conv1x1_64_64_L1", 1, 64, 64, 1, 1), ("conv1x1_32_32_L0", 0, 32, 32, 1, 1), ("conv_32_1_L0", 0, 32, 1, 3, 1),
     ]
     for name, lv, Cin, Cout, ks, s in convs:
-        if not want(name):
+        if not (want(name + "_fwd") or want(name + "_wgrad")):
             continue
         D, Hh, Ww = L[lv]
         x = torch.randn(B, D, Hh, Ww, Cin, device=dev)
@@ -109,10 +110,11 @@ def main():
         nblk = lib.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
         st = torch.empty(B * nblk, 2, Cout, device=dev)
         fl = 2.0 * B * Do * Ho * Wo * Cout * Cin * ks ** 3
-        ms = timeit(lambda: lib.call("stx_conv3d_fwd", P(x), P(wp), P(out), None, None, None, P(st), B, D, Hh, Ww, Cin,
-                                     Cout, ks, s, 0, stream()), it)
-        report(name + "_fwd", ms, flops=fl)
-        if Cout % 32 == 0 and Cin % 32 == 0:
+        if want(name + "_fwd"):
+            ms = timeit(lambda: lib.call("stx_conv3d_fwd", P(x), P(wp), P(out), None, None, None, P(st), B, D, Hh, Ww,
+                                         Cin, Cout, ks, s, 0, stream()), it)
+            report(name + "_fwd", ms, flops=fl)
+        if Cout % 32 == 0 and Cin % 32 == 0 and not a.skip_wgrad and want(name + "_wgrad"):
             n = lib.raw("stx_conv3d_wgrad_workspace_floats")(B, Do, Ho, Wo, Cin, Cout, ks, s)
             ws = torch.empty(n, device=dev)
             dw = torch.empty(Cout, Cin, ks ** 3, device=dev)

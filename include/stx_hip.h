@@ -90,6 +90,21 @@ long long stx_conv3d_c1_wgrad_workspace_floats(int Cin);
 int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, float* workspace, int B, int D, int H, int W,
                         int Cin, void* stream);
 
+/* ---- ACVNet extras (models/ACVNet/acv.py) --------------------------------------------------------------
+ * Depth-wise nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d)) (acv.py:109-112,183-187) on a channels-last
+ * volume; `dil` = int[C/4] dilation per channel quad (device pointer); w = [C][9]; flip=1 mirrors the taps (input gradient). */
+int stx_dwconv_hw_fwd(const float* x, const float* w, const int* dil, float* out, int B, int D, int H, int W, int C,
+                      int flip, void* stream);
+long long stx_dwconv_hw_wgrad_workspace_floats(int C);
+int stx_dwconv_hw_wgrad(const float* x, const float* gy, const int* dil, float* dw, float* workspace, int B, int D,
+                        int H, int W, int C, void* stream);
+/* gradient of `softmax(att, dim=2) * concat_volume` (acv.py:196) w.r.t. the probabilities:
+ * gscale[b][d][h][w] = sum_c gvol[b][d][h][w][c] * concat[b][d][h][w][c]; gvol has 2*Cc channels */
+int stx_cost_volume_scale_bwd(const float* gvol, const float* Lc, const float* Rc, float* gscale, int B, int Cc, int H,
+                              int W, int D, int mask_left, void* stream);
+/* out[v][c] = x[v][c] * s[v] over [nvox][C] */
+int stx_scale_channels(const float* x, const float* s, float* out, long long nvox, int C, void* stream);
+
 /* ---- train-mode BatchNorm3d (+ReLU / residual) around the convolutions ---------------------------------
  * nn.BatchNorm3d of convbn_3d (models/GwcNet/submodule.py:17-20) in train() mode and the adds/ReLUs that follow it
  * (GwcNet/gwcnet.py:96-103,185; PSMNet/stackhourglass.py:31-48). */

@@ -43,6 +43,12 @@ SIGNATURES = {
     "stx_conv3d_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_c1_wgrad_workspace_floats": [_I],
     "stx_conv3d_c1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    # acv.hip
+    "stx_dwconv_hw_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "stx_dwconv_hw_wgrad_workspace_floats": [_I],
+    "stx_dwconv_hw_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "stx_cost_volume_scale_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "stx_scale_channels": [_P, _P, _P, _L, _I, _P],
     # bn.hip
     "stx_bn_reduce_blocks": [],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],

@@ -1,0 +1,219 @@
+// ACVNet-specific pieces of the cost-volume path for gfx950 (reference models/ACVNet/acv.py):
+//
+//  * depth-wise "patch" convolutions  nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d))
+//      acv.py:109-112 (patch: 40 ch, d=1;  patch_l1/l2/l3: 8/16/16 ch, d=1/2/3), used at :183-187.
+//    One kernel with a per-channel-quad dilation serves both stages (stage 2 = the three patch_l*
+//    convs at once over channel slices 0:8 / 8:24 / 24:40, i.e. the torch.cat of :187 is free), its
+//    input gradient (same kernel, taps flipped) and its weight gradient (deterministic partials).
+//  * gradient of  softmax(att, dim=2) * concat_volume  (acv.py:196) with respect to the softmax
+//    probabilities (the forward and the feature gradients live in cost_volume.hip via `scale`).
+// All HBM-bound streaming kernels on channels-last volumes.
+#include "stx_common.h"
+
+namespace {
+
+constexpr int ACV_THREADS = 256;
+
+struct DwArgs {
+    const float* x;      // [B][D][H][W][C]
+    const float* w;      // [C][9]
+    const int* dil;      // [C/4] dilation of each channel quad
+    float* out;          // [B][D][H][W][C]
+    int BD, H, W, C, flip;
+};
+
+// out[v][c] = sum_{i,j} w[c][3i+j] * x[(h + dil*(i-1), w + dil*(j-1))][c]   (zero padded; flip: taps mirrored)
+__global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_kernel(DwArgs a) {
+    const int CQ = a.C >> 2;
+    const size_t nq = (size_t)a.BD * a.H * a.W * CQ;
+    for (size_t idx = (size_t)blockIdx.x * ACV_THREADS + threadIdx.x; idx < nq; idx += (size_t)gridDim.x * ACV_THREADS) {
+        const int cq = (int)(idx % CQ);
+        size_t v = idx / CQ;
+        const int w = (int)(v % a.W); v /= a.W;
+        const int h = (int)(v % a.H);
+        const size_t bd = v / a.H;
+        const int dl = a.dil[cq];
+        const float* wc = a.w + (size_t)cq * 36;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hh = h + dl * (i - 1);
+            if (hh < 0 || hh >= a.H) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ww = w + dl * (j - 1);
+                if (ww < 0 || ww >= a.W) continue;
+                const int k = a.flip ? 8 - (3 * i + j) : 3 * i + j;
+                const float4 xv = stx_ld4(a.x + ((bd * a.H + hh) * a.W + ww) * a.C + 4 * cq);
+                acc.x = fmaf(xv.x, wc[k], acc.x);
+                acc.y = fmaf(xv.y, wc[9 + k], acc.y);
+                acc.z = fmaf(xv.z, wc[18 + k], acc.z);
+                acc.w = fmaf(xv.w, wc[27 + k], acc.w);
+            }
+        }
+        stx_st4(a.out + idx * 4, acc);
+    }
+}
+
+// partial[blk][c][k] = sum over the workgroup's voxels of gy[v][c] * x[v + off_k][c]
+__global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_wgrad_kernel(const float* __restrict__ x,
+                                                                       const float* __restrict__ gy,
+                                                                       const int* __restrict__ dil,
+                                                                       float* __restrict__ partials, int BD, int H,
+                                                                       int W, int C) {
+    __shared__ float red[ACV_THREADS * 36];
+    const int tid = threadIdx.x;
+    const int CQ = C >> 2;
+    const int cq = tid % CQ, vl = tid / CQ, VPB = ACV_THREADS / CQ;   // lanes beyond VPB*CQ idle (C=40: 250 of 256)
+    const int dl = dil[cq];
+    float s[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) s[k] = 0.f;
+    const size_t nvox = (size_t)BD * H * W;
+    for (size_t v = (size_t)blockIdx.x * VPB + vl; vl < VPB && v < nvox; v += (size_t)gridDim.x * VPB) {
+        const int w = (int)(v % W), h = (int)((v / W) % H);
+        const size_t bd = v / ((size_t)W * H);
+        const float4 g = stx_ld4(gy + v * C + 4 * cq);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hh = h + dl * (i - 1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ww = w + dl * (j - 1);
+                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                    const float4 xv = stx_ld4(x + ((bd * H + hh) * W + ww) * C + 4 * cq);
+                    const int k = 3 * i + j;
+                    s[k] = fmaf(g.x, xv.x, s[k]);
+                    s[9 + k] = fmaf(g.y, xv.y, s[9 + k]);
+                    s[18 + k] = fmaf(g.z, xv.z, s[18 + k]);
+                    s[27 + k] = fmaf(g.w, xv.w, s[27 + k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) red[k * ACV_THREADS + tid] = s[k];
+    __syncthreads();
+    for (int idx = tid; idx < 36 * CQ; idx += ACV_THREADS) {
+        const int k = idx / CQ, q = idx % CQ;          // k = comp*9 + tap
+        float t = 0.f;
+        for (int j = q; j < (ACV_THREADS / CQ) * CQ; j += CQ) t += red[k * ACV_THREADS + j];
+        partials[(size_t)blockIdx.x * C * 9 + (size_t)(4 * q + k / 9) * 9 + (k % 9)] = t;
+    }
+}
+
+__global__ __launch_bounds__(ACV_THREADS) void acv_colsum_kernel(const float* __restrict__ partials, int nrows, int M,
+                                                                 float* __restrict__ sums) {
+    __shared__ double red[ACV_THREADS];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int r = tid; r < nrows; r += ACV_THREADS) s += (double)partials[(size_t)r * M + m];
+    red[tid] = s;
+    __syncthreads();
+    for (int k = ACV_THREADS / 2; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) sums[m] = (float)red[0];
+}
+
+// gscale[b][d][h][w] = sum_c gvol[b][d][h][w][c]*Lc[b][c][h][w] + gvol[..][Cc+c]*(w>=d ? Rc[b][c][h][w-d] : 0)
+// (ACV concat semantics: left half unmasked).
+__global__ __launch_bounds__(ACV_THREADS) void cv_scale_bwd_kernel(const float* __restrict__ gvol,
+                                                                    const float* __restrict__ Lc,
+                                                                    const float* __restrict__ Rc,
+                                                                    float* __restrict__ gscale, int D, int H, int W,
+                                                                    int Cc, int mask_left) {
+    const int w = blockIdx.x * ACV_THREADS + threadIdx.x;
+    const int h = blockIdx.y % H, d = blockIdx.y / H, b = blockIdx.z;
+    if (w >= W) return;
+    const int HW = H * W;
+    const float* gv = gvol + ((((size_t)b * D + d) * H + h) * W + w) * (2 * Cc);
+    const float* lp = Lc + ((size_t)b * Cc * H + h) * W + w;
+    const float* rp = Rc + ((size_t)b * Cc * H + h) * W + (w - d);
+    const bool rv = w >= d, lv = rv || !mask_left;
+    float acc = 0.f;
+    for (int c = 0; c < Cc; c += 4) {
+        const float4 gl = stx_ld4(gv + c), gr = stx_ld4(gv + Cc + c);
+        if (lv) {
+            acc = fmaf(gl.x, lp[(size_t)c * HW], acc);
+            acc = fmaf(gl.y, lp[(size_t)(c + 1) * HW], acc);
+            acc = fmaf(gl.z, lp[(size_t)(c + 2) * HW], acc);
+            acc = fmaf(gl.w, lp[(size_t)(c + 3) * HW], acc);
+        }
+        if (rv) {
+            acc = fmaf(gr.x, rp[(size_t)c * HW], acc);
+            acc = fmaf(gr.y, rp[(size_t)(c + 1) * HW], acc);
+            acc = fmaf(gr.z, rp[(size_t)(c + 2) * HW], acc);
+            acc = fmaf(gr.w, rp[(size_t)(c + 3) * HW], acc);
+        }
+    }
+    gscale[(((size_t)b * D + d) * H + h) * W + w] = acc;
+}
+
+// out = a * s (s broadcast over the channel axis): gvol * prob, the feature-gradient input of the ac-volume
+__global__ __launch_bounds__(ACV_THREADS) void scale_channels_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ s,
+                                                                      float* __restrict__ out, size_t nq, int CQ) {
+    for (size_t i = (size_t)blockIdx.x * ACV_THREADS + threadIdx.x; i < nq; i += (size_t)gridDim.x * ACV_THREADS) {
+        const float m = s[i / CQ];
+        float4 v = stx_ld4(x + i * 4);
+        v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+        stx_st4(out + i * 4, v);
+    }
+}
+
+constexpr int ACV_WGRAD_BLOCKS = 1024;
+
+int acv_grid(size_t n) {
+    size_t g = (n + ACV_THREADS - 1) / ACV_THREADS;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int stx_dwconv_hw_fwd(const float* x, const float* w, const int* dil, float* out, int B, int D, int H,
+                                 int W, int C, int flip, void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && w && dil && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "dwconv_hw_fwd: bad args");
+    DwArgs a;
+    a.x = x; a.w = w; a.dil = dil; a.out = out; a.BD = B * D; a.H = H; a.W = W; a.C = C; a.flip = flip;
+    const size_t nq = (size_t)B * D * H * W * (C / 4);
+    hipLaunchKernelGGL(dwconv_hw_kernel, dim3(acv_grid(nq)), dim3(ACV_THREADS), 0, (hipStream_t)stream, a);
+    return stx_check_launch("dwconv_hw_fwd");
+}
+
+extern "C" long long stx_dwconv_hw_wgrad_workspace_floats(int C) { return (long long)ACV_WGRAD_BLOCKS * C * 9; }
+
+extern "C" int stx_dwconv_hw_wgrad(const float* x, const float* gy, const int* dil, float* dw, float* workspace,
+                                   int B, int D, int H, int W, int C, void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && gy && dil && dw && workspace && C % 4 == 0 && C / 4 <= ACV_THREADS,
+                "dwconv_hw_wgrad: bad args (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dwconv_hw_wgrad_kernel, dim3(ACV_WGRAD_BLOCKS), dim3(ACV_THREADS), 0, st, x, gy, dil, workspace,
+                       B * D, H, W, C);
+    int rc = stx_check_launch("dwconv_hw_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(acv_colsum_kernel, dim3(C * 9), dim3(ACV_THREADS), 0, st, workspace, ACV_WGRAD_BLOCKS, C * 9, dw);
+    return stx_check_launch("dwconv_hw_wgrad_colsum");
+}
+
+extern "C" int stx_cost_volume_scale_bwd(const float* gvol, const float* Lc, const float* Rc, float* gscale, int B,
+                                         int Cc, int H, int W, int D, int mask_left, void* stream) {
+    stx_begin();
+    STX_REQUIRE(gvol && Lc && Rc && gscale && Cc % 4 == 0 && B > 0, "cost_volume_scale_bwd: bad args");
+    dim3 grid(stx_cdiv(W, ACV_THREADS), D * H, B);
+    hipLaunchKernelGGL(cv_scale_bwd_kernel, grid, dim3(ACV_THREADS), 0, (hipStream_t)stream, gvol, Lc, Rc, gscale, D, H,
+                       W, Cc, mask_left);
+    return stx_check_launch("cost_volume_scale_bwd");
+}
+
+extern "C" int stx_scale_channels(const float* x, const float* s, float* out, long long nvox, int C, void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && s && out && nvox > 0 && C % 4 == 0, "scale_channels: bad args");
+    const size_t nq = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(scale_channels_kernel, dim3(acv_grid(nq)), dim3(ACV_THREADS), 0, (hipStream_t)stream, x, s, out,
+                       nq, C / 4);
+    return stx_check_launch("scale_channels");
+}

@@ -362,6 +362,77 @@ def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
     return cost_volume_forward(*ts, maxdisp, num_groups, mask_left)
 
 
+class AcVolumeFn(torch.autograd.Function):
+    """ACVNet attention concat volume: softmax(att, dim=2) * concat_volume (acv.py:196), left half
+    unmasked (ACVNet/submodule.py:180-191).  prob: [B, D, H, W] softmax probabilities."""
+
+    @staticmethod
+    def forward(ctx, Lc, Rc, prob, maxdisp):
+        ctx.save_for_backward(Lc, Rc, prob)
+        ctx.maxdisp = maxdisp
+        return cost_volume_forward(None, None, Lc, Rc, maxdisp, 0, mask_left=False, scale=prob)
+
+    @staticmethod
+    def backward(ctx, gvol):
+        Lc, Rc, prob = ctx.saved_tensors
+        gvol = gvol.contiguous()
+        B, D, H, W, CT = gvol.shape
+        Cc = Lc.shape[1]
+        gprob = torch.empty_like(prob)
+        _call("stx_cost_volume_scale_bwd", _p(gvol), _p(Lc), _p(Rc), _p(gprob), B, Cc, H, W, D, 0)
+        scaled = torch.empty_like(gvol)
+        _call("stx_scale_channels", _p(gvol), _p(prob), _p(scaled), B * D * H * W, CT)
+        gL, gR = torch.empty_like(Lc), torch.empty_like(Rc)
+        _call("stx_cost_volume_bwd", _p(scaled), None, None, 0, 0, Cc, None, None, _p(gL), _p(gR), B, H, W, D, 0)
+        return gL, gR, gprob, None
+
+
+def ac_volume(Lc, Rc, prob, maxdisp):
+    Lc, Rc, prob = Lc.contiguous(), Rc.contiguous(), prob.contiguous()
+    if torch.is_grad_enabled() and (Lc.requires_grad or Rc.requires_grad or prob.requires_grad):
+        return AcVolumeFn.apply(Lc, Rc, prob, maxdisp)
+    return cost_volume_forward(None, None, Lc, Rc, maxdisp, 0, mask_left=False, scale=prob)
+
+
+class DwConvHWFn(torch.autograd.Function):
+    """Depth-wise (1,3,3) convolution with per-channel-quad dilation on an NDHWC volume.
+    w: [C, 9]; dil: int32 [C/4] device tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, dil):
+        _chk(x, "x", 5)
+        B, D, H, W, C = x.shape
+        out = torch.empty_like(x)
+        _call("stx_dwconv_hw_fwd", _p(x), _p(w), _p(dil), _p(out), B, D, H, W, C, 0)
+        ctx.save_for_backward(x, w, dil)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, dil = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, D, H, W, C = x.shape
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _call("stx_dwconv_hw_fwd", _p(gy), _p(w), _p(dil), _p(gx), B, D, H, W, C, 1)
+        if ctx.needs_input_grad[1]:
+            ws = _WS.get("dwwgrad", get_lib().raw("stx_dwconv_hw_wgrad_workspace_floats")(C), x.device)
+            gw = torch.empty_like(w)
+            _call("stx_dwconv_hw_wgrad", _p(x), _p(gy), _p(dil), _p(gw), _p(ws), B, D, H, W, C)
+        return gx, gw, None
+
+
+def dwconv_hw(x, w, dil):
+    w = w.contiguous()
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        return DwConvHWFn.apply(x, w, dil)
+    B, D, H, W, C = x.shape
+    out = torch.empty_like(x)
+    _call("stx_dwconv_hw_fwd", _p(x), _p(w), _p(dil), _p(out), B, D, H, W, C, 0)
+    return out
+
+
 # --------------------------------------------------------------------------------------- head
 class HeadFn(torch.autograd.Function):
     """trilinear upsample -> softmax over D -> soft-argmin, fused. cost: [B, D', H', W'] dense."""

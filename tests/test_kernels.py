@@ -288,6 +288,57 @@ def test_conv3d_c1_fwd_wgrad(be, case):
     _close(dw.view_as(w), w.grad)
 
 
+# ------------------------------------------------------------------------------ ACVNet extras
+def test_dwconv_hw_fwd_bwd(be):
+    """Depth-wise (1,3,3) patch convolutions with per-channel dilation (acv.py:109-112,183-187)."""
+    torch.manual_seed(12)
+    B, C, D, H, W = 1, 40, 3, 7, 13
+    x = torch.randn(B, C, D, H, W, requires_grad=True)
+    w1 = torch.randn(8, 1, 1, 3, 3, requires_grad=True)
+    w2 = torch.randn(16, 1, 1, 3, 3, requires_grad=True)
+    w3 = torch.randn(16, 1, 1, 3, 3, requires_grad=True)
+    ref = torch.cat((F.conv3d(x[:, :8], w1, None, 1, (0, 1, 1), 1, 8), F.conv3d(x[:, 8:24], w2, None, 1, (0, 2, 2), 2, 16),
+                     F.conv3d(x[:, 24:40], w3, None, 1, (0, 3, 3), 3, 16)), 1)
+    gy = torch.randn_like(ref)
+    ref.backward(gy)
+    wcat = torch.cat((w1.detach().reshape(8, 9), w2.detach().reshape(16, 9), w3.detach().reshape(16, 9)), 0)
+    dil = torch.tensor([1] * 2 + [2] * 4 + [3] * 4, dtype=torch.int32)
+    xl, gl, dw_, dd = be.dev(ndhwc(x.detach())), be.dev(ndhwc(gy)), be.dev(wcat), be.dev(dil)
+    out = be.empty(B, D, H, W, C)
+    be.call("stx_dwconv_hw_fwd", ptr(xl), ptr(dw_), ptr(dd), ptr(out), B, D, H, W, C, 0)
+    _close(ncdhw(out), ref.detach(), rtol=1e-5)
+    gx = be.empty(B, D, H, W, C)
+    be.call("stx_dwconv_hw_fwd", ptr(gl), ptr(dw_), ptr(dd), ptr(gx), B, D, H, W, C, 1)
+    _close(ncdhw(gx), x.grad, rtol=1e-5)
+    ws = be.empty(be.raw("stx_dwconv_hw_wgrad_workspace_floats")(C))
+    gw = be.empty(C, 9)
+    be.call("stx_dwconv_hw_wgrad", ptr(xl), ptr(gl), ptr(dd), ptr(gw), ptr(ws), B, D, H, W, C)
+    gref = torch.cat((w1.grad.reshape(8, 9), w2.grad.reshape(16, 9), w3.grad.reshape(16, 9)), 0)
+    _close(gw, gref, rtol=1e-4)
+
+
+def test_ac_volume_backward(be):
+    """Gradients of softmax(att)*concat_volume (acv.py:196) w.r.t. probabilities and features."""
+    torch.manual_seed(13)
+    B, Cc, H, W, D = 1, 8, 3, 21, 9
+    Lc = torch.randn(B, Cc, H, W, requires_grad=True)
+    Rc = torch.randn(B, Cc, H, W, requires_grad=True)
+    prob = torch.rand(B, D, H, W, requires_grad=True)
+    ref = prob.unsqueeze(1) * O.build_concat_volume(Lc, Rc, D, mask_left=False)
+    gv = torch.randn(B, D, H, W, 2 * Cc)
+    ref.backward(ncdhw(gv))
+    dL, dR, dp, dgv = be.dev(Lc.detach()), be.dev(Rc.detach()), be.dev(prob.detach()), be.dev(gv)
+    gp = be.empty(B, D, H, W)
+    be.call("stx_cost_volume_scale_bwd", ptr(dgv), ptr(dL), ptr(dR), ptr(gp), B, Cc, H, W, D, 0)
+    _close(gp, prob.grad, rtol=1e-5)
+    scaled = be.empty(B, D, H, W, 2 * Cc)
+    be.call("stx_scale_channels", ptr(dgv), ptr(dp), ptr(scaled), B * D * H * W, 2 * Cc)
+    gL, gR = be.empty(B, Cc, H, W), be.empty(B, Cc, H, W)
+    be.call("stx_cost_volume_bwd", ptr(scaled), None, None, 0, 0, Cc, None, None, ptr(gL), ptr(gR), B, H, W, D, 0)
+    _close(gL, Lc.grad, rtol=1e-5)
+    _close(gR, Rc.grad, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("case", [(1000, 32, False, True, False), (777, 64, True, True, False),
                                   (500, 32, False, False, True), (640, 128, False, True, True)])

@@ -135,6 +135,56 @@ def test_gwcnet_gc_train_parity(env):
     assert int(msd["dres0.0.1.num_batches_tracked"]) == 1
 
 
+def _acv_shape(env):
+    # ACVNet needs maxdisp % 64 == 0 (attention windows of 4 at 1/16 resolution)
+    return (16, 64, 64, 1) if env.name == "emu" else (64, 128, 64, 2)
+
+
+@pytest.mark.parametrize("flags", [{}, {"attn_weights_only": True}])
+def test_acvnet_eval_parity(env, flags):
+    from stereo_toolbox_amd.models import ACVNet
+    H, W, D, B = _acv_shape(env)
+    if env.name == "emu" and flags:
+        pytest.skip("attention-only variant covered on the GPU")
+    m, sd = _filled(ACVNet, D, **flags)
+    m = m.to(env.device).eval()
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    with env.ctx(), torch.no_grad():
+        got = m(left.to(env.device), right.to(env.device)).cpu()
+    with torch.no_grad():
+        ref = O.acvnet_forward(sd, left, right, D, **flags)
+    assert got.shape == ref.shape == (B, H, W)
+    assert ref.std() > 0.5
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_acvnet_train_parity(env):
+    from stereo_toolbox_amd.models import ACVNet
+    H, W, D, B = _acv_shape(env)
+    m, sd = _filled(ACVNet, D)
+    m = m.to(env.device).train()
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    gt = synthetic_tensor((B, H, W), 3, lo=0.0, hi=float(D - 2))
+    with env.ctx():
+        preds = m(left.to(env.device), right.to(env.device))
+        loss = O.smooth_l1_multi(preds, gt.to(env.device), D, LOSS_W)
+        loss.backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    rp = O.acvnet_forward(ref_sd, left, right, D, training=True)
+    O.smooth_l1_multi(rp, gt, D, LOSS_W).backward()
+    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
+            for k, v in sd.items()}
+    rp64 = O.acvnet_forward(sd64, left.double(), right.double(), D, training=True)
+    O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
+    assert len(preds) == 4          # [pred_attention, pred0, pred1, pred2] (acv.py:235)
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
+        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+    n, _ = _check_grads(m, ref_sd, sd64)
+    assert n > 280
+
+
 def test_psmnet_aggregation_parity(env):
     """PSMNet's 3-D path (PSM-style hourglasses with pre/post skips, cumulative heads) from
     synthetic 32-channel features; eval and train."""

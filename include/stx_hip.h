@@ -44,8 +44,10 @@ int stx_cost_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int
  * cost [B][Dc][Hc][Wc] -> disp [B][H][W]; stats [B][H][W][2] (per-pixel max and sum-exp, kept for backward; may be NULL). */
 int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H, int W,
                  void* stream);
-int stx_head_bwd(const float* gdisp, const float* cost, const float* disp, const float* stats, float* gcost, int B,
-                 int Dc, int Hc, int Wc, int D, int H, int W, void* stream);
+/* backward (deterministic, two passes); workspace: stx_head_bwd_workspace_floats(B, Dc, H, W) floats */
+long long stx_head_bwd_workspace_floats(int B, int Dc, int H, int W);
+int stx_head_bwd(const float* gdisp, const float* cost, const float* disp, const float* stats, float* gcost,
+                 float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream);
 /* disparity_regression (GwcNet/submodule.py:23-27), disparityregression (PSMNet/submodule.py:46-54),
  * softargmax_disparity_estimator (disparity_estimators/__init__.py:7-10): out[b][hw] = sum_d d * x[b][d][hw] */
 int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream);

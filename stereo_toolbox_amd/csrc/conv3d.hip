@@ -654,21 +654,40 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
             }
         } else {
-            for (int p = 0; p < NV / 2; ++p) {
+            // address of operand A = (voxel part) + (tap part): tap offsets live in NTAP registers, the
+            // operands of voxel pair p+1 are fetched while pair p is multiplied (pinned by the fences).
+            int toff[NTAP];
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int tap = (t * NW + wave < T) ? t * NW + wave : 0;
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
+                                   : ((kd * EH + kh) * EWS + kw) * 32;
+            }
+            float av[2][NTAP], bv[2];
+            auto load_pair = [&](int p, int buf) {
                 const int v = 2 * p + half;
                 const int lw = v % TW, lh = v / TW;
-                const float bv = ctile[v * 32 + i];
+                const int vb = ((lh * S) * EWS + lw) * 32 + i;
+                bv[buf] = ctile[v * 32 + i];
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) {
-                    const int tap = t * NW + wave;
-                    if (tap < T) {
-                        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                        const int wx = lw * S + kw, hy = lh * S + kh;
-                        const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
-                        const float av = ftile[((kd * EH + hy) * EWS + slot) * 32 + i];
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < NTAP; ++t) av[buf][t] = ftile[vb + toff[t]];
+            };
+            auto mma_pair = [&](int buf) {
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+                    if (t * NW + wave < T) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf], acc[t], 0, 0, 0);
+            };
+            load_pair(0, 0);
+            for (int p = 0; p < NV / 2; p += 2) {
+                load_pair(p + 1, 1);
+                STX_SCHED_BARRIER();
+                mma_pair(0);
+                STX_SCHED_BARRIER();
+                if (p + 2 < NV / 2) load_pair(p + 2, 0);
+                STX_SCHED_BARRIER();
+                mma_pair(1);
+                STX_SCHED_BARRIER();
             }
         }
     }

@@ -26,11 +26,13 @@
 // gwc quad (4 groups x cpg channels) stays in registers across the disparity loop;
 // the D-shifted right operand comes from the LDS tile.
 #include "stx_common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int CV_WT = 16;       // output columns per workgroup
-constexpr int CV_THREADS = 256;
+constexpr int CV_THREADS = 256;    // backward kernel
+constexpr int CVF_THREADS = 1024;  // forward kernel: 16 waves share one feature tile (latency hiding)
 constexpr int CV_MAX_DC = 32;   // disparities per workgroup (runtime DC <= this)
 
 // LDS image of a feature tile: [column][C+4 dwords].  A gwc work item (column, quad q) reads the NJ
@@ -54,42 +56,55 @@ __device__ __forceinline__ int cv_phys_channel(int c) {
 // lane keeps BATCH independent global loads in flight before the first LDS write (the tile is read
 // once per workgroup: latency, not bandwidth, is what this loop has to hide).  Lanes run along the
 // image row, so a wave reads contiguous row segments.
-template <int NJ>
+template <int NJ, int NTHR>
 __device__ __forceinline__ void cv_stage_rows(const float* __restrict__ src,  // &F[b][0][h][0]
-                                              int C, int HW, int W, int x_first, int ncols,
+                                              int C, int HW, int W, int x_first, int ncols, unsigned magic,
                                               float* lds, int tid) {
-    constexpr int BATCH = 16;
+    // The kernel is VALU-bound if this loop does integer divisions per element (rocprofv3:
+    // 5.8k VALU instructions per wave, 3/4 of them index math): e / ncols is one v_mul_hi with a
+    // host-computed reciprocal (exact for e < 2^16), and (channel, column) are computed once per
+    // element and reused for the LDS write.
+    constexpr int BATCH = 8;
     const int RS = C + 4;
     const int total = C * ncols;
-    for (int e0 = tid; e0 < total; e0 += CV_THREADS * BATCH) {
+    for (int e0 = tid; e0 < total; e0 += NTHR * BATCH) {
         float v[BATCH];
+        int dst[BATCH];
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
-            const int e = e0 + k * CV_THREADS;
-            const int c = e / ncols, col = e - c * ncols;
+            const unsigned e = (unsigned)(e0 + k * NTHR);
+            const int c = (int)__umulhi(e, magic);
+            const int col = (int)e - c * ncols;
             const int x = x_first + col;
-            v[k] = (e < total && x >= 0 && x < W) ? src[(size_t)c * HW + x] : 0.f;
+            const bool ok = (int)e < total;
+            v[k] = (ok && x >= 0 && x < W) ? src[(size_t)c * HW + x] : 0.f;
+            dst[k] = ok ? col * RS + cv_phys_channel<NJ>(c) : -1;
         }
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) {
-            const int e = e0 + k * CV_THREADS;
-            const int c = e / ncols, col = e - c * ncols;
-            if (e < total) lds[col * RS + cv_phys_channel<NJ>(c)] = v[k];
-        }
+        for (int k = 0; k < BATCH; ++k)
+            if (dst[k] >= 0) lds[dst[k]] = v[k];
     }
 }
 
 template <int CPG>
-__global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
+__global__ __launch_bounds__(CVF_THREADS) void cost_volume_fwd_kernel(
     const float* __restrict__ Lg, const float* __restrict__ Rg, int Cg, int G,
     const float* __restrict__ Lc, const float* __restrict__ Rc, int Cc,
     const float* __restrict__ scale, float* __restrict__ vol,
-    int H, int W, int D, int DC, int mask_left) {
+    int H, int W, int D, int DC, int mask_left, unsigned magicL, unsigned magicR, int ablate) {
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * CV_WT;
-    const int d0 = blockIdx.y * DC;
-    const int bh = blockIdx.z;
+    // XCD-aware order (workgroup b -> XCD b % 8, private L2s): all column tiles and disparity chunks
+    // of one image row run on the same XCD, so its feature rows are fetched into one L2 only.
+    int bid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
+    const int nwt = (W + CV_WT - 1) / CV_WT, ndc = (D + DC - 1) / DC;
+    const int w0 = (bid % nwt) * CV_WT;
+    const int d0 = ((bid / nwt) % ndc) * DC;
+    const int bh = bid / (nwt * ndc);
     const int b = bh / H, h = bh % H;
     const int HW = H * W;
     const int CT = G + 2 * Cc;
@@ -103,25 +118,39 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
     float* Lc_s = Rg_s + (G ? NR * RSg : 0);
     float* Rc_s = Lc_s + (Cc ? CV_WT * RSc : 0);
 
-    if (G) {
-        cv_stage_rows<CPG>(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, Lg_s, tid);
-        cv_stage_rows<CPG>(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, Rg_s, tid);
+    if (G && ablate != 1) {
+        cv_stage_rows<CPG, CVF_THREADS>(Lg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, w0, CV_WT, magicL, Lg_s, tid);
+        cv_stage_rows<CPG, CVF_THREADS>(Rg + ((size_t)b * Cg * H + h) * W, Cg, HW, W, x_first, NR, magicR, Rg_s, tid);
     }
     if (Cc) {
-        cv_stage_rows<0>(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, Lc_s, tid);
-        cv_stage_rows<0>(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, Rc_s, tid);
+        cv_stage_rows<0, CVF_THREADS>(Lc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, w0, CV_WT, magicL, Lc_s, tid);
+        cv_stage_rows<0, CVF_THREADS>(Rc + ((size_t)b * Cc * H + h) * W, Cc, HW, W, x_first, NR, magicR, Rc_s, tid);
     }
     __syncthreads();
 
-    const int dend = (d0 + DC < D) ? DC : (D - d0);
+    const int dend_blk = (d0 + DC < D) ? DC : (D - d0);
     const float inv = 1.0f / (float)CPG;
-    for (int item = tid; item < CV_WT * Q; item += CV_THREADS) {
+    // The CV_WT*Q (column, quad) items of the tile are replicated over NG = threads/items groups that
+    // split the chunk's disparities: 16 waves keep LDS reads, FMAs and stores of one tile in flight.
+    const int nitems = CV_WT * Q;
+    const int NG = CVF_THREADS / nitems > 0 ? CVF_THREADS / nitems : 1;
+    const int dper = (dend_blk + NG - 1) / NG;
+    for (int t = tid; t < nitems * NG; t += CVF_THREADS) {
+        const int item = t % nitems, grp = t / nitems;
         const int wl = item / Q, q = item - wl * Q;
         const int w = w0 + wl;
-        if (w >= W) continue;
-        float* out = vol + ((((size_t)b * D + d0) * H + h) * W + w) * CT + 4 * q;
+        const int dbeg = grp * dper;                               // first disparity (within the chunk) of this group
+        int dend = dbeg + dper < dend_blk ? dbeg + dper : dend_blk;
+        if (w >= W || dbeg >= dend) continue;
+        dend -= dbeg;                                             // disparities handled here: [0, dend) relative to dbeg
+        float* out = vol + ((((size_t)b * D + d0 + dbeg) * H + h) * W + w) * CT + 4 * q;
         const size_t dstride = (size_t)H * W * CT;
-        const float* sc = scale ? scale + (((size_t)b * D + d0) * H + h) * W + w : nullptr;
+        const float* sc = scale ? scale + (((size_t)b * D + d0 + dbeg) * H + h) * W + w : nullptr;
+        const int dq0 = d0 + dbeg;                                // absolute disparity of relative index 0
+        // disparities dd < nval are valid (w >= dq0+dd); the rest is zero-filled
+        int nval = w - dq0 + 1;
+        nval = nval < 0 ? 0 : (nval > dend ? dend : nval);
+        if (ablate == 2) nval = 0;
         if (q < GQ) {
             // 4 groups x CPG channels of the left feature stay in registers.
             constexpr int P = (CPG >= 16) ? 1 : 16 / CPG;
@@ -129,35 +158,35 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
             float4 l[CPG];
 #pragma unroll
             for (int j = 0; j < CPG; ++j) l[j] = stx_ld4(Lg_s + wl * RSg + q * 4 * CPG + 4 * ((j + rot) % CPG));
-            for (int dd = 0; dd < dend; ++dd) {
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (w >= d0 + dd) {
-                    const float* r = Rg_s + (wl + DC - 1 - dd) * RSg + q * 4 * CPG;
-                    float acc[4];
+            const float* r = Rg_s + (wl + DC - 1 - dbeg) * RSg + q * 4 * CPG;
+            float* o_ = out;
+            int dd = 0;
+            for (; dd < nval; ++dd, r -= RSg, o_ += dstride) {
+                float acc[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float s = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    float s = 0.f;
 #pragma unroll
-                        for (int j = 0; j < CPG / 4; ++j) {
-                            const float4 a = l[g * (CPG / 4) + j];
-                            const float4 v = stx_ld4(r + ((g * (CPG / 4) + j + rot) % CPG) * 4);
-                            s = fmaf(a.x, v.x, s);
-                            s = fmaf(a.y, v.y, s);
-                            s = fmaf(a.z, v.z, s);
-                            s = fmaf(a.w, v.w, s);
-                        }
-                        acc[g] = s * inv;
+                    for (int j = 0; j < CPG / 4; ++j) {
+                        const float4 a = l[g * (CPG / 4) + j];
+                        const float4 v = stx_ld4(r + ((g * (CPG / 4) + j + rot) % CPG) * 4);
+                        s = fmaf(a.x, v.x, s);
+                        s = fmaf(a.y, v.y, s);
+                        s = fmaf(a.z, v.z, s);
+                        s = fmaf(a.w, v.w, s);
                     }
-                    o = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
+                    acc[g] = s * inv;
                 }
-                stx_st4(out + dd * dstride, o);
+                float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
+                stx_st4(o_, o);
             }
+            for (; dd < dend; ++dd, o_ += dstride) stx_st4(o_, make_float4(0.f, 0.f, 0.f, 0.f));
         } else if (q < GQ + CQ) {
             const float4 l = stx_ld4(Lc_s + wl * RSc + 4 * (q - GQ));
             for (int dd = 0; dd < dend; ++dd) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (!mask_left || w >= d0 + dd) {
+                if (!mask_left || w >= dq0 + dd) {
                     o = l;
                     if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
                 }
@@ -166,8 +195,8 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_fwd_kernel(
         } else {
             for (int dd = 0; dd < dend; ++dd) {
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (w >= d0 + dd) {
-                    o = stx_ld4(Rc_s + (wl + DC - 1 - dd) * RSc + 4 * (q - GQ - CQ));
+                if (w >= dq0 + dd) {
+                    o = stx_ld4(Rc_s + (wl + DC - 1 - dbeg - dd) * RSc + 4 * (q - GQ - CQ));
                     if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
                 }
                 stx_st4(out + dd * dstride, o);
@@ -348,15 +377,20 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
         DC = (DC + 1) / 2;
     }
     STX_REQUIRE(lds <= 160 * 1024 && DC <= CV_MAX_DC, "cost_volume_fwd: feature tile (%zu B) exceeds LDS", lds);
-    dim3 grid(stx_cdiv(W, CV_WT), stx_cdiv(D, DC), B * H);
+    dim3 grid(stx_cdiv(W, CV_WT) * stx_cdiv(D, DC) * B * H);
     hipStream_t st = (hipStream_t)stream;
+    // reciprocals for e / ncols by multiply-high (exact while e < 2^16: the largest tile has Cg*NR elements)
+    const int NRh = CV_WT + DC - 1;
+    STX_REQUIRE((long long)(Cg > Cc ? Cg : Cc) * NRh < 65536, "cost_volume_fwd: feature tile too large");
+    const unsigned magicL = (unsigned)(0x100000000ULL / CV_WT + 1), magicR = (unsigned)(0x100000000ULL / NRh + 1);
+    static const int ablate = getenv("STX_CV_ABLATE") ? atoi(getenv("STX_CV_ABLATE")) : 0;   // profiling only
 #define CV_LAUNCH(CPG_)                                                                                       \
     {                                                                                                         \
         if (lds > 64 * 1024)                                                                                  \
             hipFuncSetAttribute((const void*)cost_volume_fwd_kernel<CPG_>,                                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-        hipLaunchKernelGGL(cost_volume_fwd_kernel<CPG_>, grid, dim3(CV_THREADS), lds, st, Lg, Rg, Cg, G, Lc, \
-                           Rc, Cc, scale, vol, H, W, D, DC, mask_left);                                       \
+        hipLaunchKernelGGL(cost_volume_fwd_kernel<CPG_>, grid, dim3(CVF_THREADS), lds, st, Lg, Rg, Cg, G, Lc, \
+                           Rc, Cc, scale, vol, H, W, D, DC, mask_left, magicL, magicR, ablate);               \
     }
     if (cpg == 4) CV_LAUNCH(4) else if (cpg == 8) CV_LAUNCH(8) else CV_LAUNCH(16)
 #undef CV_LAUNCH

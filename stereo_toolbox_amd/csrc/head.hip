@@ -23,7 +23,6 @@
 namespace {
 
 constexpr int HD_THREADS = 256;
-constexpr int HB_TW = 16, HB_TH = 16;   // backward pixel tile
 
 struct Lerp { int i0, i1; float t; };
 
@@ -84,78 +83,84 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     if (stats) { stats[2 * o] = m; stats[2 * o + 1] = s; }
 }
 
-// Backward: dlogit_d = g * p_d * (d - disp); scattered back through the three lerps.  A
-// workgroup owns a 16x16 pixel tile, reduces into an LDS image of the cost cells it touches
-// (ds_add_f32) and flushes that image with one global atomic per cell.
-__global__ __launch_bounds__(HD_THREADS) void head_bwd_kernel(
+// Backward, deterministic and atomic-free, in two streaming passes:
+//  pass 1 (one thread per output pixel): dlogit_d = g * p_d * (d - disp), pushed back through the D
+//          lerp into the pixel's 48 H/W-interpolated cost samples -> gpix[b][dc][h][w];
+//  pass 2 (one thread per cost cell): gathers gpix over the <= 8x8 pixels whose H/W lerp touches the
+//          cell, with the same lerp weights.
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_kernel(
     const float* __restrict__ gout, const float* __restrict__ cost, const float* __restrict__ disp,
-    const float* __restrict__ stats, float* __restrict__ gcost,
-    int Dc, int Hc, int Wc, int D, int H, int W, int FH, int FW) {
-    STX_DYN_SMEM(smem);
-    float* acc = reinterpret_cast<float*>(smem);            // [Dc][FH][FW]
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int hbase = blockIdx.y * HB_TH, wbase = blockIdx.x * HB_TW;
+    const float* __restrict__ stats, float* __restrict__ gpix, int Dc, int Hc, int Wc, int D, int H, int W) {
+    const int w = blockIdx.x * HD_THREADS + threadIdx.x;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (w >= W) return;
     const float rd = (float)Dc / (float)D, rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
-    const int hc_lo = hd_src(hbase, rh, Hc).i0, wc_lo = hd_src(wbase, rw, Wc).i0;
-    for (int i = tid; i < Dc * FH * FW; i += HD_THREADS) acc[i] = 0.f;
-    __syncthreads();
-    const int h = hbase + tid / HB_TW, w = wbase + tid % HB_TW;
-    if (h < H && w < W) {
-        const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
-        const float* cb = cost + (size_t)b * Dc * Hc * Wc;
-        const int plane = Hc * Wc;
-        const size_t o = ((size_t)b * H + h) * W + w;
-        const float g = gout[o], dv = disp[o], m = stats[2 * o], inv_s = 1.f / stats[2 * o + 1];
-        const int r0 = (lh.i0 - hc_lo) * FW, r1 = (lh.i1 - hc_lo) * FW;
-        const int q0 = lw.i0 - wc_lo, q1 = lw.i1 - wc_lo;
-        const float k00 = (1.f - lh.t) * (1.f - lw.t), k01 = (1.f - lh.t) * lw.t;
-        const float k10 = lh.t * (1.f - lw.t), k11 = lh.t * lw.t;
-        int cur = 0;
-        float c0 = hd_sample(cb, Wc, lh, lw);
-        float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
-        float a0 = 0.f, a1 = 0.f;   // gradient wrt c0 / c1
-        for (int d = 0; d < D; ++d) {
-            const Lerp ld = hd_src(d, rd, Dc);
-            while (cur < ld.i0) {
-                float* cell = acc + cur * FH * FW;
-                atomicAdd(cell + r0 + q0, k00 * a0);
-                atomicAdd(cell + r0 + q1, k01 * a0);
-                atomicAdd(cell + r1 + q0, k10 * a0);
-                atomicAdd(cell + r1 + q1, k11 * a0);
-                ++cur;
-                c0 = c1; a0 = a1; a1 = 0.f;
-                const int nx = cur + 1 < Dc ? cur + 1 : Dc - 1;
-                c1 = hd_sample(cb + (size_t)nx * plane, Wc, lh, lw);
-            }
-            const bool same = ld.i1 == ld.i0;
-            const float hi = same ? c0 : c1;
-            const float x = (1.f - ld.t) * c0 + ld.t * hi;
-            const float p = stx_exp(x - m) * inv_s;
-            const float gl = g * p * ((float)d - dv);
-            if (same) a0 += gl; else { a0 = fmaf(1.f - ld.t, gl, a0); a1 = fmaf(ld.t, gl, a1); }
+    const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
+    const float* cb = cost + (size_t)b * Dc * Hc * Wc;
+    const int plane = Hc * Wc;
+    const size_t o = ((size_t)b * H + h) * W + w;
+    const float g = gout[o], dv = disp[o], m = stats[2 * o], inv_s = 1.f / stats[2 * o + 1];
+    float* gp = gpix + ((size_t)b * Dc * H + h) * W + w;      // + dc * H * W
+    const size_t pstride = (size_t)H * W;
+    int cur = 0;
+    float c0 = hd_sample(cb, Wc, lh, lw);
+    float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
+    float a0 = 0.f, a1 = 0.f;   // gradient wrt c0 / c1
+    for (int d = 0; d < D; ++d) {
+        const Lerp ld = hd_src(d, rd, Dc);
+        while (cur < ld.i0) {
+            gp[cur * pstride] = a0;
+            ++cur;
+            c0 = c1; a0 = a1; a1 = 0.f;
+            const int nx = cur + 1 < Dc ? cur + 1 : Dc - 1;
+            c1 = hd_sample(cb + (size_t)nx * plane, Wc, lh, lw);
         }
-        for (int k = 0; k < 2; ++k) {   // flush the last window entries (cur, cur+1)
-            const int dc = cur + k;
-            const float a = k ? a1 : a0;
-            if (dc < Dc && a != 0.f) {
-                float* cell = acc + dc * FH * FW;
-                atomicAdd(cell + r0 + q0, k00 * a);
-                atomicAdd(cell + r0 + q1, k01 * a);
-                atomicAdd(cell + r1 + q0, k10 * a);
-                atomicAdd(cell + r1 + q1, k11 * a);
-            }
-        }
+        const bool same = ld.i1 == ld.i0;
+        const float hi = same ? c0 : c1;
+        const float x = (1.f - ld.t) * c0 + ld.t * hi;
+        const float p = stx_exp(x - m) * inv_s;
+        const float gl = g * p * ((float)d - dv);
+        if (same) a0 += gl; else { a0 = fmaf(1.f - ld.t, gl, a0); a1 = fmaf(ld.t, gl, a1); }
     }
-    __syncthreads();
-    for (int i = tid; i < Dc * FH * FW; i += HD_THREADS) {
-        const float v = acc[i];
-        if (v != 0.f) {
-            const int dc = i / (FH * FW), r = (i / FW) % FH, q = i % FW;
-            const int hc = hc_lo + r, wc = wc_lo + q;
-            if (hc < Hc && wc < Wc) atomicAdd(gcost + (((size_t)b * Dc + dc) * Hc + hc) * Wc + wc, v);
+    gp[cur * pstride] = a0;
+    if (cur + 1 < Dc) gp[(cur + 1) * pstride] = a1;
+    for (int dc = cur + 2; dc < Dc; ++dc) gp[dc * pstride] = 0.f;
+}
+
+// weight with which output index `dst` reads source cell `cell` under the align_corners=False lerp
+__device__ __forceinline__ float hd_weight(int dst, float scale, int n, int cell) {
+    const Lerp l = hd_src(dst, scale, n);
+    return (l.i0 == cell ? 1.f - l.t : 0.f) + (l.i1 == cell ? l.t : 0.f);
+}
+
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_gather_kernel(
+    const float* __restrict__ gpix, float* __restrict__ gcost, int Dc, int Hc, int Wc, int H, int W,
+    int fh, int fw) {
+    const int wc = blockIdx.x * HD_THREADS + threadIdx.x;
+    const int hc = blockIdx.y % Hc, dc = blockIdx.y / Hc, b = blockIdx.z;
+    if (wc >= Wc) return;
+    const float rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
+    // pixels that can touch cell (hc, wc): src in (cell-1, cell+1)  ->  dst in a window of ~2/scale
+    int h_lo = (int)(((float)hc - 1.f + 0.5f) / rh - 0.5f) - 1, w_lo = (int)(((float)wc - 1.f + 0.5f) / rw - 0.5f) - 1;
+    h_lo = h_lo < 0 ? 0 : h_lo;
+    w_lo = w_lo < 0 ? 0 : w_lo;
+    const float* gp = gpix + (((size_t)b * Dc + dc) * H) * W;
+    float acc = 0.f;
+    for (int i = 0; i < fh; ++i) {
+        const int h = h_lo + i;
+        if (h >= H) break;
+        const float kh = hd_weight(h, rh, Hc, hc);
+        if (kh == 0.f) continue;
+        float row = 0.f;
+        for (int j = 0; j < fw; ++j) {
+            const int w = w_lo + j;
+            if (w >= W) break;
+            const float kw = hd_weight(w, rw, Wc, wc);
+            if (kw != 0.f) row = fmaf(kw, gp[(size_t)h * W + w], row);
         }
+        acc = fmaf(kh, row, acc);
     }
+    gcost[(((size_t)b * Dc + dc) * Hc + hc) * Wc + wc] = acc;
 }
 
 // disp[b,h,w] = sum_d d * x[b,d,h,w]
@@ -210,21 +215,23 @@ extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B,
     return stx_check_launch("head_fwd");
 }
 
+extern "C" long long stx_head_bwd_workspace_floats(int B, int Dc, int H, int W) { return (long long)B * Dc * H * W; }
+
 extern "C" int stx_head_bwd(const float* gout, const float* cost, const float* disp, const float* stats,
-                            float* gcost, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
+                            float* gcost, float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                            void* stream) {
     stx_begin();
-    STX_REQUIRE(gout && cost && disp && stats && gcost && B > 0, "head_bwd: null operand");
+    STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(gcost, 0, (size_t)B * Dc * Hc * Wc * sizeof(float), st);
-    const int FH = (int)((double)HB_TH * Hc / H) + 3, FW = (int)((double)HB_TW * Wc / W) + 3;
-    const size_t lds = (size_t)Dc * FH * FW * sizeof(float);
-    STX_REQUIRE(lds <= 160 * 1024, "head_bwd: cost footprint too large for LDS (%zu B)", lds);
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(stx_cdiv(W, HB_TW), stx_cdiv(H, HB_TH), B);
-    hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(HD_THREADS), lds, st, gout, cost, disp, stats, gcost, Dc, Hc, Wc,
-                       D, H, W, FH, FW);
-    return stx_check_launch("head_bwd");
+    hipLaunchKernelGGL(head_bwd_pix_kernel, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
+                       disp, stats, workspace, Dc, Hc, Wc, D, H, W);
+    int rc = stx_check_launch("head_bwd(pixels)");
+    if (rc) return rc;
+    // footprint of a cost cell in output pixels: 2/scale (+ slack for the border clamps)
+    const int fh = 2 * stx_cdiv(H, Hc) + 3, fw = 2 * stx_cdiv(W, Wc) + 3;
+    hipLaunchKernelGGL(head_bwd_gather_kernel, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
+                       workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);
+    return stx_check_launch("head_bwd(gather)");
 }
 
 extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {

@@ -455,7 +455,8 @@ class HeadFn(torch.autograd.Function):
         B, Dc, Hc, Wc = cost.shape
         gc = torch.empty_like(cost)
         g = g.contiguous()      # keep the dense copy alive across the launch
-        _call("stx_head_bwd", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), B, Dc, Hc, Wc, maxdisp, H, W)
+        ws = _WS.get("headbwd", get_lib().raw("stx_head_bwd_workspace_floats")(B, Dc, H, W), cost.device)
+        _call("stx_head_bwd", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), _p(ws), B, Dc, Hc, Wc, maxdisp, H, W)
         return gc, None, None, None
 
 

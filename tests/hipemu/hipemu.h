@@ -199,6 +199,7 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values

@@ -99,7 +99,8 @@ def test_head_fwd_bwd(be, case):
     g = torch.randn(B, H, W)
     ref.backward(g)
     gc = be.empty(B, 1, Dc, Hc, Wc)
-    be.call("stx_head_bwd", ptr(be.dev(g)), ptr(dcost), ptr(disp), ptr(stats), ptr(gc), B, Dc, Hc, Wc, D, H, W)
+    ws = be.empty(be.raw("stx_head_bwd_workspace_floats")(B, Dc, H, W))
+    be.call("stx_head_bwd", ptr(be.dev(g)), ptr(dcost), ptr(disp), ptr(stats), ptr(gc), ptr(ws), B, Dc, Hc, Wc, D, H, W)
     _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
 
 

@@ -173,8 +173,9 @@ def main():
         ms = timeit(lambda: lib.call("stx_head_fwd", P(cost), P(disp), P(stats), B, D4, H4, W4, a.D, a.H, a.W, stream()), it)
         report("head_fwd", ms, nbytes=(cost.numel() + disp.numel()) * 4)
         g, gc = torch.randn_like(disp), torch.empty_like(cost)
-        ms = timeit(lambda: lib.call("stx_head_bwd", P(g), P(cost), P(disp), P(stats), P(gc), B, D4, H4, W4, a.D, a.H,
-                                     a.W, stream()), it)
+        ws = torch.empty(lib.raw("stx_head_bwd_workspace_floats")(B, D4, a.H, a.W), device=dev)
+        ms = timeit(lambda: lib.call("stx_head_bwd", P(g), P(cost), P(disp), P(stats), P(gc), P(ws), B, D4, H4, W4, a.D,
+                                     a.H, a.W, stream()), it)
         report("head_bwd", ms, nbytes=(cost.numel() * 2 + disp.numel() * 4) * 4)
 
 

@@ -31,11 +31,15 @@ LOSS_W = (0.5, 0.5, 0.7, 1.0)      # GwcNet paper weights (the reference ships n
 
 
 def smooth_l1_multi(preds, gt, maxdisp):
+    """sum_i w_i * mean over valid pixels of smooth_l1(pred_i, gt).  Same value as indexing with the
+    boolean mask (`pred[mask]`, reference trainer/trainer_torchrun.py:272-284), but written with a
+    multiply/sum so that no device->host synchronisation (dynamic-shape nonzero) sits in the step."""
     import torch.nn.functional as F
-    mask = (gt > 0) & (gt < maxdisp - 1)       # reference trainer/trainer_torchrun.py:272
+    mask = ((gt > 0) & (gt < maxdisp - 1)).to(gt.dtype)
+    inv = 1.0 / mask.sum().clamp_min(1.0)
     loss = 0.0
     for p, w in zip(preds, LOSS_W):
-        loss = loss + w * F.smooth_l1_loss(p[mask], gt[mask], reduction="mean")
+        loss = loss + w * (F.smooth_l1_loss(p, gt, reduction="none") * mask).sum() * inv
     return loss
 
 
@@ -104,6 +108,8 @@ def main():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--maxdisp", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (fwd+bwd+all-reduce+Adam) in one hipGraph and replay it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,7 +135,7 @@ def main():
     model = model.to(dev).train()
     broadcast_parameters(model)
     sync = FlatGradSync(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
 
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
@@ -150,12 +156,27 @@ def main():
         sync.all_reduce()
         opt.step()
 
+    if args.graph:
+        # hipGraph path: warm up on a side stream (MIOpen search, workspaces), then capture one step.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(2, args.warmup)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        sync.detach_grads()
+        with torch.cuda.graph(graph):
+            step()
+        eager_step = step
+        step = graph.replay            # noqa: F811
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = not args.graph   # per-launch HIP events cannot be recorded inside a replayed graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -195,7 +216,8 @@ def main():
             "config": {"workload": f"GwcNet_GC(maxdisp={args.maxdisp}) train step: fwd+bwd+allreduce+Adam, "
                                    f"{H}x{W} (540x960 padded by pad_to_2x) pairs, batch {B}/GPU, fp32, "
                                    "synthetic randn inputs, deterministic filler weights",
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

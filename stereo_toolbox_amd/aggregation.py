@@ -77,6 +77,11 @@ def _infer_conv(x, conv, scale, bias, residual, relu):
 
 def _bn_state(bn, partials, count):
     training = bn.training
+    if training and isinstance(bn, nn.SyncBatchNorm):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise ops.StxError("SyncBatchNorm statistics exchange is not implemented on the HIP path yet: "
+                               "train with per-replica BatchNorm (the reference default, sync_bn off)")
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = bn.momentum if bn.momentum is not None else 0.1

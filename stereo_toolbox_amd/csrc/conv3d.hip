@@ -255,6 +255,7 @@ constexpr int MARCH_NF4 = (MARCH_EH * MARCH_EW * 8 + MARCH_THREADS - 1) / MARCH_
 struct MarchArgs {
     ConvArgs c;
     int nseg, dseg;      // D segments per column and planes per segment
+    int ablate;          // profiling only (STX_MARCH_ABLATE): 1 = no plane staging, 2 = no epilogue stores
 };
 
 template <int NT>
@@ -318,9 +319,9 @@ __global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs m
     const unsigned wlane = (unsigned)lane * 4u;
 
     for (int d = d_lo; d < d_hi; ++d) {
-        store_plane(d + 1);                 // slot of plane d-2: free since the barrier ending iteration d-1
+        if (ma.ablate != 1) store_plane(d + 1);   // slot of plane d-2: free since the barrier ending iteration d-1
         __syncthreads();
-        if (d + 2 <= d_hi) load_plane(d + 2);
+        if (d + 2 <= d_hi && ma.ablate != 1) load_plane(d + 2);
 
         // Two independent accumulator chains per column block (one per K step of the tap): a single
         // chain of dependent fp32 MFMAs does not keep the matrix pipe full.
@@ -334,9 +335,9 @@ __global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs m
         // 2 ds_read_b128 + 2*NT global_load_dwordx4 + 8*NT MFMAs and almost no address arithmetic
         // (a clump of scalar/vector address code between MFMA groups leaves the matrix pipe idle: an
         // in-order wave can only hide a handful of instructions behind each 64-cycle MFMA).
-        // The fence after each tap keeps the NEXT tap's loads at least one tap ahead of their use while
-        // still letting the scheduler interleave them with this tap's MFMAs.
-        float4 av[2][2], bv[2][2][NT];
+        // Scheduling fences pin "issue loads, then multiply": without them hipcc sinks each weight load
+        // to ~3 MFMAs before its first use (s_waitcnt vmcnt right behind it) and every tap stalls on L2.
+        float4 av[3][2], bv[3][2][NT];
         const float* slotp[3];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) slotp[kd] = ring + ((d - 1 + kd + 3) % 3) * MARCH_SLOT + abase;
@@ -366,12 +367,16 @@ __global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs m
                 acc2[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][1].w, bv[buf][1][nt].w, acc2[1][nt], 0, 0, 0);
             }
         };
+        // prefetch distance = 2 taps (3 rotating register buffers): the loads of tap t+2 are issued,
+        // fenced, before the 8*NT MFMAs of tap t, so they have >= 16*NT MFMAs (1-2k cycles) to land.
         load_tap(0, 0);
+        load_tap(1, 1);
         STX_SCHED_BARRIER();
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) load_tap(tap + 1, (tap + 1) & 1);
-            mma_tap(tap & 1);
+            if (tap + 2 < 27) load_tap(tap + 2, (tap + 2) % 3);
+            STX_SCHED_BARRIER();
+            mma_tap(tap % 3);
             STX_SCHED_BARRIER();
         }
         f32x16 acc[NT];
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs m
             for (int r = 0; r < 8; ++r) {
                 const int rr = kh2 ? 8 + r : r;
                 const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
-                if (row < nrows && n < a.Cout) {
+                if (row < nrows && n < a.Cout && (ma.ablate != 2 || d == d_lo)) {
                     const size_t idx = (vox0 + row) * a.Cout + n;
                     float v = acc[nt][rr] + theirs[(nt * 8 + r) * 64 + lane];
                     s1[nt] += v;
@@ -854,6 +859,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         ma.nseg = march_nseg(B, a.Do, a.Ho, a.Wo);
         ma.dseg = stx_cdiv(a.Do, ma.nseg);
         ma.nseg = stx_cdiv(a.Do, ma.dseg);
+        static const int ablate = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
+        ma.ablate = ablate;
         const int nblk = B * ma.nseg * ma.c.nHt * ma.c.nWt;
         const size_t lds = ((size_t)3 * MARCH_SLOT + (size_t)4 * 2 * NT * 8 * 64) * 4;
         hipStream_t st = (hipStream_t)stream;

@@ -266,3 +266,69 @@ def test_product_path_has_no_cpu_fallback():
     from stereo_toolbox_amd._capi import StxError
     with pytest.raises(StxError):
         ops.cost_volume(torch.zeros(1, 8, 2, 4), torch.zeros(1, 8, 2, 4), None, None, 2, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full-size configurations (GPU only): parity at the headline shapes and
+# size-independent properties of the builders.
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(576, 960), (384, 1248)])    # SceneFlow 540x960 / KITTI 375x1242 after pad_to_2x
+def test_gwcnet_gc_full_size_eval_parity(shape):
+    """configs[2]/[4] shape: GwcNet_GC(192) eval forward at the padded full resolution vs the CPU oracle."""
+    from stereo_toolbox_amd.models import GwcNet_GC
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    H, W = shape
+    m, sd = _filled(GwcNet_GC, 192)
+    m = m.cuda().eval()
+    left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
+    with torch.no_grad():
+        got = m(left.cuda(), right.cuda()).cpu()
+        ref = O.gwcnet_forward(sd, left, right, 192, True)
+    assert got.shape == (1, H, W)
+    assert ref.std() > 1.0
+    err = (got - ref).abs().max().item()
+    if err >= 1e-3:
+        # 553k pixels, disparities up to ~190 (fp32 ulp 1.5e-5), ~30 fp32 conv layers: the worst pixel of
+        # two correct fp32 implementations sits right at the 1e-3 bar.  Arbitrate with an fp64 oracle run:
+        # the product must be no further from fp64 than 2x the fp32 CPU oracle itself is.
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        with torch.no_grad():
+            ref64 = O.gwcnet_forward(sd64, left.double(), right.double(), 192, True)
+        e_prod = (got.double() - ref64).abs().max().item()
+        e_orc = (ref.double() - ref64).abs().max().item()
+        assert e_prod < max(1e-3, 2 * e_orc), (err, e_prod, e_orc)
+    assert (got - ref).abs().mean().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_cost_volume_full_size_properties():
+    """configs[1] shape (PSMNet concat volume, 540x960 D=192 -> features 32x135x240, D'=48) and the
+    GwcNet_GC volume at 144x240: exact-copy / zero-region / linearity properties (no oracle needed)."""
+    from stereo_toolbox_amd import ops
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    dev = torch.device("cuda:0")
+    D = 48
+    L = synthetic_tensor((1, 32, 135, 240), 21).to(dev)
+    R = synthetic_tensor((1, 32, 135, 240), 22).to(dev)
+    vol = ops.cost_volume(None, None, L, R, D, 0, mask_left=True)        # [1,48,135,240,64]
+    w = torch.arange(240, device=dev).view(1, 1, 1, 240, 1)
+    d = torch.arange(D, device=dev).view(1, D, 1, 1, 1)
+    valid = (w >= d)
+    assert torch.equal(vol * (~valid), torch.zeros_like(vol))             # zero where w < d
+    left_ref = L.permute(0, 2, 3, 1).unsqueeze(1).expand(1, D, 135, 240, 32)
+    assert torch.equal(vol[..., :32][valid.expand_as(vol[..., :32])], left_ref[valid.expand_as(left_ref)])
+    for dd in (0, 1, 17, 47):                                             # right half = exact shifted copy
+        assert torch.equal(vol[0, dd, :, dd:, 32:], R[0, :, :, :240 - dd].permute(1, 2, 0))
+    # gwc volume: linear in the right feature, symmetric scaling, group mean
+    Lg = synthetic_tensor((1, 320, 144, 240), 23).to(dev)
+    R1 = synthetic_tensor((1, 320, 144, 240), 24).to(dev)
+    R2 = synthetic_tensor((1, 320, 144, 240), 25).to(dev)
+    v1 = ops.cost_volume(Lg, R1, None, None, D, 40)
+    v2 = ops.cost_volume(Lg, R2, None, None, D, 40)
+    v12 = ops.cost_volume(Lg, R1 + R2, None, None, D, 40)
+    assert (v12 - (v1 + v2)).abs().max().item() < 1e-5
+    # d = 0 slice equals the plain group-wise correlation
+    gc = (Lg * R1).view(1, 40, 8, 144, 240).mean(2).permute(0, 2, 3, 1)
+    assert (v1[:, 0] - gc).abs().max().item() < 1e-5

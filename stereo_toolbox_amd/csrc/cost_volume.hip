@@ -206,6 +206,172 @@ __global__ __launch_bounds__(CVF_THREADS) void cost_volume_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-persistent, software-pipelined builder (used when gwc features are present).
+//
+// The tile kernel above re-stages a (16 + 39)-column x 320-channel feature tile (71 KB) per
+// workgroup and only then computes: rocprofv3 shows it latency-bound at 28 % of the HBM roofline.
+// Here a workgroup (8 waves) owns (b, h, 16 disparities) and walks the image row left to right in
+// 16-column tiles.  LDS holds the current 16 left columns and a 32-column *ring* of right columns
+// (column x lives in slot x & 31): moving one tile to the right needs exactly 16 new left and 16
+// new right columns, so every feature element is staged once per (row, disparity chunk).  Those 32
+// columns for tile t+1 are loaded into registers (about 21 dwords per lane, all in flight) while
+// tile t is being multiplied and stored; they are written into LDS between two barriers.
+constexpr int CVR_THREADS = 512;
+constexpr int CVR_DC = 16;        // disparities per workgroup
+constexpr int CVR_RING = 32;      // right-feature ring (>= CV_WT + CVR_DC - 1 columns)
+constexpr int CVR_MAXK = 10;      // max channel steps of 32 per operand (Cg <= 320)
+
+template <int CPG>
+__global__ __launch_bounds__(CVR_THREADS, 4) void cost_volume_fwd_row_kernel(
+    const float* __restrict__ Lg, const float* __restrict__ Rg, int Cg, int G,
+    const float* __restrict__ Lc, const float* __restrict__ Rc, int Cc,
+    const float* __restrict__ scale, float* __restrict__ vol, int H, int W, int D, int mask_left) {
+    STX_DYN_SMEM(smem);
+    const int tid = threadIdx.x;
+    int bid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
+    const int ndc = (D + CVR_DC - 1) / CVR_DC;
+    const int d0 = (bid % ndc) * CVR_DC;
+    const int bh = bid / ndc;
+    const int b = bh / H, h = bh % H;
+    const int HW = H * W;
+    const int CT = G + 2 * Cc;
+    const int Q = CT >> 2, GQ = G >> 2, CQ = Cc >> 2;
+    const int RSg = Cg + 4, RSc = Cc + 4;
+    float* Lg_s = reinterpret_cast<float*>(smem);          // [16][RSg]
+    float* Rg_s = Lg_s + CV_WT * RSg;                      // [32][RSg] ring
+    float* Lc_s = Rg_s + CVR_RING * RSg;                   // [16][RSc]
+    float* Rc_s = Lc_s + CV_WT * RSc;                      // [32][RSc] ring
+    const float* Lg_row = Lg + ((size_t)b * Cg * H + h) * W;
+    const float* Rg_row = Rg + ((size_t)b * Cg * H + h) * W;
+    const float* Lc_row = Cc ? Lc + ((size_t)b * Cc * H + h) * W : nullptr;
+    const float* Rc_row = Cc ? Rc + ((size_t)b * Cc * H + h) * W : nullptr;
+    const int dend_blk = (d0 + CVR_DC < D) ? CVR_DC : (D - d0);
+    const float inv = 1.0f / (float)CPG;
+    const int ntile = (W + CV_WT - 1) / CV_WT;
+    // Staging map: lane -> column (tid & 15) and channel (tid >> 4) + 32*k: one base pointer per
+    // operand and a constant channel stride, so a tile costs ~2*Cg/32 + 2 independent loads per lane
+    // and almost no index arithmetic or live state (a generic flattened map blew up to 256 VGPRs).
+    constexpr int CPS = CVR_THREADS / CV_WT;                  // channels covered per k step (32)
+    const int scol = tid & (CV_WT - 1), sch = tid >> 4;
+    const int nkg = (Cg + CPS - 1) / CPS;                     // <= CVR_MAXK (checked on the host)
+    float stL[CVR_MAXK], stR[CVR_MAXK], stLc = 0.f, stRc = 0.f;
+    auto prefetch = [&](int t) {                              // loads for tile t -> registers
+        const int xl = t * CV_WT + scol, xr = xl - d0;
+        const bool okl = xl < W, okr = xr >= 0 && xr < W;
+        const float* pl = Lg_row + (size_t)sch * HW + xl;
+        const float* pr = Rg_row + (size_t)sch * HW + xr;
+#pragma unroll
+        for (int k = 0; k < CVR_MAXK; ++k) {
+            const bool ck = k < nkg && sch + CPS * k < Cg;
+            stL[k] = (ck && okl) ? pl[(size_t)k * CPS * HW] : 0.f;
+            stR[k] = (ck && okr) ? pr[(size_t)k * CPS * HW] : 0.f;
+        }
+        if (sch < Cc) {
+            stLc = okl ? Lc_row[(size_t)sch * HW + xl] : 0.f;
+            stRc = okr ? Rc_row[(size_t)sch * HW + xr] : 0.f;
+        }
+    };
+    auto commit = [&](int t) {                                // registers -> LDS (left tile, right ring)
+        const int rslot = (t * CV_WT + scol - d0 + 1024) & (CVR_RING - 1);
+#pragma unroll
+        for (int k = 0; k < CVR_MAXK; ++k) {
+            const int c = sch + CPS * k;
+            if (k < nkg && c < Cg) {
+                const int pc = cv_phys_channel<CPG>(c);
+                Lg_s[scol * RSg + pc] = stL[k];
+                Rg_s[rslot * RSg + pc] = stR[k];
+            }
+        }
+        if (sch < Cc) {
+            Lc_s[scol * RSc + sch] = stLc;
+            Rc_s[rslot * RSc + sch] = stRc;
+        }
+    };
+
+    // work split of a tile: (column, quad) items replicated over NG disparity groups
+    const int nitems = CV_WT * Q;
+    const int NG = CVR_THREADS / nitems > 0 ? CVR_THREADS / nitems : 1;
+    const int dper = (dend_blk + NG - 1) / NG;
+    const size_t dstride = (size_t)H * W * CT;
+
+    prefetch(0);
+    for (int t = 0; t < ntile; ++t) {
+        __syncthreads();                 // everyone is done reading tile t-1 from LDS
+        commit(t);
+        __syncthreads();
+        if (t + 1 < ntile) prefetch(t + 1);
+        const int w0 = t * CV_WT;
+        for (int u = tid; u < nitems * NG; u += CVR_THREADS) {
+            const int item = u % nitems, grp = u / nitems;
+            const int wl = item / Q, q = item - wl * Q;
+            const int w = w0 + wl;
+            const int dbeg = grp * dper;
+            int dend = dbeg + dper < dend_blk ? dbeg + dper : dend_blk;
+            if (w >= W || dbeg >= dend) continue;
+            dend -= dbeg;
+            const int dq0 = d0 + dbeg;
+            float* o_ = vol + ((((size_t)b * D + dq0) * H + h) * W + w) * CT + 4 * q;
+            const float* sc = scale ? scale + (((size_t)b * D + dq0) * H + h) * W + w : nullptr;
+            int nval = w - dq0 + 1;
+            nval = nval < 0 ? 0 : (nval > dend ? dend : nval);
+            if (q < GQ) {
+                constexpr int P = (CPG >= 16) ? 1 : 16 / CPG;
+                const int rot = q / P;
+                float4 l[CPG];
+#pragma unroll
+                for (int j = 0; j < CPG; ++j) l[j] = stx_ld4(Lg_s + wl * RSg + q * 4 * CPG + 4 * ((j + rot) % CPG));
+                int dd = 0;
+                for (; dd < nval; ++dd, o_ += dstride) {
+                    const float* r = Rg_s + ((w - dq0 - dd) & (CVR_RING - 1)) * RSg + q * 4 * CPG;
+                    float acc[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int j = 0; j < CPG / 4; ++j) {
+                            const float4 a = l[g * (CPG / 4) + j];
+                            const float4 v = stx_ld4(r + ((g * (CPG / 4) + j + rot) % CPG) * 4);
+                            s = fmaf(a.x, v.x, s);
+                            s = fmaf(a.y, v.y, s);
+                            s = fmaf(a.z, v.z, s);
+                            s = fmaf(a.w, v.w, s);
+                        }
+                        acc[g] = s * inv;
+                    }
+                    float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
+                    stx_st4(o_, o);
+                }
+                for (; dd < dend; ++dd, o_ += dstride) stx_st4(o_, make_float4(0.f, 0.f, 0.f, 0.f));
+            } else if (q < GQ + CQ) {
+                const float4 l = stx_ld4(Lc_s + wl * RSc + 4 * (q - GQ));
+                for (int dd = 0; dd < dend; ++dd, o_ += dstride) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!mask_left || dd < nval) {
+                        o = l;
+                        if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
+                    }
+                    stx_st4(o_, o);
+                }
+            } else {
+                for (int dd = 0; dd < dend; ++dd, o_ += dstride) {
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (dd < nval) {
+                        o = stx_ld4(Rc_s + ((w - dq0 - dd) & (CVR_RING - 1)) * RSc + 4 * (q - GQ - CQ));
+                        if (sc) { const float m = sc[(size_t)dd * HW]; o.x *= m; o.y *= m; o.z *= m; o.w *= m; }
+                    }
+                    stx_st4(o_, o);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the builders, scatter-free (no atomics).  blockIdx.y selects the side:
 //   LEFT : gLg[c][t] = 1/cpg * sum_d gvol[d][t][g(c)]     * Rg[c][t-d]   (t >= d)
 //          gLc[c][t] =         sum_d gvol[d][t][G+c]                     (t >= d or !mask_left)
@@ -363,6 +529,22 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     if (Cc) STX_REQUIRE(Lc && Rc, "cost_volume_fwd: concat features missing");
     const int cpg = G ? Cg / G : 4;
     STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, "cost_volume_fwd: channels per group %d not in {4,8,16}", cpg);
+    hipStream_t st0 = (hipStream_t)stream;
+    static const int no_row = getenv("STX_CV_NO_ROW") ? 1 : 0;
+    const size_t lds_row = ((size_t)(CV_WT + CVR_RING) * (Cg + 4) + (size_t)(CV_WT + CVR_RING) * (Cc + 4)) * 4;
+    if (G && !no_row && Cg <= CVR_MAXK * (CVR_THREADS / CV_WT) && Cc <= CVR_THREADS / CV_WT && lds_row <= 160 * 1024) {
+        dim3 grid(B * H * stx_cdiv(D, CVR_DC));
+#define CVR_LAUNCH(CPG_)                                                                                          \
+    {                                                                                                             \
+        hipFuncSetAttribute((const void*)cost_volume_fwd_row_kernel<CPG_>,                                        \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_row);                            \
+        hipLaunchKernelGGL(cost_volume_fwd_row_kernel<CPG_>, grid, dim3(CVR_THREADS), lds_row, st0, Lg, Rg, Cg,   \
+                           G, Lc, Rc, Cc, scale, vol, H, W, D, mask_left);                                        \
+    }
+        if (cpg == 4) CVR_LAUNCH(4) else if (cpg == 8) CVR_LAUNCH(8) else CVR_LAUNCH(16)
+#undef CVR_LAUNCH
+        return stx_check_launch("cost_volume_fwd(row)");
+    }
     // disparities per workgroup: split D evenly into chunks of <= 24 (two workgroups per CU for the
     // 320-channel gwc features: (16 + 16+24-1) columns x 1296 B = 71 KB of LDS each)
     const int nchunk = stx_cdiv(D, 24);

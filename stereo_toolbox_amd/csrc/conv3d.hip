@@ -596,9 +596,10 @@ struct WgradArgs {
     int B, Df, Hf, Wf, CF;
     int Dc, Hc, Wc, CC;
     int nHt, nWt, ntiles;
+    int ablate;          // profiling only (STX_WGRAD_ABLATE): 1 = no tile staging, 2 = no MFMA loop
 };
 
-template <int KS, int S, int TH, int TW, int NW>
+template <int KS, int S, int TH, int TW, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int PAD = KS / 2;
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     float* ftile = reinterpret_cast<float*>(smem);          // [ED*EH*EWS][32]
     float* ctile = ftile + ED * EH * EWS * 32;              // [NV][32]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
     const int ncf = a.CF / 32;
     const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;
@@ -621,7 +623,14 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) acc[t] = zero16();
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // Tile staging is split into "global -> registers" and "registers -> LDS".  With PIPE the loads
+    // of the next tile are issued right before the current tile's MFMA loop and only written to LDS
+    // after it (one workgroup per CU, 2 waves per SIMD: measured, more fp32-MFMA waves per SIMD lower
+    // the matrix-pipe throughput); without PIPE both halves run back to back (small 1x1 case).
+    constexpr int NFL = (ED * EH * EW * 8 + NTHR - 1) / NTHR;    // float4 per lane: fine tile
+    constexpr int NCL = (NV * 8 + NTHR - 1) / NTHR;              //                  coarse tile
+    float4 sf[NFL], sc[NCL];
+    auto load_tile = [&](int tile) {
         int r = tile;
         const int wt = r % a.nWt; r /= a.nWt;
         const int ht = r % a.nHt; r /= a.nHt;
@@ -629,26 +638,52 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
         const int b = r / a.Dc;
         const int oh0 = ht * TH, ow0 = wt * TW;
         const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
-        __syncthreads();
-        for (int idx = tid; idx < ED * EH * EW * 8; idx += NTHR) {
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int idx = tid + k * NTHR;
             const int v = idx >> 3, f = idx & 7;
             const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
             const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gd >= 0 && gd < a.Df && gh >= 0 && gh < a.Hf && gw >= 0 && gw < a.Wf)
+            if (idx < ED * EH * EW * 8 && gd >= 0 && gd < a.Df && gh >= 0 && gh < a.Hf && gw >= 0 && gw < a.Wf)
                 val = stx_ld4(a.f + ((((size_t)b * a.Df + gd) * a.Hf + gh) * a.Wf + gw) * a.CF + cfb * 32 + 4 * f);
-            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
-            stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, val);
+            sf[k] = val;
         }
-        for (int idx = tid; idx < NV * 8; idx += NTHR) {
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) {
+            const int idx = tid + k * NTHR;
             const int v = idx >> 3, f = idx & 7;
             const int ow = ow0 + v % TW, oh = oh0 + v / TW;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oh < a.Hc && ow < a.Wc)
+            if (idx < NV * 8 && oh < a.Hc && ow < a.Wc)
                 val = stx_ld4(a.c + ((((size_t)b * a.Dc + od) * a.Hc + oh) * a.Wc + ow) * a.CC + ccb * 32 + 4 * f);
-            stx_st4(ctile + v * 32 + 4 * f, val);
+            sc[k] = val;
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int idx = tid + k * NTHR;
+            const int v = idx >> 3, f = idx & 7;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+            if (idx < ED * EH * EW * 8) stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, sf[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NCL; ++k) {
+            const int idx = tid + k * NTHR;
+            if (idx < NV * 8) stx_st4(ctile + (idx >> 3) * 32 + 4 * (idx & 7), sc[k]);
+        }
+    };
+
+    if (PIPE && (int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        if (!PIPE && a.ablate != 1) load_tile(tile);
+        __syncthreads();                 // every wave is done with the previous tile in LDS
+        if (a.ablate != 1) store_tile();
         __syncthreads();
+        if (PIPE && tile + (int)gridDim.x < a.ntiles && a.ablate != 1) load_tile(tile + gridDim.x);
+        if (a.ablate == 2) continue;
         if (KS == 1) {
             // waves split the voxel pairs
             for (int p = wave; p < NV / 2; p += NW) {
@@ -689,8 +724,8 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 STX_SCHED_BARRIER();
                 mma_pair(0);
                 STX_SCHED_BARRIER();
-                if (p + 2 < NV / 2) load_pair(p + 2, 0);
-                STX_SCHED_BARRIER();
+                load_pair((p + 2 < NV / 2) ? p + 2 : 0, 0);     // unconditional (wraps): keeps the lgkmcnt
+                STX_SCHED_BARRIER();                            // pipeline one stage deep on every trip
                 mma_pair(1);
                 STX_SCHED_BARRIER();
             }
@@ -910,8 +945,23 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
 }
 
 // Workgroups along the split-K axis for the weight gradient.
-static int wgrad_chunks(int ntiles, int npairs) {
-    int c = 512 / npairs;      // ~2 resident workgroups per CU in total
+// Spatial tile of the weight-gradient kernel (coarse voxels) and whether tile staging is software-pipelined.
+// 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 when the narrower tile wastes fewer columns
+// (W' = 240 = 15 x 16 = 7.5 x 32: 6 % fewer MFMAs).  STX_WGRAD_PIPE / STX_WGRAD_TW32 are tuning switches.
+static bool wgrad_pipe(int ks, int stride, int npairs) {
+    static const int force = getenv("STX_WGRAD_PIPE") ? atoi(getenv("STX_WGRAD_PIPE")) : -1;
+    if (ks != 3) return false;
+    if (force >= 0) return force != 0;
+    return stride == 2 || npairs <= 2;    // measured: the L1/L2 stride-1 layers (few tiles per chunk) prefer the plain loop
+}
+static void wgrad_tile(int ks, int stride, int Wc, bool pipe, int* TH, int* TW) {
+    static const int force32 = getenv("STX_WGRAD_TW32") ? 1 : 0;
+    *TH = pipe ? 4 : 2; *TW = (stride == 2) ? 16 : 32;
+    if (ks == 3 && stride == 1 && !force32 && stx_cdiv(Wc, 16) * 16 < stx_cdiv(Wc, 32) * 32) { *TH = 4; *TW = 16; }
+}
+static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
+    static const int budget = getenv("STX_WGRAD_CHUNKS") ? atoi(getenv("STX_WGRAD_CHUNKS")) : 0;
+    int c = (budget > 0 ? (budget > 512 ? 512 : budget) : (pipe ? 256 : 512)) / npairs;   // workgroups in total
     if (c < 1) c = 1;
     if (c > ntiles) c = ntiles;
     return c;
@@ -919,11 +969,17 @@ static int wgrad_chunks(int ntiles, int npairs) {
 
 extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks,
                                                        int stride) {
-    const int TH = 2, TW = (stride == 2) ? 16 : 32;
-    const int ntiles = B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW);
     const int npairs = (CF / 32) * (CC / 32);
     const int rows = (ks == 1) ? 8 : 27;
-    return (long long)npairs * wgrad_chunks(ntiles, npairs) * rows * 1024;
+    // sized for the largest chunk count any tile/pipeline choice can produce (they are tuning switches)
+    int cmax = 1;
+    for (int pipe = 0; pipe < 2; ++pipe)
+        for (int th = 2; th <= 4; th += 2)
+            for (int tw = 16; tw <= 32; tw += 16) {
+                const int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, th) * stx_cdiv(Wc, tw), npairs, pipe);
+                if (c > cmax) cmax = c;
+            }
+    return (long long)npairs * cmax * rows * 1024;
 }
 
 extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float* workspace, int B, int Df, int Hf,
@@ -935,31 +991,39 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     WgradArgs a;
     a.f = f; a.c = c; a.slab = workspace;
     a.B = B; a.Df = Df; a.Hf = Hf; a.Wf = Wf; a.CF = CF; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.CC = CC;
-    const int TH = 2, TW = (stride == 2) ? 16 : 32;
+    const int npairs = (CF / 32) * (CC / 32);
+    const bool pipe = wgrad_pipe(ks, stride, npairs);
+    static const int ablate = getenv("STX_WGRAD_ABLATE") ? atoi(getenv("STX_WGRAD_ABLATE")) : 0;
+    a.ablate = ablate;
+    int TH, TW;
+    wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
     a.nHt = stx_cdiv(Hc, TH); a.nWt = stx_cdiv(Wc, TW);
     a.ntiles = B * Dc * a.nHt * a.nWt;
-    const int npairs = (CF / 32) * (CC / 32);
-    const int nchunks = wgrad_chunks(a.ntiles, npairs);
+    const int nchunks = wgrad_chunks(a.ntiles, npairs, pipe);
     dim3 grid(nchunks, npairs);
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
     static const int nw_env = getenv("STX_WGRAD_WAVES") ? atoi(getenv("STX_WGRAD_WAVES")) : 0;
     const int NW = (nw_env == 4 || nw_env == 8) ? nw_env : 8;   // 8 waves: 4 taps (64 acc regs) per wave, measured +22 % over 4 waves
-#define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, LDS_)                                                                   \
+#define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, PIPE_, LDS_)                                                           \
     {                                                                                                             \
         const size_t lds = (LDS_);                                                                                \
-        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_>,                             \
+        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_>,                      \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_>), grid, dim3(NW_ * 64), lds, st, a);      \
+        hipLaunchKernelGGL((conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_>), grid, dim3(NW_ * 64), lds, st, a); \
     }
     if (ks == 3 && stride == 1) {
-        if (NW == 8) WG_LAUNCH(3, 1, 2, 32, 8, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
-        else WG_LAUNCH(3, 1, 2, 32, 4, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
+        if (TW == 16 && pipe) WG_LAUNCH(3, 1, 4, 16, 8, true, ((size_t)3 * 6 * 18 + 64) * 32 * 4)
+        else if (TW == 16) WG_LAUNCH(3, 1, 4, 16, 8, false, ((size_t)3 * 6 * 18 + 64) * 32 * 4)
+        else if (pipe) WG_LAUNCH(3, 1, 4, 32, 8, true, ((size_t)3 * 6 * 34 + 128) * 32 * 4)
+        else if (NW == 8) WG_LAUNCH(3, 1, 2, 32, 8, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
+        else WG_LAUNCH(3, 1, 2, 32, 4, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
     } else if (ks == 3) {
-        if (NW == 8) WG_LAUNCH(3, 2, 2, 16, 8, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
-        else WG_LAUNCH(3, 2, 2, 16, 4, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+        if (pipe) WG_LAUNCH(3, 2, 4, 16, 8, true, ((size_t)3 * 9 * 34 + 64) * 32 * 4)
+        else if (NW == 8) WG_LAUNCH(3, 2, 2, 16, 8, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+        else WG_LAUNCH(3, 2, 2, 16, 4, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
     } else {
-        WG_LAUNCH(1, 1, 2, 32, 4, ((size_t)2 * 32 + 64) * 32 * 4)
+        WG_LAUNCH(1, 1, 2, 32, 4, false, ((size_t)2 * 32 + 64) * 32 * 4)
     }
 #undef WG_LAUNCH
     int rc = stx_check_launch("conv3d_wgrad");

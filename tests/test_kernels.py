@@ -244,7 +244,7 @@ def run_wgrad(be, fine, coarse, ks, stride):
     return dw.cpu()
 
 
-@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1)])
+@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1)])
 def test_conv3d_wgrad(be, case):
     B, Cin, Cout, D, H, W, ks, s = case
     torch.manual_seed(8)

@@ -12,6 +12,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stereo_toolbox_amd import _capi  # noqa: E402
+if os.environ.get("STX_BENCH_LIB"):          # A/B a variant build of the library (tuning only)
+    _capi.LIB_PATH = os.path.abspath(os.environ["STX_BENCH_LIB"])
 from stereo_toolbox_amd._capi import get_lib  # noqa: E402
 
 lib = get_lib()

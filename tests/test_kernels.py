@@ -159,7 +159,9 @@ CONV_CASES = [
     (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
     (1, 64, 128, 4, 4, 24, 3, 2),
     (2, 32, 64, 7, 6, 40, 3, 1),     # march kernel, 2 column blocks (NT=2), ragged H/W, several D segments
-    (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 3 tiles
+    (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 5 16-wide tiles (8 x 16 columns)
+    (1, 32, 32, 3, 9, 60, 3, 1),     # march kernel, 4 x 32 columns (W = 60 wastes the same either way), ragged H
+    (2, 32, 64, 4, 6, 64, 3, 1),     # march kernel, 4 x 32 columns, NT=2
 ]
 
 

@@ -513,6 +513,194 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward for 8 channels per group (GwcNet / ACVNet: 320 channels in 40 groups), software-pipelined.
+//
+// The generic kernel above alternates "stage a slice" and "multiply it" (measured 1.27 ms at 576x960:
+// 0.5 ms staging + 0.5 ms of 2-LDS-reads-per-FMA compute + 0.2 ms of a serial concat loop, nothing
+// overlapped).  Here a workgroup (320 threads = 40 groups x 8 column pairs) owns (b, h, side, 16 output
+// columns) and ALL channels, and walks the disparities in slices of 8:
+//   * gvol slice: whole 64-channel voxels [8 dd][16 columns] (256-byte coalesced float4 loads; RIGHT side: the
+//     sheared set w = t + d), staged once per slice and shared by the gwc and the concat sums;
+//   * feature window: a 32-slot ring of image columns in LDS ([column][channel], transposed from NCHW on the
+//     way in); moving to the next slice needs only 8 new columns;
+//   * the loads of slice s+1 (8 float4 + 8 dwords per lane) are in flight while slice s is multiplied;
+//   * a thread keeps 8 channels x 2 columns of accumulators: per slice 16 gvol scalars and 9 feature columns
+//     (2 ds_read_b128 each) feed 128 FMAs (0.27 LDS reads per FMA instead of 2).
+// LDS layouts are chosen so that every read is conflict-free: gvol voxel stride 68 dwords (lanes = 8 column
+// pairs x 8 groups -> 64 distinct banks), feature column stride 324 dwords with the two 4-channel halves of
+// all groups stored as two planes ([half][group][4]: a 16-lane ds_read_b128 phase covers 16 distinct 16-byte
+// bank groups).
+constexpr int CVG_THREADS = 320;
+constexpr int CVG_DC = 8;            // disparities per slice
+constexpr int CVG_GS = 68;           // dwords per staged gvol voxel
+constexpr int CVG_RING = 32;         // feature-column ring (23-column window + 8 new columns)
+constexpr int CVG_FS = 324;          // dwords per ring column
+
+__global__ __launch_bounds__(CVG_THREADS, 3) void cost_volume_bwd_g8_kernel(
+    const float* __restrict__ gvol, const float* __restrict__ Lg, const float* __restrict__ Rg, int G, int Cc,
+    float* __restrict__ gLg, float* __restrict__ gRg, float* __restrict__ gLc, float* __restrict__ gRc, int H, int W,
+    int D, int mask_left) {
+    STX_DYN_SMEM(smem);
+    float* gvs = reinterpret_cast<float*>(smem);                 // [8 dd][16 tl][CVG_GS]
+    float* fs = gvs + CVG_DC * CV_WT * CVG_GS;                   // [CVG_RING][CVG_FS]
+    const int tid = threadIdx.x;
+    const int tp = tid & 7, g = tid >> 3;                        // column pair, group
+    int bid;
+    {   // consecutive work items on the same XCD (the 2 x ntile workgroups of a row share its gvol slab in L2)
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
+    const int ntile = (W + CV_WT - 1) / CV_WT;
+    const bool right = bid & 1;
+    const int tile = (bid >> 1) % ntile, bh = (bid >> 1) / ntile;
+    const int b = bh / H, h = bh - b * H;
+    const int t0 = tile * CV_WT;
+    const int HW = H * W, Cg = 8 * G, CT = G + 2 * Cc;
+    const size_t dstride = (size_t)HW * CT;
+    const float* gv_row = gvol + (((size_t)b * D) * H + h) * W * CT;
+    const float* feat = (right ? Lg : Rg) + ((size_t)b * Cg * H + h) * W;
+
+    // ---- staging: global -> registers -> LDS
+    // gvol slice: threads 0..255 = 16 columns x 16 float4 of a voxel; one disparity row per step, so the
+    // 8 loads of a lane differ by a constant stride (one base pointer, no per-load index arithmetic)
+    float4 sg[CVG_DC];
+    float sf[8];
+    const int gtl = (tid >> 4) & 15, gf4 = tid & 15;
+    const bool gthread = tid < 256;
+    const size_t gstep = right ? dstride + CT : dstride;          // RIGHT: w = t + d moves one voxel per disparity
+    auto load_gv = [&](int d0) {
+        const int w0 = right ? t0 + gtl + d0 : t0 + gtl;
+        const float* p = gv_row + (size_t)d0 * dstride + (size_t)w0 * CT + 4 * gf4;
+#pragma unroll
+        for (int k = 0; k < CVG_DC; ++k) {
+            const int w = right ? w0 + k : w0;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gthread && d0 + k < D && w < W && 4 * gf4 < CT) val = stx_ld4(p + (size_t)k * gstep);
+            sg[k] = val;
+        }
+    };
+    auto store_gv = [&]() {
+        if (gthread) {
+#pragma unroll
+            for (int k = 0; k < CVG_DC; ++k) stx_st4(gvs + (k * CV_WT + gtl) * CVG_GS + 4 * gf4, sg[k]);
+        }
+    };
+    // 8 image columns fc0 .. fc0+7 x all channels: lane -> column tid & 7, channel (tid >> 3) + 40 i
+    // (STX_OPAQUE_VGPR: recompute the per-load offsets from the lane id each time instead of keeping ~40
+    //  loop-invariant addresses alive across the disparity loop -- they cost the second resident workgroup)
+    auto load_f = [&](int fc0) {
+        const int fc = fc0 + (tid & 7);
+        const bool ok = fc >= 0 && fc < W;
+        int r = tid >> 3;
+        STX_OPAQUE_VGPR(r);
+        const float* p = feat + (size_t)r * HW + fc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sf[i] = (ok && r + 40 * i < Cg) ? p[(size_t)(40 * i) * HW] : 0.f;
+    };
+    auto store_f = [&](int fc0) {
+        const int slot = (fc0 + (tid & 7) + 4096) & (CVG_RING - 1);
+        int r = tid >> 3;
+        STX_OPAQUE_VGPR(r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = r + 40 * i;
+            fs[slot * CVG_FS + ((c >> 2) & 1) * 160 + (c >> 3) * 4 + (c & 3)] = sf[i];
+        }
+    };
+    // feature window of slice d0: LEFT columns [t0 - d0 - 7, +23), RIGHT [t0 + d0, +23)
+    const int lo0 = right ? t0 : t0 - (CVG_DC - 1);
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+        load_f(lo0 + 8 * k);
+        store_f(lo0 + 8 * k);
+    }
+    load_gv(0);
+    store_gv();
+    __syncthreads();
+
+    float acc[2][8];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
+    float cacc = 0.f;                                             // concat: thread -> (channel tid % Cc, column tid / Cc)
+    const bool cthread = tid < Cc * CV_WT;
+    const int cc = cthread ? tid % Cc : 0, ctl = cthread ? tid / Cc : 0;
+
+    for (int d0 = 0; d0 < D; d0 += CVG_DC) {
+        const bool more = d0 + CVG_DC < D;
+        const int fnew = right ? t0 + d0 + 23 : t0 - d0 - 15;     // the 8 new columns of the next slice
+        if (more) {
+            load_gv(d0 + CVG_DC);
+            load_f(fnew);
+        }
+        if (g < G) {
+            float gvr[2][CVG_DC];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int dd = 0; dd < CVG_DC; ++dd) gvr[e][dd] = gvs[(dd * CV_WT + 2 * tp + e) * CVG_GS + g];
+            const int fc0 = right ? t0 + 2 * tp + d0 : t0 + 2 * tp - d0 - (CVG_DC - 1);
+#pragma unroll
+            for (int k = 0; k <= CVG_DC; ++k) {
+                const float* fp = fs + ((fc0 + k + 4096) & (CVG_RING - 1)) * CVG_FS + g * 4;
+                const float4 f0 = stx_ld4(fp), f1 = stx_ld4(fp + 160);
+                // column k meets (e = 0, dd = 7 - k) and (e = 1, dd = 8 - k) on the LEFT, (0, k) and (1, k - 1) on the RIGHT
+                if (k < CVG_DC) {
+                    const float m = right ? gvr[0][k] : gvr[0][CVG_DC - 1 - k];
+                    acc[0][0] = fmaf(m, f0.x, acc[0][0]); acc[0][1] = fmaf(m, f0.y, acc[0][1]);
+                    acc[0][2] = fmaf(m, f0.z, acc[0][2]); acc[0][3] = fmaf(m, f0.w, acc[0][3]);
+                    acc[0][4] = fmaf(m, f1.x, acc[0][4]); acc[0][5] = fmaf(m, f1.y, acc[0][5]);
+                    acc[0][6] = fmaf(m, f1.z, acc[0][6]); acc[0][7] = fmaf(m, f1.w, acc[0][7]);
+                }
+                if (k % 3 == 2) STX_SCHED_BARRIER();      // keep at most 3 columns (24 VGPRs) of reads in flight
+                if (k >= 1) {
+                    const float m = right ? gvr[1][k - 1] : gvr[1][CVG_DC - k];
+                    acc[1][0] = fmaf(m, f0.x, acc[1][0]); acc[1][1] = fmaf(m, f0.y, acc[1][1]);
+                    acc[1][2] = fmaf(m, f0.z, acc[1][2]); acc[1][3] = fmaf(m, f0.w, acc[1][3]);
+                    acc[1][4] = fmaf(m, f1.x, acc[1][4]); acc[1][5] = fmaf(m, f1.y, acc[1][5]);
+                    acc[1][6] = fmaf(m, f1.z, acc[1][6]); acc[1][7] = fmaf(m, f1.w, acc[1][7]);
+                }
+            }
+        }
+        if (cthread) {
+            const int coff = right ? G + Cc : G;
+#pragma unroll
+            for (int dd = 0; dd < CVG_DC; ++dd) {
+                const float x = gvs[(dd * CV_WT + ctl) * CVG_GS + coff + cc];
+                if (right || !mask_left || t0 + ctl >= d0 + dd) cacc += x;
+            }
+        }
+        __syncthreads();                 // slice d0 has been consumed
+        if (more) {
+            store_gv();
+            store_f(fnew);
+        }
+        __syncthreads();
+    }
+
+    // ---- results: transpose through LDS so that a wave writes 64-byte row segments of the NCHW gradients
+    float* ts = fs;                                               // [Cg][17]
+    if (g < G) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts[(g * 8 + j) * (CV_WT + 1) + 2 * tp + e] = acc[e][j] * 0.125f;
+    }
+    __syncthreads();
+    float* gout = (right ? gRg : gLg) + ((size_t)b * Cg * H + h) * W;
+    for (int idx = tid; idx < Cg * CV_WT; idx += CVG_THREADS) {
+        const int tl = idx & (CV_WT - 1), c = idx >> 4;
+        if (t0 + tl < W) gout[(size_t)c * HW + t0 + tl] = ts[c * (CV_WT + 1) + tl];
+    }
+    if (cthread && t0 + ctl < W) {
+        float* cout = (right ? gRc : gLc) + ((size_t)b * Cc * H + h) * W;
+        cout[(size_t)cc * HW + t0 + ctl] = cacc;
+    }
+}
+
 }  // namespace
 
 extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc,
@@ -592,6 +780,14 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
                     "cost_volume_bwd: channels per group %d unsupported", cpg);
     }
     if (Cc) STX_REQUIRE(gLc && gRc, "cost_volume_bwd: concat outputs missing");
+    static const int no_g8 = getenv("STX_CVB_GENERIC") ? 1 : 0;
+    if (G && Cg == 8 * G && G <= 40 && G + 2 * Cc <= 64 && Cc * CV_WT <= CVG_THREADS && !no_g8) {
+        const size_t lds8 = ((size_t)CVG_DC * CV_WT * CVG_GS + (size_t)CVG_RING * CVG_FS) * 4;
+        hipFuncSetAttribute((const void*)cost_volume_bwd_g8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+        hipLaunchKernelGGL(cost_volume_bwd_g8_kernel, dim3(2 * stx_cdiv(W, CV_WT) * B * H), dim3(CVG_THREADS), lds8,
+                           (hipStream_t)stream, gvol, Lg, Rg, G, Cc, gLg, gRg, gLc, gRc, H, W, D, mask_left);
+        return stx_check_launch("cost_volume_bwd(g8)");
+    }
     const size_t lds = ((size_t)CVB_DC * CV_WT * 40 + (size_t)(CV_WT + CVB_DC - 1) * (CVB_CH + 4) +
                         (size_t)CVB_CH * (CV_WT + 1)) * 4;
     dim3 grid(stx_cdiv(W, CV_WT), 2, B * H);

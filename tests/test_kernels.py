@@ -26,6 +26,8 @@ CV_CASES = [
     (1, 0, 0, 32, 3, 21, 18, 1),      # PSMNet concat
     (1, 0, 0, 32, 3, 21, 18, 0),      # ACVNet concat (left half unmasked)
     (1, 64, 8, 4, 2, 40, 48, 1),      # D' = 48 > W tile
+    (2, 320, 40, 0, 2, 24, 12, 1),    # ACVNet gwc-only volume, batch 2
+    (1, 64, 8, 4, 3, 52, 13, 0),      # 8 channels per group, left half unmasked, D not a multiple of 8
 ]
 
 

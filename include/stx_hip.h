@@ -85,12 +85,14 @@ int stx_conv3d_wgrad(const float* fine, const float* coarse, float* dw, float* w
 
 /* Classifier tail Conv3d(Cin, 1, k=3, p=1, bias=False) (GwcNet/gwcnet.py:139-153, PSMNet/stackhourglass.py:74-84):
  * N = 1 is not GEMM-shaped, so it gets VALU kernels. w: torch layout [1][Cin][27]; out/residual/gy: [B][D][H][W].
- * Cin % 16 == 0 (wgrad: Cin <= 64). dgrad uses stx_conv3d_fwd with the weight zero-padded to 8 output channels. */
+ * Cin % 16 == 0 (wgrad: Cin <= 64). dgrad: gx [B][D][H][W][Cin] = autograd input gradient of the same layer
+ * (Cin % 4 == 0, Cin <= 64); a streaming kernel: reads the 1-channel gy, writes Cin channels. */
 int stx_conv3d_c1_fwd(const float* x, const float* w, const float* residual, float* out, int B, int D, int H, int W,
                       int Cin, void* stream);
 long long stx_conv3d_c1_wgrad_workspace_floats(int Cin);
 int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, float* workspace, int B, int D, int H, int W,
                         int Cin, void* stream);
+int stx_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin, void* stream);
 
 /* ---- ACVNet extras (models/ACVNet/acv.py) --------------------------------------------------------------
  * Depth-wise nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d)) (acv.py:109-112,183-187) on a channels-last

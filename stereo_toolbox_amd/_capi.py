@@ -44,6 +44,7 @@ SIGNATURES = {
     "stx_conv3d_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_c1_wgrad_workspace_floats": [_I],
     "stx_conv3d_c1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "stx_conv3d_c1_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     # acv.hip
     "stx_dwconv_hw_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_dwconv_hw_wgrad_workspace_floats": [_I],

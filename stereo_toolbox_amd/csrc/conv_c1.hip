@@ -2,14 +2,16 @@
 // reference models/GwcNet/gwcnet.py:139-153, PSMNet/stackhourglass.py:74-84, ACVNet/acv.py:122-144)
 // and its weight gradient, for gfx950.
 //
-// With N = 1 the layer is not GEMM-shaped: putting it on the 32-wide MFMA tile wastes 31/32 of the
-// matrix work ("N=1: vector-dot kernel, HBM-bound: reads 212 MB").  These are
-// plain VALU kernels over the same LDS halo tile as the MFMA convolution:
-//   forward : one thread per output voxel, 27 x Cin FMAs against scalar-loaded weights;
-//   wgrad   : one thread per (channel, tap group) reducing over the tile's voxels, per-workgroup
-//             partials -> deterministic column sum.
-// Roofline: HBM (algorithmic bytes = read x once + write 1 channel).
+// With N = 1 the layer is not GEMM-shaped in the usual (voxels x Cout) sense: putting it on the 32-wide MFMA
+// tile wastes 31/32 of the matrix work ("N=1: vector-dot kernel, HBM-bound: reads 212 MB").
+// The 27 taps, however, make a fine N dimension:
+//   forward (Cin = 32)      : P[v][tap] = x[v][:] . w[:][tap] on the matrix cores, then a 27-point gather (march along d);
+//   wgrad   (Cin % 32 == 0) : dW[c][tap] = sum_v x[v][c] * gy[v - tap + 1], M = channels, N = taps, K = voxels;
+//   dgrad                   : streaming VALU kernel (reads 1 channel, writes Cin);
+//   other channel counts    : the first-generation VALU kernels over an LDS halo tile (kept as fallback).
+// Roofline: HBM (algorithmic bytes = read x once + write 1 channel, or the reverse for dgrad).
 #include "stx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -156,6 +158,279 @@ __global__ __launch_bounds__(C1_THREADS) void c1_colsum_kernel(const float* __re
 constexpr size_t C1_TILE_BYTES = (size_t)C1_ED * C1_EH * C1_EW * C1_VS * 4;
 constexpr int C1_WGRAD_BLOCKS = 512;
 
+
+// Data gradient of Conv3d(Cin, 1, 3, padding=1): gx[v][c] = sum_tap gy[v - (tap - 1)] * w[0][c][tap].
+// Pure streaming: reads the 1-channel gy (B*D*H*W*4 B, L2-resident), writes Cin channels.  A workgroup owns
+// 1 x 4 x 32 voxels; the 3 x 6 x 34 halo of gy and the weights ([tap][Cin]) sit in LDS; a work item is
+// (4 consecutive voxels along w, one 4-channel quad): per tap one ds_read_b128 of weights and 4 gy scalars
+// feed 16 FMAs; the Cin/4 quads of a voxel are consecutive lanes, so stores are 16 B x (Cin/4) contiguous.
+constexpr int C1D_TH = 4, C1D_TW = 32;
+constexpr int C1D_EH = C1D_TH + 2, C1D_EW = C1D_TW + 2;
+
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_dgrad_kernel(const float* __restrict__ gy,
+                                                                   const float* __restrict__ w, float* __restrict__ gx,
+                                                                   int B, int D, int H, int W, int Cin, int nHt, int nWt) {
+    __shared__ float gys[3 * C1D_EH * C1D_EW];
+    __shared__ float ws[27 * 64];
+    const int tid = threadIdx.x;
+    int r = blockIdx.x;
+    const int wt = r % nWt; r /= nWt;
+    const int ht = r % nHt; r /= nHt;
+    const int d = r % D;
+    const int b = r / D;
+    const int h0 = ht * C1D_TH, w0 = wt * C1D_TW;
+    for (int idx = tid; idx < 3 * C1D_EH * C1D_EW; idx += C1_THREADS) {
+        const int wx = idx % C1D_EW, hy = (idx / C1D_EW) % C1D_EH, dz = idx / (C1D_EW * C1D_EH);
+        const int gd = d - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+        gys[idx] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                       ? gy[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
+    }
+    for (int idx = tid; idx < 27 * Cin; idx += C1_THREADS) {       // ws[tap][c] = w[c][tap]
+        const int c = idx % Cin, tap = idx / Cin;
+        ws[tap * Cin + c] = w[(size_t)c * 27 + tap];
+    }
+    __syncthreads();
+    const int CQ = Cin >> 2;
+    for (int item = tid; item < CQ * (C1D_TH * C1D_TW / 4); item += C1_THREADS) {
+        const int q = item % CQ, grp = item / CQ;
+        const int lw = (grp % (C1D_TW / 4)) * 4, lh = grp / (C1D_TW / 4);
+        float4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // gy row of the halo for this (kd, kh): output voxel (d, h, w) meets gy(d + 1 - kd, h + 1 - kh, w + 1 - kw)
+                const float* gp = gys + (((2 - kd) * C1D_EH) + (lh + 2 - kh)) * C1D_EW + lw;
+                float g6[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) g6[j] = gp[j];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 wv = stx_ld4(ws + ((kd * 3 + kh) * 3 + kw) * Cin + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g = g6[j + 2 - kw];
+                        acc[j].x = fmaf(g, wv.x, acc[j].x);
+                        acc[j].y = fmaf(g, wv.y, acc[j].y);
+                        acc[j].z = fmaf(g, wv.z, acc[j].z);
+                        acc[j].w = fmaf(g, wv.w, acc[j].w);
+                    }
+                }
+            }
+        const int oh = h0 + lh;
+        if (oh < H) {
+            float* o = gx + ((((size_t)b * D + d) * H + oh) * W + w0 + lw) * Cin + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (w0 + lw + j < W) stx_st4(o + (size_t)j * Cin, acc[j]);
+        }
+    }
+}
+
+
+// Weight gradient on the matrix cores (Cin a multiple of 32).  Re-indexed over INPUT voxels v:
+//   dW[c][tap] = sum_v x[v][c] * gy[v - (tap - 1)]          (gy = 0 outside the volume)
+// is a GEMM with M = 32 channels, N = 27 taps (padded to 32), K = voxels.  v_mfma_f32_32x32x2f32 takes two
+// voxels per instruction: lane (i, half) supplies A = x[v0 + half][i] -- a wave's A loads are 256 contiguous
+// bytes straight from global memory, x is never staged -- and B = gy[v0 + half - off(tap = i)] from a small LDS
+// halo tile of gy (the 27 tap offsets of a lane are fixed; they land in distinct banks).  x is read exactly
+// once (the VALU kernel above re-reads its 3.2x halo through LDS for 27 x Cin FMAs per voxel: 0.39 ms).
+// A workgroup (4 waves) walks 2 x 8 x 32-voxel tiles; a wave owns 4 rows of 32 voxels per tile and keeps one
+// 32 x 32 accumulator; the waves meet in LDS at the end and write one slab row per workgroup.
+constexpr int C1M_TD = 2, C1M_TH = 8, C1M_TW = 32;
+constexpr int C1M_ED = C1M_TD + 2, C1M_EH = C1M_TH + 2, C1M_EW = C1M_TW + 2;
+constexpr int C1M_BLOCKS = 1024;
+
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_wgrad_mfma_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ gy,
+                                                                        float* __restrict__ slab, int B, int D, int H,
+                                                                        int W, int Cin, int nDt, int nHt, int nWt,
+                                                                        int ntiles) {
+    __shared__ float gys[C1M_ED * C1M_EH * C1M_EW];
+    __shared__ float red[4][1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int cb = blockIdx.y;                                   // 32-channel block
+    const int kd = i / 9, kh = (i / 3) % 3, kw = i % 3;          // my tap (i < 27)
+    const int toff = (i < 27) ? ((2 - kd) * C1M_EH + (2 - kh)) * C1M_EW + (2 - kw) + half : half;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int r = t;
+        const int wt = r % nWt; r /= nWt;
+        const int ht = r % nHt; r /= nHt;
+        const int dt = r % nDt;
+        const int b = r / nDt;
+        const int d0 = dt * C1M_TD, h0 = ht * C1M_TH, w0 = wt * C1M_TW;
+        __syncthreads();                                         // previous tile's gy halo is no longer read
+        for (int idx = tid; idx < C1M_ED * C1M_EH * C1M_EW; idx += C1_THREADS) {
+            const int wx = idx % C1M_EW, hy = (idx / C1M_EW) % C1M_EH, dz = idx / (C1M_EW * C1M_EH);
+            const int gd = d0 - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+            gys[idx] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                           ? gy[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
+        }
+        __syncthreads();
+        // my 4 rows of the tile: row = wave * 4 + k -> (ld, lh)
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int row = wave * 4 + k;
+            const int ld = row / C1M_TH, lh = row % C1M_TH;
+            const int gd = d0 + ld, gh = h0 + lh;
+            const bool rowok = gd < D && gh < H;
+            const float* xr = x + ((((size_t)b * D + gd) * H + gh) * W + w0 + half) * Cin + cb * 32 + i;
+            float av[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                av[p] = (rowok && w0 + 2 * p + half < W) ? xr[(size_t)(2 * p) * Cin] : 0.f;
+            const float* gp = gys + (ld * C1M_EH + lh) * C1M_EW + toff;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                float bv = gp[2 * p];
+                bv = (i < 27) ? bv : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv, acc, 0, 0, 0);
+            }
+        }
+    }
+    // D layout: acc[r] = element (row c = (r & 3) + 8 (r >> 2) + 4 half, col tap = i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + i] = acc[r];
+    __syncthreads();
+    float* dst = slab + ((size_t)cb * gridDim.x + blockIdx.x) * 1024;
+    for (int idx = tid; idx < 1024; idx += C1_THREADS)
+        dst[idx] = (red[0][idx] + red[1][idx]) + (red[2][idx] + red[3][idx]);
+}
+
+// dw[(cb*32 + c)*27 + tap] = sum over the workgroup rows of slab[cb][row][c][tap] (fp64, fixed order)
+__global__ __launch_bounds__(C1_THREADS) void c1m_reduce_kernel(const float* __restrict__ slab, int nrows,
+                                                                float* __restrict__ dw) {
+    __shared__ double red[C1_THREADS];
+    const int m = blockIdx.x, tid = threadIdx.x;                 // m = (cb*32 + c) * 27 + tap
+    const int tap = m % 27, cfull = m / 27, cb = cfull >> 5, c = cfull & 31;
+    const float* p = slab + (size_t)cb * nrows * 1024 + c * 32 + tap;
+    double s = 0.0;
+    for (int r = tid; r < nrows; r += C1_THREADS) s += (double)p[(size_t)r * 1024];
+    red[tid] = s;
+    __syncthreads();
+    for (int k = C1_THREADS / 2; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) dw[m] = (float)red[0];
+}
+
+
+// Forward of Conv3d(32, 1, 3, padding=1) on the matrix cores.  Per INPUT voxel v the 27 products
+//   P[v][tap] = sum_c x[v][c] * w[c][tap]
+// are a GEMM (M = voxels, N = 27 taps padded to 32, K = 32 channels = 16 x v_mfma_f32_32x32x2f32 per 32
+// voxels) whose A operand comes straight from global memory (lane (i, half) loads the 64 contiguous bytes
+// x[v_i][16 half .. +16]); the output is the 27-point gather out[o] = sum_tap P[o + tap - 1][tap].
+// A workgroup owns an 8 x 32 column and marches along d: per input plane p it multiplies the 10 x 34 halo plane
+// (11 M-tiles over 4 waves) into an LDS image Ps[voxel][27] (double-buffered: one barrier per plane), then every
+// thread gathers the three 9-tap sums of its column; plane p finishes output p-1, continues p, starts p+1
+// (two rolling registers).  x is read 1.33 x (halo) instead of 3.2 x through LDS with 27 x 32 FMAs per voxel
+// on the VALU kernel above (0.30 ms).  The (column, plane) work list is split evenly over the grid.
+constexpr int C1F_TH = 8, C1F_TW = 32;
+constexpr int C1F_EH = C1F_TH + 2, C1F_EW = C1F_TW + 2, C1F_NV = C1F_EH * C1F_EW;      // 340 halo voxels
+constexpr int C1F_MT = (C1F_NV + 31) / 32;                                             // 11 M-tiles
+constexpr int C1F_WGS = 512;
+
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_mfma_kernel(const float* __restrict__ x,
+                                                                      const float* __restrict__ w,
+                                                                      const float* __restrict__ res,
+                                                                      float* __restrict__ out, int B, int D, int H, int W,
+                                                                      int nHt, int nWt, int ncols) {
+    STX_DYN_SMEM(smem);
+    float* Ps = reinterpret_cast<float*>(smem);                  // [2][C1F_NV][27]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    // B operand: step s multiplies channel 16 half + s; lane column = tap i
+    float wreg[16];
+#pragma unroll
+    for (int s_ = 0; s_ < 16; ++s_) wreg[s_] = (i < 27) ? w[(size_t)(16 * half + s_) * 27 + i] : 0.f;
+    const int lh = tid / C1F_TW, lw = tid % C1F_TW;              // my output column of the tile
+
+    const long long units = (long long)ncols * D;
+    int u = (int)(units * blockIdx.x / gridDim.x);
+    const int u_end = (int)(units * (blockIdx.x + 1) / gridDim.x);
+    while (u < u_end) {
+        const int col = u / D;
+        const int d_lo = u - col * D;
+        const int left = u_end - u;
+        const int d_hi = (D - d_lo < left) ? D : d_lo + left;
+        u += d_hi - d_lo;
+        const int wt = col % nWt, ht = (col / nWt) % nHt, b = col / (nWt * nHt);
+        const int h0 = ht * C1F_TH, w0 = wt * C1F_TW;
+        const int oh = h0 + lh, ow = w0 + lw;
+        const bool ook = oh < H && ow < W;
+        float accA = 0.f, accB = 0.f;
+        __syncthreads();                                          // previous run is done with Ps
+        for (int p = d_lo - 1; p <= d_hi; ++p) {
+            float* Pb = Ps + ((p + 2) & 1) * (C1F_NV * 27);
+            const bool pin = p >= 0 && p < D;
+            if (pin) {
+#pragma unroll 1
+                for (int m = wave; m < C1F_MT; m += 4) {
+                    const int hv = m * 32 + i;
+                    const int hy = hv / C1F_EW, wx = hv - hy * C1F_EW;
+                    const int gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+                    float4 a4[4];
+                    if (hv < C1F_NV && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                        const float* xp = x + ((((size_t)b * D + p) * H + gh) * W + gw) * 32 + 16 * half;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a4[q] = stx_ld4(xp + 4 * q);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) a4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, wreg[4 * q + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, wreg[4 * q + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, wreg[4 * q + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, wreg[4 * q + 3], acc, 0, 0, 0);
+                    }
+                    // D: acc[r] = P[voxel (r & 3) + 8 (r >> 2) + 4 half of the M-tile][tap i]
+                    if (i < 27) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int v = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (v < C1F_NV) Pb[v * 27 + i] = acc[r];
+                        }
+                    }
+                }
+            }
+            __syncthreads();                                      // P[p] complete (and P[p-1] fully gathered)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            if (pin) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const float* pp = Pb + ((lh + kh) * C1F_EW + lw + kw) * 27 + kh * 3 + kw;
+                        s0 += pp[0];
+                        s1 += pp[9];
+                        s2 += pp[18];
+                    }
+            }
+            // input plane p: tap kd = 2 finishes output p-1, kd = 1 continues output p, kd = 0 starts output p+1
+            const float done = accA + s2;
+            const int od = p - 1;
+            if (od >= d_lo && od < d_hi && ook) {
+                const size_t o = (((size_t)b * D + od) * H + oh) * W + ow;
+                out[o] = res ? done + res[o] : done;
+            }
+            accA = accB + s1;
+            accB = s0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int stx_conv3d_c1_fwd(const float* x, const float* w, const float* residual, float* out, int B, int D,
@@ -163,6 +438,19 @@ extern "C" int stx_conv3d_c1_fwd(const float* x, const float* w, const float* re
     stx_begin();
     STX_REQUIRE(x && w && out && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_c1_fwd: bad shape");
     STX_REQUIRE(Cin % C1_CK == 0, "conv3d_c1_fwd: Cin=%d must be a multiple of %d", Cin, C1_CK);
+    static const int no_mfma = getenv("STX_C1_FWD_VALU") ? 1 : 0;
+    if (Cin == 32 && !no_mfma) {
+        const int nHt = stx_cdiv(H, C1F_TH), nWt = stx_cdiv(W, C1F_TW);
+        const long long ncols = (long long)B * nHt * nWt, units = ncols * D;
+        STX_REQUIRE(units < (1ll << 31), "conv3d_c1_fwd: volume too large");
+        long long g = C1F_WGS;
+        if (g > units / 4) g = units / 4 > 0 ? units / 4 : 1;
+        const size_t lds = (size_t)2 * C1F_NV * 27 * 4;
+        hipFuncSetAttribute((const void*)conv_c1_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv_c1_fwd_mfma_kernel, dim3((unsigned)g), dim3(C1_THREADS), lds, (hipStream_t)stream, x, w,
+                           residual, out, B, D, H, W, nHt, nWt, (int)ncols);
+        return stx_check_launch("conv3d_c1_fwd(mfma)");
+    }
     C1Args a;
     a.x = x; a.w = w; a.gy = nullptr; a.res = residual; a.out = out;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin;
@@ -173,7 +461,11 @@ extern "C" int stx_conv3d_c1_fwd(const float* x, const float* w, const float* re
     return stx_check_launch("conv3d_c1_fwd");
 }
 
-extern "C" long long stx_conv3d_c1_wgrad_workspace_floats(int Cin) { return (long long)C1_WGRAD_BLOCKS * Cin * 27; }
+extern "C" long long stx_conv3d_c1_wgrad_workspace_floats(int Cin) {
+    const long long valu = (long long)C1_WGRAD_BLOCKS * Cin * 27;
+    const long long mfma = (long long)C1M_BLOCKS * 1024 * ((Cin + 31) / 32);
+    return valu > mfma ? valu : mfma;
+}
 
 // dw: [1][Cin][27] (torch layout of the Conv3d(Cin, 1, 3) weight gradient)
 extern "C" int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, float* workspace, int B, int D, int H,
@@ -181,6 +473,20 @@ extern "C" int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, f
     stx_begin();
     STX_REQUIRE(x && gy && dw && workspace && B > 0, "conv3d_c1_wgrad: null operand");
     STX_REQUIRE(Cin % C1_CK == 0 && Cin <= 4 * C1_CK, "conv3d_c1_wgrad: Cin=%d must be 16..64 in steps of 16", Cin);
+    static const int no_mfma = getenv("STX_C1_WGRAD_VALU") ? 1 : 0;
+    if (Cin % 32 == 0 && !no_mfma) {
+        const int nDt = stx_cdiv(D, C1M_TD), nHt = stx_cdiv(H, C1M_TH), nWt = stx_cdiv(W, C1M_TW);
+        const long long nt = (long long)B * nDt * nHt * nWt;
+        STX_REQUIRE(nt < (1ll << 31), "conv3d_c1_wgrad: volume too large");
+        const int nblk = nt < C1M_BLOCKS ? (int)nt : C1M_BLOCKS;
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(conv_c1_wgrad_mfma_kernel, dim3(nblk, Cin / 32), dim3(C1_THREADS), 0, st, x, gy, workspace, B,
+                           D, H, W, Cin, nDt, nHt, nWt, (int)nt);
+        int rc = stx_check_launch("conv3d_c1_wgrad(mfma)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(c1m_reduce_kernel, dim3(Cin * 27), dim3(C1_THREADS), 0, st, workspace, nblk, dw);
+        return stx_check_launch("conv3d_c1_wgrad(reduce)");
+    }
     C1Args a;
     a.x = x; a.w = nullptr; a.gy = gy; a.res = nullptr; a.out = workspace;
     a.B = B; a.D = D; a.H = H; a.W = W; a.Cin = Cin;
@@ -195,4 +501,17 @@ extern "C" int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, f
     if (rc) return rc;
     hipLaunchKernelGGL(c1_colsum_kernel, dim3(Cin * 27), dim3(C1_THREADS), 0, st, workspace, nblk, Cin * 27, dw);
     return stx_check_launch("conv3d_c1_colsum");
+}
+
+// gx: [B][D][H][W][Cin] = data gradient of Conv3d(Cin, 1, 3, padding=1) for the output gradient gy [B][D][H][W]
+// (reference autograd of models/GwcNet/gwcnet.py:139-153 `classifN.2`).
+extern "C" int stx_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin,
+                                   void* stream) {
+    stx_begin();
+    STX_REQUIRE(gy && w && gx && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_c1_dgrad: bad shape");
+    STX_REQUIRE(Cin % 4 == 0 && Cin <= 64, "conv3d_c1_dgrad: Cin=%d must be a multiple of 4, <= 64", Cin);
+    const int nHt = stx_cdiv(H, C1D_TH), nWt = stx_cdiv(W, C1D_TW);
+    hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)((size_t)B * D * nHt * nWt)), dim3(C1_THREADS), 0,
+                       (hipStream_t)stream, gy, w, gx, B, D, H, W, Cin, nHt, nWt);
+    return stx_check_launch("conv3d_c1_dgrad");
 }

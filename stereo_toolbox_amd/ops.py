@@ -173,6 +173,14 @@ def conv3d_c1_wgrad(x, gy):
     return dw
 
 
+def conv3d_c1_dgrad(gy, w, Cin):
+    """gy [B,D,H,W,1], w [1,Cin,3,3,3] -> gx [B,D,H,W,Cin]."""
+    B, D, H, W, _ = gy.shape
+    gx = torch.empty(B, D, H, W, Cin, dtype=torch.float32, device=gy.device)
+    _call("stx_conv3d_c1_dgrad", _p(gy), _p(w), _p(gx), B, D, H, W, Cin)
+    return gx
+
+
 class ConvRawFn(torch.autograd.Function):
     """z = conv(x, w) (or transposed conv), raw output + BN partial sums; backward = dgrad + wgrad
     on the same MFMA kernels with re-packed weights."""
@@ -210,19 +218,22 @@ class ConvRawFn(torch.autograd.Function):
                 gw = conv3d_wgrad(gz, x, 3, 2).view_as(w)
         else:
             Co, Ci = w.shape[0], w.shape[1]
+            c1 = _is_c1(w, ks, stride, transposed)
             gz_k, w_k = gz, w
-            if Co % 8 != 0:               # e.g. the classifier tail Conv3d(32 -> 1): pad GEMM-K to 8
+            if Co % 8 != 0 and not c1:    # pad GEMM-K to 8
                 Cp = (Co + 7) // 8 * 8
                 gz_k = _pad_channels(gz, Cp)
                 w_k = w.new_zeros(Cp, *w.shape[1:])
                 w_k[:Co] = w
             if ctx.needs_input_grad[0]:
-                if stride == 1:
+                if c1:                    # classifier tail Conv3d(32 -> 1): streaming VALU kernel
+                    gx = conv3d_c1_dgrad(gz, w.contiguous(), Ci)
+                elif stride == 1:
                     gx, _ = conv3d_forward(gz_k, pack_weight(w_k, 1), Ci, ks, 1)
                 else:                     # stride-2 dgrad = transposed conv of gz
                     gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W))
             if ctx.needs_input_grad[1]:
-                if _is_c1(w, ks, stride, transposed):
+                if c1:
                     gw = conv3d_c1_wgrad(x, gz)
                 else:
                     gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)

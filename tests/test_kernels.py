@@ -270,7 +270,7 @@ def test_deconv3d_wgrad(be):
     _close(run_wgrad(be, gy, x, 3, 2).view_as(w), w.grad)
 
 
-@pytest.mark.parametrize("case", [(1, 32, 3, 5, 37), (2, 16, 2, 4, 32), (1, 64, 2, 9, 40)])
+@pytest.mark.parametrize("case", [(1, 32, 3, 5, 37), (2, 16, 2, 4, 32), (1, 64, 2, 9, 40), (2, 32, 7, 11, 40)])
 def test_conv3d_c1_fwd_wgrad(be, case):
     """Classifier tail Conv3d(Cin, 1, 3, padding=1) on the dedicated VALU kernels."""
     B, Cin, D, H, W = case
@@ -291,6 +291,11 @@ def test_conv3d_c1_fwd_wgrad(be, case):
     dw = be.empty(1, Cin, 27)
     be.call("stx_conv3d_c1_wgrad", ptr(xl), ptr(be.dev(gy)), ptr(dw), ptr(ws), B, D, H, W, Cin)
     _close(dw.view_as(w), w.grad)
+    xg = x.clone().requires_grad_()
+    F.conv3d(xg, w.detach(), None, 1, 1).backward(gy)
+    gx = be.empty(B, D, H, W, Cin)
+    be.call("stx_conv3d_c1_dgrad", ptr(be.dev(gy)), ptr(be.dev(w.detach())), ptr(gx), B, D, H, W, Cin)
+    _close(ncdhw(gx), xg.grad)
 
 
 # ------------------------------------------------------------------------------ ACVNet extras

@@ -137,6 +137,8 @@ def main():
         dw = torch.empty(1, 32, 27, device=dev)
         ms = timeit(lambda: lib.call("stx_conv3d_c1_wgrad", P(x), P(out), P(dw), P(ws), B, D, Hh, Ww, 32, stream()), it)
         report("conv_c1_32_1_L0_wgrad", ms, nbytes=(x.numel() + out.numel()) * 4)
+        ms = timeit(lambda: lib.call("stx_conv3d_c1_dgrad", P(out), P(w), P(x), B, D, Hh, Ww, 32, stream()), it)
+        report("conv_c1_32_1_L0_dgrad", ms, nbytes=(x.numel() + out.numel()) * 4)
         del x, out
 
     for name, lv, Cin, Cout in [("deconv_128_64_L2", 2, 128, 64), ("deconv_64_32_L1", 1, 64, 32)]:

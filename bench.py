@@ -10,7 +10,7 @@ throughput is counted per original pair.  One rank per GPU, per-GPU batch fixed 
 gradients averaged with one RCCL all-reduce over a flat bucket.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3x3 stride-1 32->32 fp32-MFMA
-implicit-GEMM Conv3d `conv3d_march_kernel<1>`; achieved = algorithmic FLOPs of its launches / their HIP-event time inside the
+implicit-GEMM Conv3d `conv3d_march_kernel<1,16,2>`; achieved = algorithmic FLOPs of its launches / their HIP-event time inside the
 timed region) and `cpu_baseline` (the CPU oracle -- a torch-op restatement of the reference -- timed on
 this box's host cores on a bounded sample; baseline only).
 """
@@ -195,7 +195,7 @@ def main():
         roof = None
         if ks:
             ach = ks["flops_total"] / (ks["ms_total"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3d_march_kernel<1> (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA)",
+            roof = {"bound": "mfma", "kernel": "conv3d_march_kernel<1,16,2> (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                     "launches_per_step": ks["launches"] // max(1, args.steps),

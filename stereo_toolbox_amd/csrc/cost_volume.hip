@@ -372,6 +372,146 @@ __global__ __launch_bounds__(CVR_THREADS, 4) void cost_volume_fwd_row_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lean row-persistent builder for 8 channels per group and voxels of <= 64 channels (GwcNet_GC: 40 groups +
+// 2 x 12 concat channels = exactly 64; GwcNet_G / ACVNet gwc volume: 40).
+//
+// cost_volume_fwd_row_kernel above keeps every size a run-time value and maps a thread to (column, 4-channel quad):
+// its compute loop issues ~150 instructions per stored float4 (run-time divisions and multiplies for the item
+// map and the ring addresses, three divergent quad flavours per wave) and is VALU-issue bound at 13 us per
+// 16-column tile.  Here one LANE is one channel of the voxel and a wave walks the disparities of one column:
+//   lanes [0, G)          group g: L[w][8g..8g+8) stays in 8 registers, per disparity 2 ds_read_b128 of the right
+//                         column + 8 FMAs;
+//   lanes [G, G+Cc)       left concat channel (a register, masked);   lanes [G+Cc, G+2Cc): right concat (ds_read_b32);
+// every disparity is one 256-byte dword store per wave and ~25 instructions.  The waves are specialised: waves 0-3
+// stage (the 16 new left and 16 new right columns of tile t+1 go through registers into LDS between the two
+// barriers of a tile), waves 4-15 multiply and store and never wait on a memory counter.
+// Measured at 576x960 (ablations in one session): staging alone 0.045 ms, multiply + store alone 0.099 ms, both
+// 0.172 ms (row kernel above: 0.198 ms); with 4 instead of 12 compute waves 0.21 ms; the stores cost nothing extra
+// (multiply without stores 0.114 ms): the per-voxel chain ds_read -> 8 dependent FMAs is latency-bound.  LDS image of a column:
+// [half][group][4] (+4 pad) so that the 16 lanes of a ds_read_b128 phase hit 16 distinct 16-byte bank groups.
+constexpr int CVL_THREADS = 1024, CVL_LOADERS = 256;      // 4 staging waves + 12 compute waves
+constexpr int CVL_DC = 16, CVL_RING = 32, CVL_FS = 324, CVL_CS = 16;
+constexpr int CVL_MAXK = 20;                                   // channel steps of 16 per operand (Cg <= 320)
+
+__global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
+    const float* __restrict__ Lg, const float* __restrict__ Rg, int G, const float* __restrict__ Lc,
+    const float* __restrict__ Rc, int Cc, float* __restrict__ vol, int H, int W, int D, int mask_left) {
+    STX_DYN_SMEM(smem);
+    float* Lg_s = reinterpret_cast<float*>(smem);             // [16][CVL_FS]
+    float* Rg_s = Lg_s + CV_WT * CVL_FS;                      // [32][CVL_FS] ring
+    float* Lc_s = Rg_s + CVL_RING * CVL_FS;                   // [16][CVL_CS]
+    float* Rc_s = Lc_s + CV_WT * CVL_CS;                      // [32][CVL_CS] ring
+    const int tid = threadIdx.x;
+    int bid;
+    {
+        const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+        bid = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
+    const int ndc = (D + CVL_DC - 1) / CVL_DC;
+    const int d0 = (bid % ndc) * CVL_DC;
+    const int bh = bid / ndc;
+    const int b = bh / H, h = bh - b * H;
+    const int HW = H * W, Cg = 8 * G, CT = G + 2 * Cc;
+    const int dend = (d0 + CVL_DC < D) ? CVL_DC : (D - d0);
+    const int ntile = (W + CV_WT - 1) / CV_WT;
+    const bool loader = __builtin_amdgcn_readfirstlane(tid >> 6) < CVL_LOADERS / 64;     // wave-uniform role
+
+    if (loader) {
+        const float* Lg_row = Lg + ((size_t)b * Cg * H + h) * W;
+        const float* Rg_row = Rg + ((size_t)b * Cg * H + h) * W;
+        const float* Lc_row = Cc ? Lc + ((size_t)b * Cc * H + h) * W : nullptr;
+        const float* Rc_row = Cc ? Rc + ((size_t)b * Cc * H + h) * W : nullptr;
+        // staging map: lane -> column tid & 15, channel (tid >> 4) + 16 k
+        const int scol = tid & (CV_WT - 1), sch = tid >> 4;
+        float stL[CVL_MAXK], stR[CVL_MAXK], stLc = 0.f, stRc = 0.f;
+        auto prefetch = [&](int t) {
+            const int xl = t * CV_WT + scol, xr = xl - d0;
+            const bool okl = xl < W, okr = xr >= 0 && xr < W;
+            unsigned ol = (unsigned)(sch * HW + xl), orr = (unsigned)(sch * HW + xr);
+            STX_OPAQUE_VGPR(ol);         // (otherwise the 40 per-step offsets are hoisted out of the tile loop and spilled)
+            STX_OPAQUE_VGPR(orr);
+            const unsigned step = (unsigned)(16 * HW);
+#pragma unroll
+            for (int k = 0; k < CVL_MAXK; ++k) {
+                const bool ck = sch + 16 * k < Cg;
+                stL[k] = (ck && okl) ? Lg_row[ol] : 0.f;
+                stR[k] = (ck && okr) ? Rg_row[orr] : 0.f;
+                ol += step; orr += step;
+            }
+            if (sch < Cc) {
+                stLc = okl ? Lc_row[(unsigned)(sch * HW + xl)] : 0.f;
+                stRc = okr ? Rc_row[(unsigned)(sch * HW + xr)] : 0.f;
+            }
+        };
+        auto commit = [&](int t) {
+            const int rslot = (t * CV_WT + scol - d0 + 1024) & (CVL_RING - 1);
+            int r = sch;
+            STX_OPAQUE_VGPR(r);
+#pragma unroll
+            for (int k = 0; k < CVL_MAXK; ++k) {
+                const int c = r + 16 * k;
+                if (c < Cg) {
+                    const int pos = ((c >> 2) & 1) * 160 + (c >> 3) * 4 + (c & 3);
+                    Lg_s[scol * CVL_FS + pos] = stL[k];
+                    Rg_s[rslot * CVL_FS + pos] = stR[k];
+                }
+            }
+            if (sch < Cc) {
+                Lc_s[scol * CVL_CS + sch] = stLc;
+                Rc_s[rslot * CVL_CS + sch] = stRc;
+            }
+        };
+        prefetch(0);
+        for (int t = 0; t < ntile; ++t) {
+            __syncthreads();             // the compute waves are done reading tile t-1
+            commit(t);
+            __syncthreads();
+            if (t + 1 < ntile) prefetch(t + 1);
+        }
+        return;
+    }
+
+    // ---- compute waves: lane = channel of the voxel; a work item is (column, group of 4 disparities), the 64 items of
+    // a tile are dealt round-robin to the 12 compute waves (2 workgroups per CU = 24 compute waves: the per-voxel chain
+    // ds_read -> 8 dependent FMAs -> store is latency-bound, measured 0.15 ms with 8 compute waves per CU)
+    constexpr int NCW = (CVL_THREADS - CVL_LOADERS) / 64;
+    const int lane = tid & 63, cw = (tid >> 6) - CVL_LOADERS / 64;
+    const bool is_g = lane < G, is_l = !is_g && lane < G + Cc, is_r = lane >= G + Cc && lane < CT;
+    const int gq = is_g ? lane * 4 : 0;
+    const int cl = is_l ? lane - G : 0, cr = is_r ? lane - G - Cc : 0;
+    const size_t dstride = (size_t)HW * CT;
+    for (int t = 0; t < ntile; ++t) {
+        __syncthreads();
+        __syncthreads();                 // tile t is in LDS
+#pragma unroll 1
+        for (int item = cw; item < CV_WT * (CVL_DC / 4); item += NCW) {
+            const int wl = item & (CV_WT - 1), dg = item >> 4;
+            const int w = t * CV_WT + wl;
+            if (w >= W || 4 * dg >= dend) continue;
+            const float4 l0 = stx_ld4(Lg_s + wl * CVL_FS + gq), l1 = stx_ld4(Lg_s + wl * CVL_FS + 160 + gq);
+            const float lcv = Lc_s[wl * CVL_CS + cl];
+            float* o = vol + ((((size_t)b * D + d0 + 4 * dg) * H + h) * W + w) * CT + lane;
+            const int x0 = w - d0 - 4 * dg;                      // right column of the item's first disparity
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const int slot = (x0 - dd + 1024) & (CVL_RING - 1);
+                const float* rp = Rg_s + slot * CVL_FS + gq;
+                const float4 r0 = stx_ld4(rp), r1 = stx_ld4(rp + 160);
+                const float rc = Rc_s[slot * CVL_CS + cr];
+                float s = l0.x * r0.x;
+                s = fmaf(l0.y, r0.y, s); s = fmaf(l0.z, r0.z, s); s = fmaf(l0.w, r0.w, s);
+                s = fmaf(l1.x, r1.x, s); s = fmaf(l1.y, r1.y, s); s = fmaf(l1.z, r1.z, s); s = fmaf(l1.w, r1.w, s);
+                const bool valid = x0 - dd >= 0;
+                float v = valid ? s * 0.125f : 0.f;              // (ring slots left of the image hold stale data)
+                v = is_l ? ((valid || !mask_left) ? lcv : 0.f) : v;
+                v = is_r ? (valid ? rc : 0.f) : v;
+                if (lane < CT && 4 * dg + dd < dend) o[(size_t)dd * dstride] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of the builders, scatter-free (no atomics).  blockIdx.y selects the side:
 //   LEFT : gLg[c][t] = 1/cpg * sum_d gvol[d][t][g(c)]     * Rg[c][t-d]   (t >= d)
 //          gLc[c][t] =         sum_d gvol[d][t][G+c]                     (t >= d or !mask_left)
@@ -720,6 +860,14 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     hipStream_t st0 = (hipStream_t)stream;
     static const int no_row = getenv("STX_CV_NO_ROW") ? 1 : 0;
     const size_t lds_row = ((size_t)(CV_WT + CVR_RING) * (Cg + 4) + (size_t)(CV_WT + CVR_RING) * (Cc + 4)) * 4;
+    static const int no_g8 = getenv("STX_CV_NO_G8") ? 1 : 0;
+    if (G && !no_g8 && !scale && cpg == 8 && G <= 40 && Cc <= CVL_CS && G + 2 * Cc <= 64) {
+        const size_t lds8 = ((size_t)(CV_WT + CVL_RING) * CVL_FS + (size_t)(CV_WT + CVL_RING) * CVL_CS) * 4;
+        hipFuncSetAttribute((const void*)cost_volume_fwd_g8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+        hipLaunchKernelGGL(cost_volume_fwd_g8_kernel, dim3(B * H * stx_cdiv(D, CVL_DC)), dim3(CVL_THREADS), lds8, st0, Lg,
+                           Rg, G, Lc, Rc, Cc, vol, H, W, D, mask_left);
+        return stx_check_launch("cost_volume_fwd(g8)");
+    }
     if (G && !no_row && Cg <= CVR_MAXK * (CVR_THREADS / CV_WT) && Cc <= CVR_THREADS / CV_WT && lds_row <= 160 * 1024) {
         dim3 grid(B * H * stx_cdiv(D, CVR_DC));
 #define CVR_LAUNCH(CPG_)                                                                                          \

@@ -1,0 +1,8 @@
+#!/bin/bash
+export TMPDIR=/tmp
+run() { timeout 120 python tools/kernel_bench.py --iters 10 --only "$1" 2>&1 | grep '"kernel"' | cut -c1-100; }
+for i in 1 2; do
+echo "=== new"; run cost_volume | grep fwd_gwc; echo "=== rowkernel"; STX_CV_NO_G8=1 run cost_volume | grep fwd_gwc
+echo "=== old"; STX_BENCH_LIB=variants/libstx_old.so run cost_volume | grep fwd_gwc
+done
+timeout 300 python -m pytest tests/test_kernels.py -m gpu -k cost_volume -q 2>&1 | tail -2

@@ -53,6 +53,13 @@ int stx_head_bwd(const float* gdisp, const float* cost, const float* disp, const
 int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
 /* argmax_disparity_estimator (disparity_estimators/__init__.py:13-15): out int64 [B][HW], first maximum */
 int stx_argmax_fwd(const float* x, long long* out, int B, int D, int HW, void* stream);
+/* unimodal_disparity_estimator (disparity_estimators/unimodal_disparity_estimator.py:4-25) and
+ * dominant_modal_disparity_estimator (disparity_estimators/dominant_modal_disparity_estimator.py:35-54):
+ * x [B][D][HW] probability volume (D = maxdisp) -> out [B][HW], the re-normalised expectation of d over the mode that
+ * contains the arg-max / over the heavier of the two main modes of the 5-tap-blurred volume. 0/0 -> NaN as in the
+ * reference. */
+int stx_unimodal_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
+int stx_dominant_modal_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
 /* F.softmax over the disparity axis of [B][D][HW] (ACVNet attention weights, acv.py:196) */
 int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream);
 

@@ -79,6 +79,69 @@ def argmax_disparity_estimator(x, maxdisp=192):
     return torch.argmax(x, 1, keepdim=True)
 
 
+def _mode_bounds(x):
+    """Support of the mode around the arg-max of x [N,D,H,W] along D: (index, index_l, index_r), int64 [N,1,H,W].
+    index_r = (first j > index with x[j] > x[j-1], the volume being extended by 1.0 at j = D) - 1;
+    index_l = last j <= index with x[j] < x[j-1] (x[-1] = 1.0); D-1 / -1 when no such j exists
+    (disparity_estimators/unimodal_disparity_estimator.py:6-19, dominant_modal_disparity_estimator.py:8-19)."""
+    N, D, H, W = x.shape
+    index = torch.argmax(x, 1, keepdim=True)
+    one = x.new_ones(N, 1, H, W)
+    ext = torch.cat((one, x, one), 1)
+    diff = ext[:, 1:] - ext[:, :-1]                               # diff[j] = x[j] - x[j-1], j = 0..D
+    j = torch.arange(D + 1, device=x.device).view(1, D + 1, 1, 1)
+    rising = ((diff > 0) & (j > index)).int()
+    index_r = torch.argmax(rising, 1, keepdim=True) - 1
+    falling = ((diff[:, :D] < 0) & (j[:, :D] <= index)).int()
+    index_l = (D - 1) - torch.argmax(torch.flip(falling, [1]), 1, keepdim=True)
+    return index, index_l, index_r
+
+
+def _range_mask(D, lo, hi, device):
+    d = torch.arange(D, device=device).view(1, D, 1, 1)
+    return (d >= lo) & (d <= hi)
+
+
+def unimodal_disparity_estimator(x, maxdisp=192):
+    """disparity_estimators/unimodal_disparity_estimator.py:4-25: expectation over the mode that contains the
+    arg-max, re-normalised.  -> [B,1,H,W]."""
+    _, lo, hi = _mode_bounds(x)
+    xs = x * _range_mask(maxdisp, lo, hi, x.device)
+    xs = xs / torch.sum(xs, 1, keepdim=True)
+    disp = torch.arange(maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+    return torch.sum(xs * disp, 1, keepdim=True)
+
+
+def _modal_mask(x):
+    """dominant_modal_disparity_estimator.py:5-32: the mode's support, symmetrised around the arg-max when the
+    arg-max is off-centre by 3 or more bins."""
+    D = x.shape[1]
+    index, lo, hi = _mode_bounds(x)
+    r = torch.min(hi - index, index - lo)
+    centred = torch.abs(2 * index - hi - lo) < 3
+    m1 = _range_mask(D, lo, hi, x.device)
+    m2 = _range_mask(D, index - r, index + r, x.device)
+    return torch.where(centred, m1, m2)
+
+
+def dominant_modal_disparity_estimator(x, maxdisp=192):
+    """disparity_estimators/dominant_modal_disparity_estimator.py:35-54: 5-tap box blur along D, the blurred
+    volume's main mode and its second mode (main mode removed); keep whichever holds more probability mass."""
+    N, D, H, W = x.shape
+    xb = x.permute(0, 2, 3, 1).reshape(N, H * W, D)
+    kernel = torch.ones(H * W, 1, 5, dtype=x.dtype, device=x.device) / 5
+    xb = F.conv1d(xb, kernel, padding="same", groups=H * W)
+    xb = xb.permute(0, 2, 1).reshape(x.shape)
+    m = _modal_mask(xb)
+    y = x * m
+    z = (x - y) * _modal_mask(xb * (~m))
+    first = (torch.sum(y, 1) >= torch.sum(z, 1)).to(torch.float32).unsqueeze(1)
+    xs = first * y + (1 - first) * z
+    xs = xs / torch.sum(xs, 1, keepdim=True)
+    disp = torch.arange(maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+    return torch.sum(xs * disp, 1, keepdim=True)
+
+
 def regression_head(cost, maxdisp, H, W, keepdim=False):
     """upsample(trilinear) -> squeeze -> softmax(dim=1) -> disparity_regression
     (GwcNet/gwcnet.py:219-224, PSMNet/stackhourglass.py:147-153, ACVNet/acv.py:247-251)."""

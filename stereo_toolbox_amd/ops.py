@@ -528,6 +528,29 @@ def argmax_disparity(x):
     return out
 
 
+def _modal_estimator(entry, x, maxdisp):
+    assert len(x.shape) == 4
+    x = x.detach().contiguous()            # the reference masks with `.data`: no gradient is defined through the mode choice
+    _chk(x, "x", 4)
+    B, D, H, W = x.shape
+    if D != maxdisp:
+        raise StxError(f"{entry}: volume has {D} disparities, maxdisp={maxdisp}")
+    out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+    _call(entry, _p(x), _p(out), B, D, H * W)
+    return out
+
+
+def unimodal_disparity(x, maxdisp):
+    """Expectation over the mode containing the arg-max (unimodal_disparity_estimator.py:4-25) -> [B,1,H,W]."""
+    return _modal_estimator("stx_unimodal_fwd", x, maxdisp)
+
+
+def dominant_modal_disparity(x, maxdisp):
+    """Expectation over the heavier of the two main modes of the blurred volume
+    (dominant_modal_disparity_estimator.py:35-54) -> [B,1,H,W]."""
+    return _modal_estimator("stx_dominant_modal_fwd", x, maxdisp)
+
+
 def softmax_over_d(x):
     """x [B, D, H, W] -> softmax over D."""
     _chk(x, "x", 4)

@@ -28,6 +28,22 @@ def synthetic_tensor(shape, seed, stream=0, lo=-1.7320508, hi=1.7320508):
     return torch.from_numpy((u * np.float32(hi - lo) + np.float32(lo)).reshape(shape))
 
 
+def synthetic_modal_volume(B, D, H, W, seed):
+    """Deterministic multi-modal probability volume [B,D,H,W] (sums to 1 over D): two Gaussian modes per pixel
+    with hash-drawn centres / widths / weights plus a small rough floor -- the kind of input the modal disparity
+    estimators are written for (a plain softmax of noise has no modes to find)."""
+    u = lambda k, lo, hi: synthetic_tensor((B, 1, H, W), seed, stream=k, lo=lo, hi=hi)
+    d = torch.arange(D, dtype=torch.float32).view(1, D, 1, 1)
+    m1, m2 = u(1, 0.0, D - 1.0), u(2, 0.0, D - 1.0)
+    s1, s2 = u(3, 0.7, 2.5), u(4, 0.7, 2.5)
+    w1 = u(5, 0.15, 0.85)
+    g1 = torch.exp(-0.5 * ((d - m1) / s1) ** 2)
+    g2 = torch.exp(-0.5 * ((d - m2) / s2) ** 2)
+    x = w1 * g1 / g1.sum(1, keepdim=True) + (1 - w1) * g2 / g2.sum(1, keepdim=True)
+    x = x + synthetic_tensor((B, D, H, W), seed, stream=6, lo=0.0, hi=2e-3)
+    return x / x.sum(1, keepdim=True)
+
+
 def fill_state_dict(sd, seed=1234, head_gain=4.0, gain2d=0.5, gain3d=0.85):
     """In-place deterministic fill of a model state-dict: He-like uniform conv/linear
     weights, BN gamma in [0.5,1.5), beta / running_mean in +-0.1, running_var in [0.5,1.5).

@@ -1,0 +1,41 @@
+"""Golden vectors for the modal disparity estimators, generated from the reference.
+
+Run in the build container only (needs /root/reference): `python tests/golden/make_golden_modal.py`.
+Writes tests/golden/estimators_modal.npz: outputs of the reference's
+disparity_estimators/{unimodal,dominant_modal}_disparity_estimator.py on deterministic volumes that the tests
+regenerate from seeds (stereo_toolbox_amd.utils.synthetic_modal_volume); only outputs are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/stereo_toolbox")
+
+import disparity_estimators as ref_est  # noqa: E402
+
+from stereo_toolbox_amd.utils import synthetic_modal_volume, synthetic_tensor  # noqa: E402
+
+CASES = {"a": (2, 32, 5, 9, 21), "b": (1, 48, 4, 7, 22), "c": (1, 192, 3, 5, 23)}
+
+
+def main():
+    out = {}
+    for tag, (B, D, H, W, seed) in CASES.items():
+        x = synthetic_modal_volume(B, D, H, W, seed)
+        out[f"uni_{tag}"] = ref_est.unimodal_disparity_estimator(x, D).numpy()
+        out[f"dom_{tag}"] = ref_est.dominant_modal_disparity_estimator(x, D).numpy()
+    # a plain peaky softmax as well (single mode almost everywhere)
+    peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
+    out["uni_peaky"] = ref_est.unimodal_disparity_estimator(peaky, 16).numpy()
+    out["dom_peaky"] = ref_est.dominant_modal_disparity_estimator(peaky, 16).numpy()
+    np.savez_compressed(os.path.join(HERE, "estimators_modal.npz"), **out)
+    print("wrote estimators_modal.npz", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

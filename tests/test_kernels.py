@@ -124,6 +124,24 @@ def test_estimators(be):
     _close(y, torch.softmax(z, 1), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22), (1, 192, 6, 40, 31), (2, 16, 6, 10, 0)])
+def test_modal_estimators(be, case):
+    """unimodal / dominant-modal estimators vs the oracle (which is pinned bitwise to the reference, tests/golden).
+    The mode choice is discrete: a pixel may legitimately flip when the blurred volume (different fp32 summation order
+    than conv1d) has two near-equal candidates, so a handful of mismatching pixels is tolerated, none is expected."""
+    from stereo_toolbox_amd.utils import synthetic_modal_volume, synthetic_tensor
+    B, D, H, W, seed = case
+    x = synthetic_modal_volume(B, D, H, W, seed) if seed else torch.softmax(synthetic_tensor((B, D, H, W), 13) * 4, 1)
+    d = be.dev(x)
+    for entry, ref in (("stx_unimodal_fwd", O.unimodal_disparity_estimator),
+                       ("stx_dominant_modal_fwd", O.dominant_modal_disparity_estimator)):
+        o = be.empty(B, H * W)
+        be.call(entry, ptr(d), ptr(o), B, D, H * W)
+        want = ref(x, D).reshape(B, H * W)
+        bad = ((o.cpu() - want).abs() > 1e-4 * (1 + want.abs())).sum().item()
+        assert bad <= (0 if entry == "stx_unimodal_fwd" else B * H * W // 100), f"{entry}: {bad} pixels differ"
+
+
 # ------------------------------------------------------------------------------ convolutions
 def pack(be, w, mode):
     A, Bd = w.shape[0], w.shape[1]

@@ -243,7 +243,9 @@ def test_psmnet_config1_eval():
 
 def test_functional_api(env):
     """Drop-in functions of models/GwcNet/submodule.py and disparity_estimators."""
-    from stereo_toolbox_amd.disparity_estimators import argmax_disparity_estimator, softargmax_disparity_estimator
+    from stereo_toolbox_amd.disparity_estimators import (argmax_disparity_estimator, dominant_modal_disparity_estimator,
+                                                         softargmax_disparity_estimator, unimodal_disparity_estimator)
+    from stereo_toolbox_amd.utils import synthetic_modal_volume
     from stereo_toolbox_amd.models.GwcNet.submodule import (build_concat_volume, build_gwc_volume,
                                                             disparity_regression, groupwise_correlation)
     a, b = synthetic_tensor((2, 16, 5, 11), 7), synthetic_tensor((2, 16, 5, 11), 8)
@@ -256,6 +258,12 @@ def test_functional_api(env):
         dr = disparity_regression(x.to(env.device), 16)
         sa = softargmax_disparity_estimator(x.to(env.device), 16)
         am = argmax_disparity_estimator(x.to(env.device), 16)
+        xm = synthetic_modal_volume(2, 32, 5, 9, 21)
+        um = unimodal_disparity_estimator(xm.to(env.device), 32)
+        dm = dominant_modal_disparity_estimator(xm.to(env.device), 32)
+    assert um.shape == (2, 1, 5, 9) and dm.shape == (2, 1, 5, 9)
+    assert (um.cpu() - O.unimodal_disparity_estimator(xm, 32)).abs().max().item() < 1e-4
+    assert (dm.cpu() - O.dominant_modal_disparity_estimator(xm, 32)).abs().max().item() < 1e-4
     assert g.shape == (2, 4, 6, 5, 11) and c.shape == (2, 32, 6, 5, 11) and gc.shape == (2, 4, 5, 11)
     assert (g.cpu() - O.build_gwc_volume(a, b, 6, 4)).abs().max().item() < 1e-6
     assert torch.equal(c.cpu(), O.build_concat_volume(a, b, 6))

@@ -72,6 +72,20 @@ def test_estimators_and_head():
     close(O.regression_head(cost, 16, 20, 28), g["head"], 1e-6)
 
 
+def test_modal_estimators():
+    """unimodal / dominant-modal estimators: bitwise against the reference's outputs
+    (tests/golden/make_golden_modal.py)."""
+    from stereo_toolbox_amd.utils import synthetic_modal_volume
+    g = load("estimators_modal.npz")
+    for tag, (B, D, H, W, seed) in {"a": (2, 32, 5, 9, 21), "b": (1, 48, 4, 7, 22), "c": (1, 192, 3, 5, 23)}.items():
+        x = synthetic_modal_volume(B, D, H, W, seed)
+        assert torch.equal(O.unimodal_disparity_estimator(x, D), g[f"uni_{tag}"])
+        assert torch.equal(O.dominant_modal_disparity_estimator(x, D), g[f"dom_{tag}"])
+    peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
+    assert torch.equal(O.unimodal_disparity_estimator(peaky, 16), g["uni_peaky"])
+    assert torch.equal(O.dominant_modal_disparity_estimator(peaky, 16), g["dom_peaky"])
+
+
 def test_blocks():
     g = load("blocks.npz")
     x = synthetic_tensor((1, 32, 8, 8, 12), 16)

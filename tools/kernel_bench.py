@@ -183,6 +183,19 @@ def main():
                                      a.H, a.W, stream()), it)
         report("head_bwd", ms, nbytes=(cost.numel() * 2 + disp.numel() * 4) * 4)
 
+    if want("estimator"):
+        # full-resolution probability volume [B,192,H,W] (425 MB): two Gaussian modes per pixel + rough floor
+        d = torch.arange(a.D, device=dev, dtype=torch.float32).view(1, a.D, 1, 1)
+        m1, m2 = torch.rand(B, 1, a.H, a.W, device=dev) * (a.D - 1), torch.rand(B, 1, a.H, a.W, device=dev) * (a.D - 1)
+        x = 0.6 * torch.exp(-0.5 * ((d - m1) / 1.5) ** 2) + 0.4 * torch.exp(-0.5 * ((d - m2) / 2.0) ** 2)
+        x += torch.rand(B, a.D, a.H, a.W, device=dev) * 1e-3
+        x /= x.sum(1, keepdim=True)
+        out = torch.empty(B, a.H, a.W, device=dev)
+        for entry in ("stx_softargmax_fwd", "stx_unimodal_fwd", "stx_dominant_modal_fwd"):
+            ms = timeit(lambda: lib.call(entry, P(x), P(out), B, a.D, a.H * a.W, stream()), it)
+            report("estimator_" + entry[4:-4], ms, nbytes=(x.numel() + out.numel()) * 4)
+        del x
+
 
 if __name__ == "__main__":
     main()

@@ -77,16 +77,17 @@ def _infer_conv(x, conv, scale, bias, residual, relu):
 
 def _bn_state(bn, partials, count):
     training = bn.training
+    sync = None
     if training and isinstance(bn, nn.SyncBatchNorm):
+        # trainer/trainer_torchrun.py:112-113 (`SyncBatchNorm.convert_sync_batchnorm`): statistics over all replicas
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise ops.StxError("SyncBatchNorm statistics exchange is not implemented on the HIP path yet: "
-                               "train with per-replica BatchNorm (the reference default, sync_bn off)")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
+            sync = (bn.process_group, dist.get_world_size(bn.process_group))
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     momentum = bn.momentum if bn.momentum is not None else 0.1
     return {"training": training, "partials": partials, "count": count, "running_mean": bn.running_mean,
-            "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps}
+            "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps, "sync": sync}
 
 
 def conv_block(x, conv, bn=None, relu=False, second=None, residual=None):

@@ -252,6 +252,20 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return outs   # scale, shift, mean, invstd
 
 
+def _sync_bn_partials(partials, count, group, world):
+    """SyncBatchNorm forward: sum the conv-epilogue partials (sum z, sum z^2 per channel) over the replicas.
+    The local rows are reduced in fp64, all-reduced in fp64 (2C values: latency-bound, RCCL), and handed to
+    stx_bn_finalize as two fp32 rows hi + lo so that its fp64 accumulation sees the exact global sums
+    (E[z^2] - mean^2 cancels badly on single-precision totals).  Equal per-replica batches are assumed, as
+    DistributedSampler(drop_last=True) guarantees (trainer_torchrun.py:130-136)."""
+    import torch.distributed as dist
+    tot = partials.double().sum(0)                 # [2, C]
+    dist.all_reduce(tot, group=group)
+    hi = tot.float()
+    lo = (tot - hi.double()).float()
+    return torch.stack((hi, lo)).contiguous(), count * world
+
+
 def bn_apply(z1, scale1, shift1, z2=None, scale2=None, shift2=None, relu=False):
     out = torch.empty_like(z1)
     C = z1.shape[-1]
@@ -269,7 +283,10 @@ class BnActFn(torch.autograd.Function):
     def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2):
         def affine(z, gamma, beta, bn):
             if bn["training"]:
-                return bn_finalize(bn["partials"], bn["count"], gamma, beta, bn["running_mean"], bn["running_var"],
+                partials, count = bn["partials"], bn["count"]
+                if bn.get("sync"):
+                    partials, count = _sync_bn_partials(partials, count, *bn["sync"])
+                return bn_finalize(partials, count, gamma, beta, bn["running_mean"], bn["running_var"],
                                    bn["momentum"], bn["eps"])
             invstd = torch.rsqrt(bn["running_var"] + bn["eps"])
             scale = gamma * invstd
@@ -286,6 +303,7 @@ class BnActFn(torch.autograd.Function):
         ctx.relu, ctx.two, ctx.has_res = relu, two, residual is not None
         ctx.train1 = bn1["training"]
         ctx.train2 = bn2["training"] if two else False
+        ctx.sync = bn1.get("sync") or (bn2.get("sync") if two else None)
         ctx.save_for_backward(z1, gamma1, m1, i1, z2, gamma2, m2, i2, y if relu else None)
         return y
 
@@ -305,6 +323,13 @@ class BnActFn(torch.autograd.Function):
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
         use = sums
+        if ctx.sync:
+            # SyncBatchNorm: the centering terms are means over ALL replicas; the kernel divides by the local voxel
+            # count, so hand it (sum over replicas) / world.  Parameter gradients stay local (DDP averages them).
+            import torch.distributed as dist
+            use = sums.clone()
+            dist.all_reduce(use, group=ctx.sync[0])
+            use /= ctx.sync[1]
         if not ctx.train1 or (ctx.two and not ctx.train2):
             # running-stat BN: no centering terms (mixed train/eval pairs are not used by these models)
             use = torch.zeros_like(sums)

@@ -91,3 +91,75 @@ def test_flat_grad_sync_single_process():
     assert sync.all_reduce() is None                # world size 1: no collective
     sync.zero_grad()
     assert sync.flat.abs().sum() == 0 and sync.views_intact()
+
+
+# ------------------------------------------------------------------------------ SyncBatchNorm
+def _syncbn_block():
+    torch.manual_seed(3)
+    conv = nn.Conv3d(32, 32, 3, padding=1, bias=False)
+    bn = nn.BatchNorm3d(32)
+    with torch.no_grad():
+        conv.weight.mul_(0.5)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    return nn.Sequential(conv, bn)
+
+
+def _syncbn_data():
+    torch.manual_seed(5)
+    return torch.randn(2, 32, 3, 4, 20) + 0.3, torch.randn(2, 32, 3, 4, 20)      # input (global batch 2), grad of output
+
+
+def _syncbn_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_util import emu_product_path
+    from stereo_toolbox_amd import aggregation
+    seq = nn.SyncBatchNorm.convert_sync_batchnorm(_syncbn_block())
+    assert isinstance(seq[1], nn.SyncBatchNorm)
+    seq.train()
+    x, gy = _syncbn_data()
+    xs = x[rank:rank + 1].permute(0, 2, 3, 4, 1).contiguous().requires_grad_()     # NDHWC shard
+    with emu_product_path():
+        y = aggregation.convbn_block(xs, seq, relu=True)
+        y.backward(gy[rank:rank + 1].permute(0, 2, 3, 4, 1).contiguous())
+    # numpy arrays are pickled by value (torch tensors travel as shared-memory handles that die with the worker)
+    q.put((rank,) + tuple(t.detach().numpy().copy() for t in (y, xs.grad, seq[0].weight.grad, seq[1].weight.grad,
+                                                               seq[1].bias.grad, seq[1].running_mean, seq[1].running_var)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_gloo():
+    """convbn_3d + ReLU in train mode under SyncBatchNorm (reference trainer_torchrun.py:112-113): two gloo ranks with one
+    sample each, run through the emulated product kernels, must reproduce stock BatchNorm over the global batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [(r[0],) + tuple(torch.from_numpy(a) for a in r[1:]) for r in res]
+    seq = _syncbn_block().train()
+    x, gy = _syncbn_data()
+    xr = x.clone().requires_grad_()
+    yr = torch.relu(seq(xr))
+    yr.backward(gy)
+
+    def close(a, b, tol=2e-4):
+        assert (a - b).abs().max().item() <= tol * (1 + b.abs().max().item()), (a - b).abs().max().item()
+    for r in range(2):
+        close(res[r][1].permute(0, 4, 1, 2, 3), yr[r:r + 1].detach())
+        close(res[r][2].permute(0, 4, 1, 2, 3), xr.grad[r:r + 1])
+        close(res[r][6], seq[1].running_mean)
+        close(res[r][7], seq[1].running_var)
+    # parameter gradients are local sums; their total over the ranks is the global-batch gradient (DDP then averages)
+    close(res[0][3] + res[1][3], seq[0].weight.grad)
+    close(res[0][4] + res[1][4], seq[1].weight.grad)
+    close(res[0][5] + res[1][5], seq[1].bias.grad)

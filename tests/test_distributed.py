@@ -163,3 +163,43 @@ def test_sync_batchnorm_two_ranks_gloo():
     close(res[0][3] + res[1][3], seq[0].weight.grad)
     close(res[0][4] + res[1][4], seq[1].weight.grad)
     close(res[0][5] + res[1][5], seq[1].bias.grad)
+
+
+# ------------------------------------------------------------------------------ sharded evaluation metrics
+def _metrics_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stereo_toolbox_amd.metrics import DisparityMetrics
+    torch.manual_seed(11)
+    gt = torch.rand(6, 8, 10) * 70
+    pred = gt + torch.randn(6, 8, 10) * 2
+    acc = DisparityMetrics(64)
+    acc.update(pred[rank::world], gt[rank::world])           # batch-sharded evaluation
+    acc.all_reduce()
+    q.put((rank, acc.compute()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_metrics_all_reduce_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_metrics_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from stereo_toolbox_amd.metrics import DisparityMetrics
+    torch.manual_seed(11)
+    gt = torch.rand(6, 8, 10) * 70
+    pred = gt + torch.randn(6, 8, 10) * 2
+    one = DisparityMetrics(64)
+    one.update(pred, gt)
+    want = one.compute()
+    for r in range(2):
+        assert abs(res[r][1]["epe"] - want["epe"]) < 1e-9
+        assert all(abs(a - b) < 1e-9 for a, b in zip(res[r][1]["outliers"], want["outliers"]))

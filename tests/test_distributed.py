@@ -135,6 +135,9 @@ def _syncbn_worker(rank, world, port, q):
 def test_sync_batchnorm_two_ranks_gloo():
     """convbn_3d + ReLU in train mode under SyncBatchNorm (reference trainer_torchrun.py:112-113): two gloo ranks with one
     sample each, run through the emulated product kernels, must reproduce stock BatchNorm over the global batch."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu_util import emu_lib
+    emu_lib()                                      # build the emulator library once, before the ranks race for it
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(CVR_THREADS, 4) void cost_volume_fwd_row_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Lean row-persistent builder for 8 channels per group and voxels of <= 64 channels (GwcNet_GC: 40 groups +
-// 2 x 12 concat channels = exactly 64; GwcNet_G / ACVNet gwc volume: 40).
+// 2 x 12 concat channels = exactly 64; GwcNet_G / ACVNet gwc volume: 40; PSMNet: no groups, 2 x 32 concat channels).
 //
 // cost_volume_fwd_row_kernel above keeps every size a run-time value and maps a thread to (column, 4-channel quad):
 // its compute loop issues ~150 instructions per stored float4 (run-time divisions and multiplies for the item
@@ -390,16 +390,17 @@ __global__ __launch_bounds__(CVR_THREADS, 4) void cost_volume_fwd_row_kernel(
 // (multiply without stores 0.114 ms): the per-voxel chain ds_read -> 8 dependent FMAs is latency-bound.  LDS image of a column:
 // [half][group][4] (+4 pad) so that the 16 lanes of a ds_read_b128 phase hit 16 distinct 16-byte bank groups.
 constexpr int CVL_THREADS = 1024, CVL_LOADERS = 256;      // 4 staging waves + 12 compute waves
-constexpr int CVL_DC = 16, CVL_RING = 32, CVL_FS = 324, CVL_CS = 16;
+constexpr int CVL_DC = 16, CVL_RING = 32, CVL_FS = 324, CVL_CS = 33, CVL_MAXCC = 32;   // concat rows: odd stride
 constexpr int CVL_MAXK = 20;                                   // channel steps of 16 per operand (Cg <= 320)
 
 __global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
     const float* __restrict__ Lg, const float* __restrict__ Rg, int G, const float* __restrict__ Lc,
     const float* __restrict__ Rc, int Cc, float* __restrict__ vol, int H, int W, int D, int mask_left) {
     STX_DYN_SMEM(smem);
-    float* Lg_s = reinterpret_cast<float*>(smem);             // [16][CVL_FS]
-    float* Rg_s = Lg_s + CV_WT * CVL_FS;                      // [32][CVL_FS] ring
-    float* Lc_s = Rg_s + CVL_RING * CVL_FS;                   // [16][CVL_CS]
+    const int fs = G ? CVL_FS : 0;                            // concat-only volumes (PSMNet) keep no gwc image
+    float* Lg_s = reinterpret_cast<float*>(smem);             // [16][fs]
+    float* Rg_s = Lg_s + CV_WT * fs;                          // [32][fs] ring
+    float* Lc_s = Rg_s + CVL_RING * fs;                       // [16][CVL_CS]
     float* Rc_s = Lc_s + CV_WT * CVL_CS;                      // [32][CVL_CS] ring
     const int tid = threadIdx.x;
     int bid;
@@ -417,13 +418,13 @@ __global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
     const bool loader = __builtin_amdgcn_readfirstlane(tid >> 6) < CVL_LOADERS / 64;     // wave-uniform role
 
     if (loader) {
-        const float* Lg_row = Lg + ((size_t)b * Cg * H + h) * W;
-        const float* Rg_row = Rg + ((size_t)b * Cg * H + h) * W;
-        const float* Lc_row = Cc ? Lc + ((size_t)b * Cc * H + h) * W : nullptr;
-        const float* Rc_row = Cc ? Rc + ((size_t)b * Cc * H + h) * W : nullptr;
+        const float* Lg_row = stx_uniform_ptr(Lg + ((size_t)b * Cg * H + h) * W);
+        const float* Rg_row = stx_uniform_ptr(Rg + ((size_t)b * Cg * H + h) * W);
+        const float* Lc_row = stx_uniform_ptr(Lc + ((size_t)b * Cc * H + h) * W);     // (only dereferenced when Cc > 0)
+        const float* Rc_row = stx_uniform_ptr(Rc + ((size_t)b * Cc * H + h) * W);
         // staging map: lane -> column tid & 15, channel (tid >> 4) + 16 k
         const int scol = tid & (CV_WT - 1), sch = tid >> 4;
-        float stL[CVL_MAXK], stR[CVL_MAXK], stLc = 0.f, stRc = 0.f;
+        float stL[CVL_MAXK], stR[CVL_MAXK], stLc[2] = {0.f, 0.f}, stRc[2] = {0.f, 0.f};
         auto prefetch = [&](int t) {
             const int xl = t * CV_WT + scol, xr = xl - d0;
             const bool okl = xl < W, okr = xr >= 0 && xr < W;
@@ -438,9 +439,16 @@ __global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
                 stR[k] = (ck && okr) ? Rg_row[orr] : 0.f;
                 ol += step; orr += step;
             }
-            if (sch < Cc) {
-                stLc = okl ? Lc_row[(unsigned)(sch * HW + xl)] : 0.f;
-                stRc = okr ? Rc_row[(unsigned)(sch * HW + xr)] : 0.f;
+            unsigned cl_ = (unsigned)(sch * HW + xl), cr_ = (unsigned)(sch * HW + xr);
+            STX_OPAQUE_VGPR(cl_);
+            STX_OPAQUE_VGPR(cr_);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (sch + 16 * j < Cc) {
+                    stLc[j] = okl ? Lc_row[cl_] : 0.f;
+                    stRc[j] = okr ? Rc_row[cr_] : 0.f;
+                }
+                cl_ += step; cr_ += step;
             }
         };
         auto commit = [&](int t) {
@@ -456,9 +464,13 @@ __global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
                     Rg_s[rslot * CVL_FS + pos] = stR[k];
                 }
             }
-            if (sch < Cc) {
-                Lc_s[scol * CVL_CS + sch] = stLc;
-                Rc_s[rslot * CVL_CS + sch] = stRc;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = sch + 16 * j;
+                if (c < Cc) {
+                    Lc_s[scol * CVL_CS + c] = stLc[j];
+                    Rc_s[rslot * CVL_CS + c] = stRc[j];
+                }
             }
         };
         prefetch(0);
@@ -488,19 +500,23 @@ __global__ __launch_bounds__(CVL_THREADS, 8) void cost_volume_fwd_g8_kernel(
             const int wl = item & (CV_WT - 1), dg = item >> 4;
             const int w = t * CV_WT + wl;
             if (w >= W || 4 * dg >= dend) continue;
-            const float4 l0 = stx_ld4(Lg_s + wl * CVL_FS + gq), l1 = stx_ld4(Lg_s + wl * CVL_FS + 160 + gq);
+            float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0;
+            if (G) { l0 = stx_ld4(Lg_s + wl * CVL_FS + gq); l1 = stx_ld4(Lg_s + wl * CVL_FS + 160 + gq); }
             const float lcv = Lc_s[wl * CVL_CS + cl];
             float* o = vol + ((((size_t)b * D + d0 + 4 * dg) * H + h) * W + w) * CT + lane;
             const int x0 = w - d0 - 4 * dg;                      // right column of the item's first disparity
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
                 const int slot = (x0 - dd + 1024) & (CVL_RING - 1);
-                const float* rp = Rg_s + slot * CVL_FS + gq;
-                const float4 r0 = stx_ld4(rp), r1 = stx_ld4(rp + 160);
                 const float rc = Rc_s[slot * CVL_CS + cr];
-                float s = l0.x * r0.x;
-                s = fmaf(l0.y, r0.y, s); s = fmaf(l0.z, r0.z, s); s = fmaf(l0.w, r0.w, s);
-                s = fmaf(l1.x, r1.x, s); s = fmaf(l1.y, r1.y, s); s = fmaf(l1.z, r1.z, s); s = fmaf(l1.w, r1.w, s);
+                float s = 0.f;
+                if (G) {                                         // wave-uniform
+                    const float* rp = Rg_s + slot * CVL_FS + gq;
+                    const float4 r0 = stx_ld4(rp), r1 = stx_ld4(rp + 160);
+                    s = l0.x * r0.x;
+                    s = fmaf(l0.y, r0.y, s); s = fmaf(l0.z, r0.z, s); s = fmaf(l0.w, r0.w, s);
+                    s = fmaf(l1.x, r1.x, s); s = fmaf(l1.y, r1.y, s); s = fmaf(l1.z, r1.z, s); s = fmaf(l1.w, r1.w, s);
+                }
                 const bool valid = x0 - dd >= 0;
                 float v = valid ? s * 0.125f : 0.f;              // (ring slots left of the image hold stale data)
                 v = is_l ? ((valid || !mask_left) ? lcv : 0.f) : v;
@@ -861,8 +877,8 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     static const int no_row = getenv("STX_CV_NO_ROW") ? 1 : 0;
     const size_t lds_row = ((size_t)(CV_WT + CVR_RING) * (Cg + 4) + (size_t)(CV_WT + CVR_RING) * (Cc + 4)) * 4;
     static const int no_g8 = getenv("STX_CV_NO_G8") ? 1 : 0;
-    if (G && !no_g8 && !scale && cpg == 8 && G <= 40 && Cc <= CVL_CS && G + 2 * Cc <= 64) {
-        const size_t lds8 = ((size_t)(CV_WT + CVL_RING) * CVL_FS + (size_t)(CV_WT + CVL_RING) * CVL_CS) * 4;
+    if (!no_g8 && !scale && (G == 0 || cpg == 8) && G <= 40 && Cc <= CVL_MAXCC && G + 2 * Cc <= 64) {
+        const size_t lds8 = ((size_t)(CV_WT + CVL_RING) * (G ? CVL_FS : 0) + (size_t)(CV_WT + CVL_RING) * CVL_CS) * 4;
         hipFuncSetAttribute((const void*)cost_volume_fwd_g8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
         hipLaunchKernelGGL(cost_volume_fwd_g8_kernel, dim3(B * H * stx_cdiv(D, CVL_DC)), dim3(CVL_THREADS), lds8, st0, Lg,
                            Rg, G, Lc, Rc, Cc, vol, H, W, D, mask_left);

@@ -23,6 +23,15 @@
 // would otherwise be precomputed into dozens of live registers; guide 5.7 item 3).
 #define STX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
+// A pointer the program knows to be wave-uniform, forced into SGPRs (two v_readfirstlane): loads through it become
+// `global_load v, v_offset, s[base:base+1]` and it cannot be spilled to scratch as a VGPR pair.
+template <typename T>
+__device__ __forceinline__ T* stx_uniform_ptr(T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (T*)(((unsigned long long)hi << 32) | lo);
+}
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

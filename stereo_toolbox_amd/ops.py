@@ -555,7 +555,11 @@ def argmax_disparity(x):
 
 def _modal_estimator(entry, x, maxdisp):
     assert len(x.shape) == 4
-    x = x.detach().contiguous()            # the reference masks with `.data`: no gradient is defined through the mode choice
+    if torch.is_grad_enabled() and x.requires_grad:
+        # the reference is differentiable w.r.t. x inside the (detached) mode mask; only the forward pass is
+        # implemented here (the toolbox calls these estimators at inference time) -- fail loudly rather than cut the graph
+        raise StxError(f"{entry}: forward only; call it under torch.no_grad() or on a detached volume")
+    x = x.contiguous()
     _chk(x, "x", 4)
     B, D, H, W = x.shape
     if D != maxdisp:

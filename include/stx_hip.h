@@ -101,6 +101,11 @@ int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, float* works
                         int Cin, void* stream);
 int stx_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int D, int H, int W, int Cin, void* stream);
 
+/* Mish activation y = x * tanh(softplus(x)) (models/PCWNet/submodule.py:11-18,178-190): n floats, n % 4 == 0, in place allowed;
+ * backward gx = gy * mish'(x) with x the activation input. */
+int stx_mish_fwd(const float* x, float* y, long long n, void* stream);
+int stx_mish_bwd(const float* gy, const float* x, float* gx, long long n, void* stream);
+
 /* ---- ACVNet extras (models/ACVNet/acv.py) --------------------------------------------------------------
  * Depth-wise nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d)) (acv.py:109-112,183-187) on a channels-last
  * volume; `dil` = int[C/4] dilation per channel quad (device pointer); w = [C][9]; flip=1 mirrors the taps (input gradient). */

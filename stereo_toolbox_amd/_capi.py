@@ -48,6 +48,9 @@ SIGNATURES = {
     "stx_conv3d_c1_wgrad_workspace_floats": [_I],
     "stx_conv3d_c1_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_c1_dgrad": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    # act.hip
+    "stx_mish_fwd": [_P, _P, _L, _P],
+    "stx_mish_bwd": [_P, _P, _P, _L, _P],
     # acv.hip
     "stx_dwconv_hw_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_dwconv_hw_wgrad_workspace_floats": [_I],

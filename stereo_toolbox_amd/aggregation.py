@@ -90,10 +90,15 @@ def _bn_state(bn, partials, count):
             "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps, "sync": sync}
 
 
-def conv_block(x, conv, bn=None, relu=False, second=None, residual=None):
+def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False):
     """One fused block on NDHWC tensors.
     second = (x2, conv2, bn2): adds BN2(conv2(x2)) before the activation (hourglass redir path).
-    residual: NDHWC tensor added before the activation."""
+    residual: NDHWC tensor added before the activation.
+    mish: Mish instead of ReLU (PCWNet / CFNet family); applied as a separate streaming pass for now."""
+    if mish:
+        if relu:
+            raise ops.StxError("conv_block: relu and mish are mutually exclusive")
+        return ops.mish(conv_block(x, conv, bn, relu=False, second=second, residual=residual))
     if second is not None and residual is not None:
         raise ops.StxError("conv_block: `second` and `residual` are mutually exclusive")
     mods = [conv, bn] + ([second[1], second[2]] if second is not None else [])
@@ -131,9 +136,9 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None):
     return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None)
 
 
-def convbn_block(x, seq, relu=False, second=None, residual=None):
+def convbn_block(x, seq, relu=False, second=None, residual=None, mish=False):
     """`seq` = nn.Sequential(conv, bn) as built by convbn_3d (or (ConvTranspose3d, BatchNorm3d))."""
     sec = None
     if second is not None:
         sec = (second[0], second[1][0], second[1][1])
-    return conv_block(x, seq[0], seq[1], relu=relu, second=sec, residual=residual)
+    return conv_block(x, seq[0], seq[1], relu=relu, second=sec, residual=residual, mish=mish)

@@ -342,6 +342,39 @@ class BnActFn(torch.autograd.Function):
                 None, None, None)
 
 
+# --------------------------------------------------------------------------------------- activations
+class MishFn(torch.autograd.Function):
+    """y = x * tanh(softplus(x)) (PCWNet/CFNet `Mish` / `FMish`, models/PCWNet/submodule.py:11-18,178-190)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _chk(x, "x")
+        y = torch.empty_like(x)
+        _call("stx_mish_fwd", _p(x), _p(y), x.numel())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        _call("stx_mish_bwd", _p(gy), _p(x), _p(gx), x.numel())
+        return gx
+
+
+def mish(x):
+    """Mish on a dense fp32 tensor with numel % 4 == 0 (every channels-last activation of these models)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return MishFn.apply(x)
+    x = x.contiguous()
+    _chk(x, "x")
+    y = torch.empty_like(x)
+    _call("stx_mish_fwd", _p(x), _p(y), x.numel())
+    return y
+
+
 # --------------------------------------------------------------------------------------- cost volume
 def _cv_shapes(Lg, Lc, num_groups):
     ref = Lg if Lg is not None else Lc

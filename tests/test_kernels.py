@@ -316,6 +316,23 @@ def test_conv3d_c1_fwd_wgrad(be, case):
     _close(ncdhw(gx), xg.grad)
 
 
+def test_mish(be):
+    """Mish forward / backward vs torch (the reference's x * tanh(softplus(x)))."""
+    torch.manual_seed(21)
+    x = torch.cat((torch.randn(2, 3, 4, 5, 8) * 3, torch.tensor([-30., -5., 0., 5., 19.9, 20.1, 30., 1e-3]).repeat(2, 3, 4, 5, 1)), 0)
+    xr = x.clone().requires_grad_()
+    y = xr * torch.tanh(F.softplus(xr))
+    g = torch.randn_like(x)
+    y.backward(g)
+    dx = be.dev(x)
+    out = be.empty(*x.shape)
+    be.call("stx_mish_fwd", ptr(dx), ptr(out), x.numel())
+    _close(out, y.detach(), rtol=1e-5, atol=1e-6)
+    gx = be.empty(*x.shape)
+    be.call("stx_mish_bwd", ptr(be.dev(g)), ptr(dx), ptr(gx), x.numel())
+    _close(gx, xr.grad, rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------ ACVNet extras
 def test_dwconv_hw_fwd_bwd(be):
     """Depth-wise (1,3,3) patch convolutions with per-channel dilation (acv.py:109-112,183-187)."""

@@ -48,6 +48,12 @@ int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, in
 long long stx_head_bwd_workspace_floats(int B, int Dc, int H, int W);
 int stx_head_bwd(const float* gdisp, const float* cost, const float* disp, const float* stats, float* gcost,
                  float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream);
+/* the same two with an explicit interpolation rule: align_corners != 0 is F.upsample(..., align_corners=True), the
+ * head of the PCWNet / CFNet family (models/PCWNet/pcwnet.py:446-470); align_corners == 0 equals the entries above */
+int stx_head_fwd2(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                  int align_corners, void* stream);
+int stx_head_bwd2(const float* gdisp, const float* cost, const float* disp, const float* stats, float* gcost,
+                  float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, int align_corners, void* stream);
 /* disparity_regression (GwcNet/submodule.py:23-27), disparityregression (PSMNet/submodule.py:46-54),
  * softargmax_disparity_estimator (disparity_estimators/__init__.py:7-10): out[b][hw] = sum_d d * x[b][d][hw] */
 int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream);

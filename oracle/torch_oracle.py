@@ -142,10 +142,11 @@ def dominant_modal_disparity_estimator(x, maxdisp=192):
     return torch.sum(xs * disp, 1, keepdim=True)
 
 
-def regression_head(cost, maxdisp, H, W, keepdim=False):
+def regression_head(cost, maxdisp, H, W, keepdim=False, align_corners=False):
     """upsample(trilinear) -> squeeze -> softmax(dim=1) -> disparity_regression
-    (GwcNet/gwcnet.py:219-224, PSMNet/stackhourglass.py:147-153, ACVNet/acv.py:247-251)."""
-    c = F.interpolate(cost, [maxdisp, H, W], mode="trilinear", align_corners=False)
+    (GwcNet/gwcnet.py:219-224, PSMNet/stackhourglass.py:147-153, ACVNet/acv.py:247-251; with align_corners=True:
+    PCWNet/pcwnet.py:446-470, CFNet/cfnet.py)."""
+    c = F.interpolate(cost, [maxdisp, H, W], mode="trilinear", align_corners=align_corners)
     c = torch.squeeze(c, 1)
     p = F.softmax(c, dim=1)
     return disparity_regression(p, maxdisp, keepdim=keepdim)

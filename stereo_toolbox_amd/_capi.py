@@ -28,6 +28,8 @@ SIGNATURES = {
     "stx_head_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_head_bwd_workspace_floats": [_I, _I, _I, _I],
     "stx_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_head_fwd2": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_head_bwd2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_softargmax_fwd": [_P, _P, _I, _I, _I, _P],
     "stx_argmax_fwd": [_P, _P, _I, _I, _I, _P],
     "stx_softmax_d_fwd": [_P, _P, _I, _I, _I, _P],

@@ -26,9 +26,24 @@ constexpr int HD_THREADS = 256;
 
 struct Lerp { int i0, i1; float t; };
 
+// AC = false: align_corners=False (GwcNet / PSMNet / ACVNet heads): src = max(scale*(dst+0.5)-0.5, 0), scale = in/out
+// AC = true : align_corners=True  (PCWNet / CFNet heads, models/PCWNet/pcwnet.py:446-470): src = scale*dst,
+//             scale = (in-1)/(out-1)
+template <bool AC>
+__device__ __forceinline__ float hd_scale(int n_in, int n_out) {
+    if (AC) return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
+    return (float)n_in / (float)n_out;
+}
+
+template <bool AC>
 __device__ __forceinline__ Lerp hd_src(int dst, float scale, int n) {
-    float s = scale * ((float)dst + 0.5f) - 0.5f;
-    s = s < 0.f ? 0.f : s;
+    float s;
+    if (AC) {
+        s = scale * (float)dst;
+    } else {
+        s = scale * ((float)dst + 0.5f) - 0.5f;
+        s = s < 0.f ? 0.f : s;
+    }
     int i0 = (int)s;
     if (i0 > n - 1) i0 = n - 1;
     Lerp r;
@@ -44,14 +59,15 @@ __device__ __forceinline__ float hd_sample(const float* __restrict__ plane, int 
     return (1.f - lh.t) * ((1.f - lw.t) * a + lw.t * b) + lh.t * ((1.f - lw.t) * c + lw.t * d);
 }
 
+template <bool AC>
 __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     const float* __restrict__ cost, float* __restrict__ disp, float* __restrict__ stats,
     int Dc, int Hc, int Wc, int D, int H, int W) {
     const int w = blockIdx.x * HD_THREADS + threadIdx.x;
     const int h = blockIdx.y, b = blockIdx.z;
     if (w >= W) return;
-    const float rd = (float)Dc / (float)D, rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
-    const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
+    const float rd = hd_scale<AC>(Dc, D), rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
+    const Lerp lh = hd_src<AC>(h, rh, Hc), lw = hd_src<AC>(w, rw, Wc);
     const float* cb = cost + (size_t)b * Dc * Hc * Wc;
     const int plane = Hc * Wc;
     int cur = 0;
@@ -59,7 +75,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
     float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
     float m = -3.0e38f, s = 0.f, t = 0.f;
     for (int d = 0; d < D; ++d) {
-        const Lerp ld = hd_src(d, rd, Dc);
+        const Lerp ld = hd_src<AC>(d, rd, Dc);
         while (cur < ld.i0) {
             ++cur;
             c0 = c1;
@@ -88,14 +104,15 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_kernel(
 //          lerp into the pixel's 48 H/W-interpolated cost samples -> gpix[b][dc][h][w];
 //  pass 2 (one thread per cost cell): gathers gpix over the <= 8x8 pixels whose H/W lerp touches the
 //          cell, with the same lerp weights.
+template <bool AC>
 __global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_kernel(
     const float* __restrict__ gout, const float* __restrict__ cost, const float* __restrict__ disp,
     const float* __restrict__ stats, float* __restrict__ gpix, int Dc, int Hc, int Wc, int D, int H, int W) {
     const int w = blockIdx.x * HD_THREADS + threadIdx.x;
     const int h = blockIdx.y, b = blockIdx.z;
     if (w >= W) return;
-    const float rd = (float)Dc / (float)D, rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
-    const Lerp lh = hd_src(h, rh, Hc), lw = hd_src(w, rw, Wc);
+    const float rd = hd_scale<AC>(Dc, D), rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
+    const Lerp lh = hd_src<AC>(h, rh, Hc), lw = hd_src<AC>(w, rw, Wc);
     const float* cb = cost + (size_t)b * Dc * Hc * Wc;
     const int plane = Hc * Wc;
     const size_t o = ((size_t)b * H + h) * W + w;
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_kernel(
     float c1 = Dc > 1 ? hd_sample(cb + plane, Wc, lh, lw) : c0;
     float a0 = 0.f, a1 = 0.f;   // gradient wrt c0 / c1
     for (int d = 0; d < D; ++d) {
-        const Lerp ld = hd_src(d, rd, Dc);
+        const Lerp ld = hd_src<AC>(d, rd, Dc);
         while (cur < ld.i0) {
             gp[cur * pstride] = a0;
             ++cur;
@@ -127,21 +144,30 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_kernel(
     for (int dc = cur + 2; dc < Dc; ++dc) gp[dc * pstride] = 0.f;
 }
 
-// weight with which output index `dst` reads source cell `cell` under the align_corners=False lerp
+// weight with which output index `dst` reads source cell `cell` under the lerp
+template <bool AC>
 __device__ __forceinline__ float hd_weight(int dst, float scale, int n, int cell) {
-    const Lerp l = hd_src(dst, scale, n);
+    const Lerp l = hd_src<AC>(dst, scale, n);
     return (l.i0 == cell ? 1.f - l.t : 0.f) + (l.i1 == cell ? l.t : 0.f);
 }
 
+template <bool AC>
 __global__ __launch_bounds__(HD_THREADS) void head_bwd_gather_kernel(
     const float* __restrict__ gpix, float* __restrict__ gcost, int Dc, int Hc, int Wc, int H, int W,
     int fh, int fw) {
     const int wc = blockIdx.x * HD_THREADS + threadIdx.x;
     const int hc = blockIdx.y % Hc, dc = blockIdx.y / Hc, b = blockIdx.z;
     if (wc >= Wc) return;
-    const float rh = (float)Hc / (float)H, rw = (float)Wc / (float)W;
+    const float rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
     // pixels that can touch cell (hc, wc): src in (cell-1, cell+1)  ->  dst in a window of ~2/scale
-    int h_lo = (int)(((float)hc - 1.f + 0.5f) / rh - 0.5f) - 1, w_lo = (int)(((float)wc - 1.f + 0.5f) / rw - 0.5f) - 1;
+    int h_lo, w_lo;
+    if (AC) {
+        h_lo = rh > 0.f ? (int)(((float)hc - 1.f) / rh) - 1 : 0;
+        w_lo = rw > 0.f ? (int)(((float)wc - 1.f) / rw) - 1 : 0;
+    } else {
+        h_lo = (int)(((float)hc - 1.f + 0.5f) / rh - 0.5f) - 1;
+        w_lo = (int)(((float)wc - 1.f + 0.5f) / rw - 0.5f) - 1;
+    }
     h_lo = h_lo < 0 ? 0 : h_lo;
     w_lo = w_lo < 0 ? 0 : w_lo;
     const float* gp = gpix + (((size_t)b * Dc + dc) * H) * W;
@@ -149,13 +175,13 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_gather_kernel(
     for (int i = 0; i < fh; ++i) {
         const int h = h_lo + i;
         if (h >= H) break;
-        const float kh = hd_weight(h, rh, Hc, hc);
+        const float kh = hd_weight<AC>(h, rh, Hc, hc);
         if (kh == 0.f) continue;
         float row = 0.f;
         for (int j = 0; j < fw; ++j) {
             const int w = w_lo + j;
             if (w >= W) break;
-            const float kw = hd_weight(w, rw, Wc, wc);
+            const float kw = hd_weight<AC>(w, rw, Wc, wc);
             if (kw != 0.f) row = fmaf(kw, gp[(size_t)h * W + w], row);
         }
         acc = fmaf(kh, row, acc);
@@ -205,33 +231,69 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 
 }  // namespace
 
-extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D,
-                            int H, int W, void* stream) {
-    stx_begin();
+template <bool AC>
+static int head_fwd_launch(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H,
+                           int W, void* stream) {
     STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
     dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
-    hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
+    hipLaunchKernelGGL(head_fwd_kernel<AC>, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
                        Wc, D, H, W);
     return stx_check_launch("head_fwd");
 }
 
+extern "C" int stx_head_fwd(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D,
+                            int H, int W, void* stream) {
+    stx_begin();
+    return head_fwd_launch<false>(cost, disp, stats, B, Dc, Hc, Wc, D, H, W, stream);
+}
+
+// same with an explicit interpolation rule (align_corners != 0: PCWNet / CFNet heads)
+extern "C" int stx_head_fwd2(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D,
+                             int H, int W, int align_corners, void* stream) {
+    stx_begin();
+    return align_corners ? head_fwd_launch<true>(cost, disp, stats, B, Dc, Hc, Wc, D, H, W, stream)
+                         : head_fwd_launch<false>(cost, disp, stats, B, Dc, Hc, Wc, D, H, W, stream);
+}
+
 extern "C" long long stx_head_bwd_workspace_floats(int B, int Dc, int H, int W) { return (long long)B * Dc * H * W; }
+
+template <bool AC>
+static int head_bwd_launch(const float* gout, const float* cost, const float* disp, const float* stats, float* gcost,
+                           float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
+    STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_bwd_pix_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
+                       disp, stats, workspace, Dc, Hc, Wc, D, H, W);
+    int rc = stx_check_launch("head_bwd(pixels)");
+    if (rc) return rc;
+    // footprint of a cost cell in output pixels: 2/scale (+ slack for the border clamps)
+    int fh, fw;
+    if (AC) {
+        fh = Hc > 1 ? 2 * stx_cdiv(H - 1, Hc - 1) + 3 : H;
+        fw = Wc > 1 ? 2 * stx_cdiv(W - 1, Wc - 1) + 3 : W;
+    } else {
+        fh = 2 * stx_cdiv(H, Hc) + 3;
+        fw = 2 * stx_cdiv(W, Wc) + 3;
+    }
+    hipLaunchKernelGGL(head_bwd_gather_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
+                       workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);
+    return stx_check_launch("head_bwd(gather)");
+}
 
 extern "C" int stx_head_bwd(const float* gout, const float* cost, const float* disp, const float* stats,
                             float* gcost, float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W,
                             void* stream) {
     stx_begin();
-    STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_bwd_pix_kernel, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
-                       disp, stats, workspace, Dc, Hc, Wc, D, H, W);
-    int rc = stx_check_launch("head_bwd(pixels)");
-    if (rc) return rc;
-    // footprint of a cost cell in output pixels: 2/scale (+ slack for the border clamps)
-    const int fh = 2 * stx_cdiv(H, Hc) + 3, fw = 2 * stx_cdiv(W, Wc) + 3;
-    hipLaunchKernelGGL(head_bwd_gather_kernel, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
-                       workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);
-    return stx_check_launch("head_bwd(gather)");
+    return head_bwd_launch<false>(gout, cost, disp, stats, gcost, workspace, B, Dc, Hc, Wc, D, H, W, stream);
+}
+
+extern "C" int stx_head_bwd2(const float* gout, const float* cost, const float* disp, const float* stats,
+                             float* gcost, float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W,
+                             int align_corners, void* stream) {
+    stx_begin();
+    return align_corners
+               ? head_bwd_launch<true>(gout, cost, disp, stats, gcost, workspace, B, Dc, Hc, Wc, D, H, W, stream)
+               : head_bwd_launch<false>(gout, cost, disp, stats, gcost, workspace, B, Dc, Hc, Wc, D, H, W, stream);
 }
 
 extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {

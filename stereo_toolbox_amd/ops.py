@@ -504,36 +504,43 @@ def dwconv_hw(x, w, dil):
 
 # --------------------------------------------------------------------------------------- head
 class HeadFn(torch.autograd.Function):
-    """trilinear upsample -> softmax over D -> soft-argmin, fused. cost: [B, D', H', W'] dense."""
+    """trilinear upsample -> softmax over D -> soft-argmin, fused. cost: [B, D', H', W'] dense.
+    align_corners=False: GwcNet / PSMNet / ACVNet heads; True: PCWNet / CFNet heads."""
 
     @staticmethod
-    def forward(ctx, cost, maxdisp, H, W):
+    def forward(ctx, cost, maxdisp, H, W, align_corners=False):
         _chk(cost, "cost", 4)
         B, Dc, Hc, Wc = cost.shape
         disp = torch.empty(B, H, W, dtype=torch.float32, device=cost.device)
         stats = torch.empty(B, H, W, 2, dtype=torch.float32, device=cost.device)
-        _call("stx_head_fwd", _p(cost), _p(disp), _p(stats), B, Dc, Hc, Wc, maxdisp, H, W)
+        if align_corners:
+            _call("stx_head_fwd2", _p(cost), _p(disp), _p(stats), B, Dc, Hc, Wc, maxdisp, H, W, 1)
+        else:
+            _call("stx_head_fwd", _p(cost), _p(disp), _p(stats), B, Dc, Hc, Wc, maxdisp, H, W)
         ctx.save_for_backward(cost, disp, stats)
-        ctx.cfg = (maxdisp, H, W)
+        ctx.cfg = (maxdisp, H, W, bool(align_corners))
         return disp
 
     @staticmethod
     def backward(ctx, g):
         cost, disp, stats = ctx.saved_tensors
-        maxdisp, H, W = ctx.cfg
+        maxdisp, H, W, ac = ctx.cfg
         B, Dc, Hc, Wc = cost.shape
         gc = torch.empty_like(cost)
         g = g.contiguous()      # keep the dense copy alive across the launch
         ws = _WS.get("headbwd", get_lib().raw("stx_head_bwd_workspace_floats")(B, Dc, H, W), cost.device)
-        _call("stx_head_bwd", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), _p(ws), B, Dc, Hc, Wc, maxdisp, H, W)
-        return gc, None, None, None
+        if ac:
+            _call("stx_head_bwd2", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), _p(ws), B, Dc, Hc, Wc, maxdisp, H, W, 1)
+        else:
+            _call("stx_head_bwd", _p(g), _p(cost), _p(disp), _p(stats), _p(gc), _p(ws), B, Dc, Hc, Wc, maxdisp, H, W)
+        return gc, None, None, None, None
 
 
-def regression_head(cost, maxdisp, H, W):
+def regression_head(cost, maxdisp, H, W, align_corners=False):
     """cost [B, D', H', W'] (or [B,1,D',H',W'] / NDHWC with C=1) -> disparity [B, H, W]."""
     if cost.dim() == 5:
         cost = cost.reshape(cost.shape[0], *_squeeze_c(cost))
-    return HeadFn.apply(cost.contiguous(), maxdisp, H, W)
+    return HeadFn.apply(cost.contiguous(), maxdisp, H, W, align_corners)
 
 
 def _squeeze_c(cost):

@@ -106,6 +106,27 @@ def test_head_fwd_bwd(be, case):
     _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("ac", [0, 1])
+@pytest.mark.parametrize("case", [(1, 4, 5, 7, 16, 20, 28, 5.0), (2, 12, 6, 9, 48, 24, 36, 3.0), (1, 5, 4, 6, 17, 13, 22, 4.0),
+                                  (1, 1, 3, 1, 4, 9, 5, 2.0)])
+def test_head2_fwd_bwd(be, case, ac):
+    """Entry points with an explicit interpolation rule: align_corners=True is the PCWNet / CFNet head."""
+    B, Dc, Hc, Wc, D, H, W, gain = case
+    torch.manual_seed(3)
+    cost = (torch.randn(B, 1, Dc, Hc, Wc) * gain).requires_grad_()
+    ref = O.regression_head(cost, D, H, W, align_corners=bool(ac))
+    dcost = be.dev(cost.detach())
+    disp, stats = be.empty(B, H, W), be.empty(B, H, W, 2)
+    be.call("stx_head_fwd2", ptr(dcost), ptr(disp), ptr(stats), B, Dc, Hc, Wc, D, H, W, ac)
+    assert (disp.cpu() - ref.detach()).abs().max().item() < 1e-4
+    g = torch.randn(B, H, W)
+    ref.backward(g)
+    gc = be.empty(B, 1, Dc, Hc, Wc)
+    ws = be.empty(be.raw("stx_head_bwd_workspace_floats")(B, Dc, H, W))
+    be.call("stx_head_bwd2", ptr(be.dev(g)), ptr(dcost), ptr(disp), ptr(stats), ptr(gc), ptr(ws), B, Dc, Hc, Wc, D, H, W, ac)
+    _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
+
+
 def test_estimators(be):
     torch.manual_seed(4)
     x = torch.softmax(torch.randn(2, 16, 6, 10) * 3, 1)

@@ -433,6 +433,163 @@ def acvnet_forward(sd, left, right, maxdisp, attn_weights_only=False, freeze_att
 
 
 # ----------------------------------------------------------------------------- loss used by bench/tests
+# ----------------------------------------------------------------------------- PCWNet
+def mish(x):
+    """PCWNet/submodule.py:11-18,178-190: x * tanh(softplus(x))."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def _pcw_block(cx, x, p, stride, pad, dilation, has_down):
+    """PCWNet/submodule.py:192-215: BasicBlock with Mish after the first conv only."""
+    out = mish(convbn_2d(cx, x, p + ".conv1.0", stride, pad, dilation))
+    out = convbn_2d(cx, out, p + ".conv2", 1, pad, dilation)
+    if has_down:
+        x = convbn_2d(cx, x, p + ".downsample", stride, 0, 1)
+    return out + x
+
+
+def _pcw_layer(cx, x, p, blocks, stride, pad, dilation, has_down):
+    for i in range(blocks):
+        x = _pcw_block(cx, x, f"{p}.{i}", stride if i == 0 else 1, pad, dilation, has_down and i == 0)
+    return x
+
+
+def _pcw_head2d(cx, x, p):
+    """convbn(3x3) + Mish + 1x1 Conv2d (pcwnet.py:36-74)."""
+    return F.conv2d(mish(convbn_2d(cx, x, p + ".0", 1, 1, 1)), cx.sd[p + ".2.weight"])
+
+
+def features_pcw(cx, x, p="feature_extraction"):
+    """PCWNet/pcwnet.py:12-131 with concat_feature=True."""
+    x = mish(convbn_2d(cx, x, p + ".firstconv.0", 2, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".firstconv.2", 1, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".firstconv.4", 1, 1, 1))
+    x = _pcw_layer(cx, x, p + ".layer1", 3, 1, 1, 1, False)
+    l2 = _pcw_layer(cx, x, p + ".layer2", 16, 2, 1, 1, True)
+    l3 = _pcw_layer(cx, l2, p + ".layer3", 3, 1, 1, 1, True)
+    l4 = _pcw_layer(cx, l3, p + ".layer4", 3, 1, 1, 2, False)
+    l5 = _pcw_layer(cx, l4, p + ".layer5", 3, 2, 1, 1, True)
+    l6 = _pcw_layer(cx, l5, p + ".layer7", 3, 2, 1, 1, True)
+    l7 = _pcw_layer(cx, l6, p + ".layer9", 3, 2, 1, 1, True)
+    comb = torch.cat((l2, l3, l4), 1)
+    refine = mish(convbn_2d(cx, comb, p + ".layer_refine.0", 1, 1, 1))
+    refine = mish(convbn_2d(cx, refine, p + ".layer_refine.2", 1, 0, 1))
+    return {"gw1": _pcw_head2d(cx, comb, p + ".layer11"), "gw2": _pcw_head2d(cx, l5, p + ".gw2"),
+            "gw3": _pcw_head2d(cx, l6, p + ".gw3"), "gw4": _pcw_head2d(cx, l7, p + ".gw4"),
+            "concat_feature1": _pcw_head2d(cx, comb, p + ".lastconv"), "finetune_feature": refine,
+            "concat_feature2": _pcw_head2d(cx, l5, p + ".concat2"), "concat_feature3": _pcw_head2d(cx, l6, p + ".concat3"),
+            "concat_feature4": _pcw_head2d(cx, l7, p + ".concat4")}
+
+
+def hourglass_pcw(cx, x, p):
+    """PCWNet/pcwnet.py:211-252."""
+    c1 = mish(convbn_3d(cx, x, p + ".conv1.0", 2, 1))
+    c2 = mish(convbn_3d(cx, c1, p + ".conv2.0", 1, 1))
+    c3 = mish(convbn_3d(cx, c2, p + ".conv3.0", 2, 1))
+    c4 = mish(convbn_3d(cx, c3, p + ".conv4.0", 1, 1))
+    c5 = mish(deconvbn_3d(cx, c4, p + ".conv5") + convbn_3d(cx, c2, p + ".redir2", 1, 0))
+    return mish(deconvbn_3d(cx, c5, p + ".conv6") + convbn_3d(cx, x, p + ".redir1", 1, 0))
+
+
+def hourglassup_pcw(cx, x, f4, f5, f6, p):
+    """PCWNet/pcwnet.py:133-208."""
+    sd = cx.sd
+    c1 = F.conv3d(x, sd[p + ".conv1.weight"], None, 2, 1)
+    c1 = mish(convbn_3d(cx, torch.cat((c1, f4), 1), p + ".combine1.0", 1, 1))
+    c2 = mish(convbn_3d(cx, c1, p + ".conv2.0", 1, 1))
+    c3 = F.conv3d(c2, sd[p + ".conv3.weight"], None, 2, 1)
+    c3 = mish(convbn_3d(cx, torch.cat((c3, f5), 1), p + ".combine2.0", 1, 1))
+    c4 = mish(convbn_3d(cx, c3, p + ".conv4.0", 1, 1))
+    c5 = F.conv3d(c4, sd[p + ".conv5.weight"], None, 2, 1)
+    c5 = mish(convbn_3d(cx, torch.cat((c5, f6), 1), p + ".combine3.0", 1, 1))
+    c6 = mish(convbn_3d(cx, c5, p + ".conv6.0", 1, 1))
+    c7 = mish(deconvbn_3d(cx, c6, p + ".conv7") + convbn_3d(cx, c4, p + ".redir3", 1, 0))
+    c8 = mish(deconvbn_3d(cx, c7, p + ".conv8") + convbn_3d(cx, c2, p + ".redir2", 1, 0))
+    return mish(deconvbn_3d(cx, c8, p + ".conv9") + convbn_3d(cx, x, p + ".redir1", 1, 0))
+
+
+def pcw_correlation_volume(ref, tgt, maxdisp, num_groups):
+    """PCWNet/submodule.py:121-135 (`build_corrleation_volume`), literal semantics: slice i+maxdisp holds, for i >= 0,
+    the correlation of ref[w] with tgt[w-i] at w >= i; for i < 0 the FIRST |i| reference columns against the LAST |i|
+    target columns (the reference's `[..., :-i]` with negative i)."""
+    B, C, H, W = ref.shape
+    cpg = C // num_groups
+    vol = ref.new_zeros(B, num_groups, 2 * maxdisp + 1, H, W)
+    for i in range(-maxdisp, maxdisp + 1):
+        if i >= 0:
+            prod = ref[..., i:] * tgt[..., :W - i]
+            vol[:, :, i + maxdisp, :, i:] = prod.view(B, num_groups, cpg, H, W - i).mean(2)
+        else:
+            prod = ref[..., :-i] * tgt[..., W + i:]
+            vol[:, :, i + maxdisp, :, :-i] = prod.view(B, num_groups, cpg, H, -i).mean(2)
+    return vol
+
+
+def pcw_warp(x, disp):
+    """PCWNet/submodule.py:137-176: bilinear sampling of x at column w - disp (grid normalised with W-1/H-1, then
+    grid_sample's align_corners=False), zeroed where the sampling footprint left the image."""
+    B, C, H, W = x.shape
+    xx = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    yy = torch.arange(H, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
+    grid = torch.cat((2.0 * (xx - disp) / max(W - 1, 1) - 1.0, 2.0 * yy / max(H - 1, 1) - 1.0), 1).permute(0, 2, 3, 1)
+    out = F.grid_sample(x, grid, align_corners=False)
+    mask = F.grid_sample(torch.ones_like(x), grid, align_corners=False)
+    mask = torch.where(mask < 0.999, torch.zeros_like(mask), torch.ones_like(mask))
+    return out * mask
+
+
+def _pcw_refine(cx, x, disp, p="refinenet3"):
+    """PCWNet/pcwnet.py:254-308."""
+    x = mish(convbn_2d(cx, x, p + ".conv1.0", 1, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".conv2.0", 1, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".conv3.0", 1, 2, 2))
+    x = mish(convbn_2d(cx, x, p + ".conv4.0", 1, 4, 4))
+    x = _pcw_block(cx, x, p + ".conv5.0", 1, 1, 8, True)
+    x = _pcw_block(cx, x, p + ".conv6.0", 1, 1, 16, True)
+    x = _pcw_block(cx, x, p + ".conv7.0", 1, 1, 1, True)
+    return disp + F.conv2d(x, cx.sd[p + ".conv8.weight"], None, 1, 1)
+
+
+def pcwnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):
+    """PCWNet/pcwnet.py:384-511 (PCWNet_GC).  train: [pred0, combine, pred1, pred2, pred3, disp_finetune]."""
+    cx = Ctx(sd, training)
+    fl, fr = features_pcw(cx, left), features_pcw(cx, right)
+    vols = []
+    for k, div in ((1, 4), (2, 8), (3, 16), (4, 32)):
+        g = build_gwc_volume(fl[f"gw{k}"], fr[f"gw{k}"], maxdisp // div, 40)
+        c = build_concat_volume(fl[f"concat_feature{k}"], fr[f"concat_feature{k}"], maxdisp // div)
+        vols.append(torch.cat((g, c), 1))
+    x = mish(convbn_3d(cx, vols[0], "dres0.0"))
+    cost0 = mish(convbn_3d(cx, x, "dres0.2"))
+    cost0 = convbn_3d(cx, mish(convbn_3d(cx, cost0, "dres1.0")), "dres1.2") + cost0
+    combine = hourglassup_pcw(cx, cost0, vols[1], vols[2], vols[3], "combine1")
+    out1 = hourglass_pcw(cx, combine, "dres2")
+    out2 = hourglass_pcw(cx, out1, "dres3")
+    out3 = hourglass_pcw(cx, out2, "dres4")
+    H, W = left.shape[2], left.shape[3]
+
+    def head(xx, p):
+        c = F.conv3d(mish(convbn_3d(cx, xx, p + ".0")), sd[p + ".2.weight"], None, 1, 1)
+        return regression_head(c, maxdisp, H, W, align_corners=True)
+
+    preds = None
+    if training:        # the reference evaluates classif0..3 then classif4 (BN running-stat order is irrelevant: distinct layers)
+        preds = [head(cost0, "classif0"), head(out1, "classif1"), head(out2, "classif2")]
+    pred3 = head(out3, "classif3")
+    comb_pred = head(combine, "classif4") if training else None
+    p3 = pred3.unsqueeze(1)
+    rl = F.interpolate(fl["finetune_feature"], [H, W], mode="bilinear", align_corners=True)
+    rr = F.interpolate(fr["finetune_feature"], [H, W], mode="bilinear", align_corners=True)
+    rw = pcw_warp(rr, p3)
+    corr = pcw_correlation_volume(rl, rw, 24, 1).squeeze(1)
+    up = mish(convbn_2d(cx, p3, "dispupsample.0", 1, 0, 1))
+    fine = _pcw_refine(cx, torch.cat((rl - rw, rl, up, p3, corr), 1), p3).squeeze(1)
+    if training:
+        out = [preds[0], comb_pred, preds[1], preds[2], pred3, fine]
+        return (out, cx) if return_ctx else out
+    return (fine, cx) if return_ctx else fine
+
+
 def smooth_l1_multi(preds, gt, maxdisp, weights):
     """Supervised loss for the train step (the reference ships none for these models; weights
     follow the GwcNet paper).  Valid mask: trainer/trainer_torchrun.py:272."""

@@ -129,6 +129,24 @@ def deconv3d_forward(x, wp, Cout, out_dims=None, scale=None, bias=None, residual
     _chk(x, "x", 5)
     B, D, H, W, Cin = x.shape
     Do, Ho, Wo = out_dims if out_dims is not None else (2 * D, 2 * H, 2 * W)
+    if Cout > 64:
+        # The transposed-conv kernel keeps 4 parity-class accumulators per 32-column block and is instantiated for
+        # N <= 64.  Wider outputs (PCWNet: ConvTranspose3d(128, 128), dgrad of Conv3d(128, 128, s2)) run as 64-channel
+        # slices of the packed weights [tap][K/8][N/32][256] and are concatenated (small 1/16-1/32-resolution volumes).
+        if Cout % 64 != 0:
+            raise StxError(f"deconv3d_forward: Cout={Cout} > 64 must be a multiple of 64")
+        nt = Cout // 32
+        wv = wp.view(-1, Cin // 8, nt, 256)
+        outs, sts = [], []
+        for h in range(Cout // 64):
+            sl = slice(64 * h, 64 * h + 64)
+            o, st_ = deconv3d_forward(x, wv[:, :, 2 * h:2 * h + 2].contiguous(), 64, (Do, Ho, Wo),
+                                      None if scale is None else scale[sl].contiguous(),
+                                      None if bias is None else bias[sl].contiguous(),
+                                      None if residual is None else residual[..., sl].contiguous(), relu, want_stats)
+            outs.append(o)
+            sts.append(st_)
+        return torch.cat(outs, -1), (torch.cat(sts, -1) if want_stats else None)
     out = torch.empty(B, Do, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
@@ -228,6 +246,15 @@ class ConvRawFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 if c1:                    # classifier tail Conv3d(32 -> 1): streaming VALU kernel
                     gx = conv3d_c1_dgrad(gz, w.contiguous(), Ci)
+                elif stride == 1 and Ci > 128:
+                    # the conv kernels produce at most 128 output channels per launch: wide inputs (PCWNet's 192-channel
+                    # fusion convs) get their gradient in slices of the weight's input-channel axis
+                    parts = []
+                    for lo in range(0, Ci, 128):
+                        hi = min(Ci, lo + 128)
+                        g, _ = conv3d_forward(gz_k, pack_weight(w_k[:, lo:hi].contiguous(), 1), hi - lo, ks, 1)
+                        parts.append(g)
+                    gx = torch.cat(parts, -1)
                 elif stride == 1:
                     gx, _ = conv3d_forward(gz_k, pack_weight(w_k, 1), Ci, ks, 1)
                 else:                     # stride-2 dgrad = transposed conv of gz

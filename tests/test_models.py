@@ -396,3 +396,64 @@ def test_acvnet_frozen_attention_train(env):
     assert m.dres1_att_[0][0].weight.grad is None and ref_sd["dres1_att_.0.0.weight"].grad is None
     g, r = m.dres0[0][0].weight.grad.cpu(), ref_sd["dres0.0.0.weight"].grad
     assert (g - r).abs().max().item() < 2e-2 * r.abs().max().item()
+
+
+# ------------------------------------------------------------------------------ PCWNet
+# Emulator-only this round: the family went in after the round's GPU budget was spent; its GPU parity tests and timings
+# are the first item of the next round (the kernels it runs on are the GPU-validated ones of GwcNet plus Mish and the
+# align_corners=True head, which have their own kernel-level tests in test_kernels.py).
+def test_pcwnet_gc_eval_parity_emu():
+    from tests.emu_util import emu_product_path
+    from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
+    D = 64
+    m, sd = _filled(PCWNet_GC, D)
+    m.eval()
+    left, right = synthetic_tensor((1, 3, 32, 64), 1), synthetic_tensor((1, 3, 32, 64), 2)
+    with torch.no_grad(), emu_product_path():
+        got = m(left, right)
+    ref = O.pcwnet_forward(sd, left, right, D)
+    assert got.shape == (1, 32, 64)
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+def test_pcwnet_hourglassup_train_emu():
+    """The multi-scale fusion block in train mode (batch-stat BN, Mish, plain strided convs, 192-channel fusion convs,
+    128-channel transposed convs): output, input gradients (x and the three injected volumes), weight gradients."""
+    from tests.emu_util import emu_product_path
+    from stereo_toolbox_amd.models.PCWNet.pcwnet import hourglassup
+    up = hourglassup(32)
+    usd = up.state_dict()
+    fill_state_dict(usd, seed=77)
+    up.load_state_dict(usd)
+    up.train()
+    shapes = ((1, 32, 16, 16, 32), (1, 64, 8, 8, 16), (1, 64, 4, 4, 8), (1, 64, 2, 2, 4))
+    ins = [synthetic_tensor(s, 31 + i) for i, s in enumerate(shapes)]
+    nd = [t.permute(0, 2, 3, 4, 1).contiguous().requires_grad_() for t in ins]
+    with emu_product_path():
+        y = up(*nd)
+        g = synthetic_tensor((1, 32, 16, 16, 32), 35)
+        y.backward(g.permute(0, 2, 3, 4, 1).contiguous())
+    rsd = {"up." + k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in usd.items()}
+    rin = [t.clone().requires_grad_() for t in ins]
+    ry = O.hourglassup_pcw(O.Ctx(rsd, True), *rin, "up")
+    ry.backward(g)
+    # fp64 run of the oracle calibrates what fp32 rounding does to this (batch-stat BN) block
+    dsd = {k: (v.detach().double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in rsd.items()}
+    din = [t.detach().double().requires_grad_() for t in ins]
+    dy = O.hourglassup_pcw(O.Ctx(dsd, True), *din, "up")
+    dy.backward(g.double())
+
+    def check(prod, ref32, ref64, what, floor):
+        e_p = (prod.double() - ref64).abs().max().item()
+        e_o = (ref32.double() - ref64).abs().max().item()
+        scale = ref64.abs().max().item() + 1e-12
+        assert e_p <= max(20 * e_o, floor * scale), f"{what}: {e_p:.3e} vs oracle {e_o:.3e} (scale {scale:.3e})"
+
+    check(y.detach().permute(0, 4, 1, 2, 3), ry.detach(), dy.detach(), "output", 1e-4)
+    for i in range(4):
+        check(nd[i].grad.permute(0, 4, 1, 2, 3), rin[i].grad, din[i].grad, f"input grad {i}", 2e-3)
+    n = 0
+    for k, p in up.named_parameters():
+        check(p.grad, rsd["up." + k].grad, dsd["up." + k].grad, k, 2e-3)
+        n += 1
+    assert n == 39

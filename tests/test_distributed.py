@@ -51,7 +51,8 @@ def _worker(rank, world, port, q):
         assert sync.views_intact()
         w = sync.all_reduce(async_op=True)
         w.wait()
-    q.put((rank, sync.flat.clone(), [p.detach().clone() for p in model.parameters()]))
+    # numpy arrays are pickled by value (torch tensors travel as shared-memory handles that die with the worker)
+    q.put((rank, sync.flat.detach().numpy().copy(), [p.detach().numpy().copy() for p in model.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,6 +68,7 @@ def test_flat_grad_sync_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = [(r[0], torch.from_numpy(r[1]), [torch.from_numpy(a) for a in r[2]]) for r in res]
     # both ranks hold identical averaged gradients and identical (broadcast) parameters
     assert torch.equal(res[0][1], res[1][1])
     for a, b in zip(res[0][2], res[1][2]):

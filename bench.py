@@ -31,16 +31,9 @@ LOSS_W = (0.5, 0.5, 0.7, 1.0)      # GwcNet paper weights (the reference ships n
 
 
 def smooth_l1_multi(preds, gt, maxdisp):
-    """sum_i w_i * mean over valid pixels of smooth_l1(pred_i, gt).  Same value as indexing with the
-    boolean mask (`pred[mask]`, reference trainer/trainer_torchrun.py:272-284), but written with a
-    multiply/sum so that no device->host synchronisation (dynamic-shape nonzero) sits in the step."""
-    import torch.nn.functional as F
-    mask = ((gt > 0) & (gt < maxdisp - 1)).to(gt.dtype)
-    inv = 1.0 / mask.sum().clamp_min(1.0)
-    loss = 0.0
-    for p, w in zip(preds, LOSS_W):
-        loss = loss + w * (F.smooth_l1_loss(p, gt, reduction="none") * mask).sum() * inv
-    return loss
+    """The sync-free masked multi-output loss of the package (stereo_toolbox_amd/losses.py) with the GwcNet weights."""
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    return masked_smooth_l1_multi(preds, gt, maxdisp, LOSS_W)
 
 
 class KernelTimer:

@@ -64,3 +64,17 @@ def test_metrics_match_reference_loops():
     assert abs(out["occ"][2] - ref_gen[1]) < 1e-4
     assert abs(out["noc"][2] - ref_gen[2]) < 1e-4
     assert abs(out["all"][2] - ref_gen[3]) < 1e-4
+
+
+def test_masked_loss_equals_boolean_indexing():
+    """losses.masked_smooth_l1_multi == the reference-style `pred[mask]` formulation (oracle.smooth_l1_multi)."""
+    from oracle import torch_oracle as O
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    torch.manual_seed(2)
+    gt = torch.rand(2, 9, 14) * 80 - 5
+    preds = [gt + torch.randn(2, 9, 14) * s for s in (3.0, 2.0, 1.0, 0.5)]
+    preds[1] = preds[1].unsqueeze(1)
+    w = (0.5, 0.5, 0.7, 1.0)
+    a = masked_smooth_l1_multi(preds, gt, 64, w)
+    b = O.smooth_l1_multi(preds, gt, 64, w)
+    assert abs(a.item() - b.item()) < 1e-5 * abs(b.item())

@@ -457,3 +457,53 @@ def test_pcwnet_hourglassup_train_emu():
         check(p.grad, rsd["up." + k].grad, dsd["up." + k].grad, k, 2e-3)
         n += 1
     assert n == 39
+
+
+_PCW_GPU = pytest.mark.skipif(__import__("os").environ.get("STX_TEST_PCWNET_GPU") != "1",
+                              reason="PCWNet has not had its first GPU run yet (round-1 GPU minutes were spent before it "
+                                     "went in); set STX_TEST_PCWNET_GPU=1 to run")
+
+
+@pytest.mark.gpu
+@_PCW_GPU
+def test_pcwnet_gc_eval_parity_gpu():
+    from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
+    D = 64
+    m, sd = _filled(PCWNet_GC, D)
+    dev = torch.device("cuda:0")
+    m = m.to(dev).eval()
+    left, right = synthetic_tensor((2, 3, 64, 128), 1), synthetic_tensor((2, 3, 64, 128), 2)
+    with torch.no_grad():
+        got = m(left.to(dev), right.to(dev)).cpu()
+    ref = O.pcwnet_forward(sd, left, right, D)
+    assert (got - ref).abs().max().item() < 1e-3
+
+
+@pytest.mark.gpu
+@_PCW_GPU
+def test_pcwnet_gc_train_step_gpu():
+    """6 predictions, loss and every parameter gradient against the fp64-calibrated oracle (as for GwcNet_GC)."""
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
+    D, w = 64, (0.5, 0.5, 0.5, 0.7, 1.0, 1.3)
+    m, sd = _filled(PCWNet_GC, D)
+    dev = torch.device("cuda:0")
+    m = m.to(dev).train()
+    left, right = synthetic_tensor((2, 3, 128, 256), 1), synthetic_tensor((2, 3, 128, 256), 2)
+    gt = synthetic_tensor((2, 128, 256), 3, lo=0.0, hi=float(D - 2))
+    preds = m(left.to(dev), right.to(dev))
+    loss = masked_smooth_l1_multi(preds, gt.to(dev), D, w)
+    loss.backward()
+    assert len(preds) == 6
+    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    rp64 = O.pcwnet_forward(sd64, left.double(), right.double(), D, training=True)
+    O.smooth_l1_multi(rp64, gt.double(), D, w).backward()
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    rp = O.pcwnet_forward(ref_sd, left, right, D, training=True)
+    O.smooth_l1_multi(rp, gt, D, w).backward()
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
+        assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
+    n, _ = _check_grads(m, ref_sd, sd64)
+    assert n > 400

@@ -183,6 +183,16 @@ def main():
                                      a.H, a.W, stream()), it)
         report("head_bwd", ms, nbytes=(cost.numel() * 2 + disp.numel() * 4) * 4)
 
+    if want("mish"):
+        D0, H0, W0 = L[0]
+        x = torch.randn(B, D0, H0, W0, 32, device=dev)
+        y, g = torch.empty_like(x), torch.randn(B, D0, H0, W0, 32, device=dev)
+        ms = timeit(lambda: lib.call("stx_mish_fwd", P(x), P(y), x.numel(), stream()), it)
+        report("mish_fwd_L0", ms, nbytes=x.numel() * 8)
+        ms = timeit(lambda: lib.call("stx_mish_bwd", P(g), P(x), P(y), x.numel(), stream()), it)
+        report("mish_bwd_L0", ms, nbytes=x.numel() * 12)
+        del x, y, g
+
     if want("estimator"):
         # full-resolution probability volume [B,192,H,W] (425 MB): two Gaussian modes per pixel + rough floor
         d = torch.arange(a.D, device=dev, dtype=torch.float32).view(1, a.D, 1, 1)

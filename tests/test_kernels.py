@@ -354,6 +354,30 @@ def test_mish(be):
     _close(gx, xr.grad, rtol=1e-5, atol=1e-6)
 
 
+def test_modal_estimators_edge_cases(be):
+    """Degenerate volumes: flat, one-hot at either end (a one-hot 1.0 in the last bin has no rising edge to its right, the
+    support is empty and the reference returns 0/0 = NaN), a plateau around the maximum, zeros."""
+    D = 12
+    x = torch.zeros(6, D, 1, 4)
+    x[0] = 1.0 / D                                   # flat
+    x[1, 0] = 1.0                                    # one-hot at d = 0
+    x[2, D - 1] = 1.0                                # one-hot at d = D-1 -> NaN
+    x[3, 4:7] = 1.0 / 3                              # plateau (arg-max = first of the plateau)
+    x[4, 2], x[4, 9] = 0.6, 0.4                      # two spikes
+    x[5] = 0.0                                       # all zeros -> NaN
+    x = x + torch.linspace(0, 1e-6, 4).view(1, 1, 1, 4) * (x > 0)      # distinct pixels
+    d = be.dev(x)
+    for entry, ref in (("stx_unimodal_fwd", O.unimodal_disparity_estimator),
+                       ("stx_dominant_modal_fwd", O.dominant_modal_disparity_estimator)):
+        o = be.empty(6, 4)
+        be.call(entry, ptr(d), ptr(o), 6, D, 4)
+        want = ref(x, D).reshape(6, 4)
+        got = o.cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), (entry, got, want)
+        ok = ~torch.isnan(want)
+        assert (got[ok] - want[ok]).abs().max().item() < 1e-5, (entry, got, want)
+
+
 # ------------------------------------------------------------------------------ ACVNet extras
 def test_dwconv_hw_fwd_bwd(be):
     """Depth-wise (1,3,3) patch convolutions with per-channel dilation (acv.py:109-112,183-187)."""

@@ -2,21 +2,33 @@
 """Headline benchmark (BASELINE.json): stereo pairs/s of one GwcNet_GC train step (fwd + bwd +
 gradient all-reduce + optimizer) on synthetic 540x960 SceneFlow-shape pairs, D=192, fp32.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W [--config gwc_train|acv_train|kitti_infer|psm_volume]
 
-Shapes: the reference pads 540x960 to 576x960 (`pad_to_2x`, datasets/data_augmentation/__init__.py:57-80);
-throughput is counted per original pair.  One rank per GPU, per-GPU batch fixed (weak scaling),
-gradients averaged with one RCCL all-reduce over a flat bucket.
+Launch.  One rank per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks come
+from the environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Started plainly with `--gpus N` (N > 1,
+no WORLD_SIZE in the environment) bench.py re-executes itself through torch.distributed.run with N ranks
+on 127.0.0.1 (reference: `torchrun --nproc_per_node=N`, trainer/trainer_torchrun.py:31-38,67-83); it refuses
+to run when fewer than N devices are visible or when WORLD_SIZE disagrees with --gpus.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the 3x3x3 stride-1 32->32 fp32-MFMA
-implicit-GEMM Conv3d `conv3d_march_kernel<1,16,2>`; achieved = algorithmic FLOPs of its launches / their HIP-event time inside the
-timed region) and `cpu_baseline` (the CPU oracle -- a torch-op restatement of the reference -- timed on
-this box's host cores on a bounded sample; baseline only).
+Configs (BASELINE.json `configs`):
+  gwc_train    [2] GwcNet_GC(192) train step, 576x960 (= 540x960 after the reference's pad_to_2x,
+                   datasets/data_augmentation/__init__.py:57-80), batch 1/GPU            <- the headline metric
+  acv_train    [3] ACVNet(192) train step, 576x960, batch 2/GPU (global batch 16 on 8 GPUs)
+  kitti_infer  [4] GwcNet_GC(192) inference, 384x1248 (= 375x1242 padded), batch-parallel (one pair per rank per step)
+  psm_volume   [1] PSMNet concat cost volume 576x960 D=192 forward only (HBM roofline)
+Per-GPU work is fixed (weak scaling); gradients are averaged over ranks through one flat fp32 buffer
+(stereo_toolbox_amd/distributed.py), by default in 2 ranges that overlap with the backward pass.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel of the config; achieved = algorithmic FLOPs or
+bytes of its launches / their HIP-event time inside the timed region, on the launching stream) and, at N=1,
+`cpu_baseline` (the CPU oracle -- a torch-op restatement of the reference -- on this box's host cores, bounded
+sample, warm-up + 2 timed runs; baseline only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +39,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md
-LOSS_W = (0.5, 0.5, 0.7, 1.0)      # GwcNet paper weights (the reference ships no supervised loss)
+PEAK_HBM_GBS = 8000.0              # same guide (spec; a float4 copy reaches 6.29 TB/s)
+LOSS_W = (0.5, 0.5, 0.7, 1.0)      # GwcNet paper weights (the reference ships no supervised loss); ACVNet: 4 outputs too
+
+CONFIGS = {
+    #               model        mode     H     W   batch  metric
+    "gwc_train":   ("GwcNet_GC", "train", 576, 960, 1, "stereo pairs/sec @ 540x960 D=192 (GwcNet_GC fwd+bwd)"),
+    "acv_train":   ("ACVNet", "train", 576, 960, 2, "stereo pairs/sec @ 540x960 D=192 (ACVNet fwd+bwd)"),
+    "kitti_infer": ("GwcNet_GC", "eval", 384, 1248, 1, "stereo pairs/sec @ 1242x375 D=192 (GwcNet_GC inference)"),
+    "psm_volume":  ("PSMNet concat volume", "volume", 576, 960, 1, "cost volumes/sec @ 540x960 D=192 (PSMNet concat volume fwd)"),
+}
 
 
 def smooth_l1_multi(preds, gt, maxdisp):
@@ -37,44 +58,68 @@ def smooth_l1_multi(preds, gt, maxdisp):
 
 
 class KernelTimer:
-    """HIP-event timing of selected C-ABI launches on the stream they are issued on."""
+    """HIP-event timing of selected C-ABI launches on the stream they are issued on (torch's current stream is the
+    stream every stx_* entry point is given, stereo_toolbox_amd/ops.py:_stream)."""
 
     def __init__(self):
         self.records = []
         self.enabled = False
 
-    def install(self):
-        from stereo_toolbox_amd import ops
-        orig = ops.conv3d_forward
+    def _timed(self, orig, units):
         timer = self
 
-        def timed(x, wp, Cout, ks, stride, *a, **k):
-            if not (timer.enabled and ks == 3 and stride == 1 and Cout <= 32 and x.shape[-1] == 32):
-                return orig(x, wp, Cout, ks, stride, *a, **k)
+        def wrapper(*a, **k):
+            u = units(*a, **k) if timer.enabled else None
+            if u is None:
+                return orig(*a, **k)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = orig(x, wp, Cout, ks, stride, *a, **k)
+            out = orig(*a, **k)
             e1.record()
-            B, D, H, W, Cin = x.shape
-            timer.records.append((e0, e1, 2.0 * B * D * H * W * Cout * Cin * 27))
+            timer.records.append((e0, e1, u))
             return out
-        ops.conv3d_forward = timed
+        return wrapper
+
+    def install_conv(self):
+        """3x3x3 stride-1 Conv3d with Cin = 32, Cout <= 32: the launches served by conv3d_march_kernel<1,*,2>."""
+        from stereo_toolbox_amd import ops
+
+        def units(x, wp, Cout, ks, stride, *a, **k):
+            if not (ks == 3 and stride == 1 and Cout <= 32 and x.shape[-1] == 32):
+                return None
+            B, D, H, W, Cin = x.shape
+            return 2.0 * B * D * H * W * Cout * Cin * 27
+        ops.conv3d_forward = self._timed(ops.conv3d_forward, units)
+
+    def install_volume(self):
+        from stereo_toolbox_amd import ops
+
+        def units(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True, scale=None):
+            n = 0
+            for t in (Lg, Rg, Lc, Rc, scale):
+                n += 0 if t is None else t.numel() * 4
+            ref = Lg if Lg is not None else Lc
+            B, _, H, W = ref.shape
+            G = num_groups if Lg is not None else 0
+            Cc = Lc.shape[1] if Lc is not None else 0
+            return float(n + B * maxdisp * H * W * (G + 2 * Cc) * 4)
+        ops.cost_volume_forward = self._timed(ops.cost_volume_forward, units)
 
     def summary(self):
         if not self.records:
             return None
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
-        return {"launches": len(self.records), "ms_total": ms, "flops_total": fl}
+        un = sum(u for _, _, u in self.records)
+        return {"launches": len(self.records), "ms_total": ms, "units_total": un}
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate passes, KB per dispatch; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    gfx950).  Counters cannot be collected inside this process, so this is the figure of the profiled session of the
-    same kernel, or None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_conv3d_march.txt")
+def committed_pmc_traffic(fname):
+    """HBM bytes per launch of the dominant kernel from a COMMITTED rocprofv3 PMC summary under profiles/
+    (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, KB per dispatch; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: this is a constant
+    of the profiled session of the same kernel (named in `traffic_source`), not a measurement of this run."""
+    path = os.path.join(ROOT, "profiles", fname)
     try:
         vals = {}
         with open(path) as f:
@@ -87,87 +132,204 @@ def pmc_traffic_bytes():
         return None
 
 
-def cpu_baseline(maxdisp):
-    """Oracle (torch-op restatement of the reference path) fwd+bwd on the host cores, bounded sample."""
+def first_existing(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, "profiles", n)):
+            return n
+    return names[-1]
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, maxdisp):
+    """Oracle (torch-op restatement of the reference path) on the host cores: 1 warm-up + 2 timed runs of a BOUNDED
+    sample of the config's workload.  `value` extrapolates the sample to the config's shape by voxel count and says
+    so (`extrapolated`); `sample_s` are the measured times."""
     from oracle import torch_oracle as O
-    from stereo_toolbox_amd.models import GwcNet_GC
+    from stereo_toolbox_amd import models
     from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
-    H, W = 288, 480                                 # 1/4 of the 576x960 pixels
-    m = GwcNet_GC(maxdisp)
-    sd = m.state_dict()
-    fill_state_dict(sd)
-    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
-    left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
-    gt = synthetic_tensor((1, H, W), 3, lo=0.0, hi=190.0)
-    t0 = time.time()
-    preds = O.gwcnet_forward(sd, left, right, maxdisp, True, training=True)
-    O.smooth_l1_multi(preds, gt, maxdisp, LOSS_W).backward()
-    dt = time.time() - t0
-    frac = (H * W) / (576.0 * 960.0)
-    return {"value": round(frac / dt, 5), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle GwcNet_GC fwd+bwd, 1 pair at {H}x{W} D={maxdisp} ({dt:.1f} s), scaled by pixel ratio "
-                      f"{frac:.3f} to the 576x960 pair"}
+    model_name, mode, Hc, Wc, _, _ = CONFIGS[cfg]
+    threads = torch.get_num_threads()
+    if mode == "volume":
+        H, W = Hc // 4, Wc // 4
+        L, R = synthetic_tensor((1, 32, H, W), 1), synthetic_tensor((1, 32, H, W), 2)
+
+        def run():
+            O.build_concat_volume(L, R, maxdisp // 4)
+        frac, what = 1.0, f"oracle build_concat_volume (PSM semantics), features 1x32x{H}x{W}, D'={maxdisp // 4}"
+    else:
+        H, W = (192, 480) if mode == "train" else (Hc // 2, Wc // 2)
+        ctor = getattr(models, model_name)
+        sd = ctor(maxdisp).state_dict()
+        fill_state_dict(sd)
+        left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
+        gt = synthetic_tensor((1, H, W), 3, lo=0.0, hi=190.0)
+        fwd = O.acvnet_forward if model_name == "ACVNet" else (lambda s, l, r, d, **k: O.gwcnet_forward(s, l, r, d, True, **k))
+
+        def run():
+            if mode == "train":
+                s = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+                O.smooth_l1_multi(fwd(s, left, right, maxdisp, training=True), gt, maxdisp, LOSS_W).backward()
+            else:
+                with torch.no_grad():
+                    fwd(sd, left, right, maxdisp)
+        frac = (H * W) / float(Hc * Wc)
+        what = (f"oracle {model_name} {'fwd+bwd' if mode == 'train' else 'eval fwd'}, 1 pair at {H}x{W} D={maxdisp}")
+    run()                                              # warm-up (thread pool, oneDNN primitive caches)
+    times = []
+    for _ in range(2):
+        t0 = time.time()
+        run()
+        times.append(time.time() - t0)
+    dt = min(times)
+    return {"value": round(frac / dt, 5), "unit": "pairs/s" if mode != "volume" else "volumes/s", "cores": threads,
+            "cpu_model": cpu_model_name(), "kind": "port", "extrapolated": frac != 1.0,
+            "sample_s": [round(t, 2) for t in times],
+            "sample": f"{what}; 1 warm-up + 2 timed runs (best {dt:.2f} s)"
+                      + ("" if frac == 1.0 else f"; value = measured rate x pixel ratio {frac:.4f} to the {Hc}x{Wc} pair "
+                                                "(an extrapolation, not a measurement of the full shape)")}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU")
-    ap.add_argument("--height", type=int, default=576)
-    ap.add_argument("--width", type=int, default=960)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="gwc_train")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--maxdisp", type=int, default=192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--buckets", type=int, default=2, help="ranges of the flat gradient buffer (overlapped all-reduce)")
+    ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after backward() instead")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+bwd+all-reduce+Adam) in one hipGraph and replay it")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def emulated():
+    """STX_BENCH_EMU=1 (tests only): run the product host code on CPU tensors against the host-emulator build of the
+    kernels with the gloo backend, so that the N > 1 launch path of this file is covered without GPUs."""
+    return os.environ.get("STX_BENCH_EMU") == "1"
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a torchrun environment: become the launcher."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not emulated() and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} ROCm device(s) visible on this node; refusing to run "
+                         f"{args.gpus} ranks (one process per GPU, no oversubscription)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this host driver)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_spawn(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus})")
+    emu = emulated()
+    if emu:
+        from tests.emu_util import emu_product_path
+        emu_product_path().__enter__()
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} device(s) visible")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
+
+    from stereo_toolbox_amd import models, ops
     from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
-    from stereo_toolbox_amd.models import GwcNet_GC
     from stereo_toolbox_amd.utils import fill_state_dict
 
+    model_name, mode, H, W, B, metric = CONFIGS[args.config]
+    H, W, B = args.height or H, args.width or W, args.batch or B
+    D = args.maxdisp
     torch.backends.cudnn.benchmark = True
-    model = GwcNet_GC(args.maxdisp)
-    sd = model.state_dict()
-    fill_state_dict(sd)
-    model.load_state_dict(sd)
-    model = model.to(dev).train()
-    broadcast_parameters(model)
-    sync = FlatGradSync(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
-
     g = torch.Generator(device=dev)
-    g.manual_seed(1000 + rank)
-    B, H, W = args.batch, args.height, args.width
-    left = torch.randn(B, 3, H, W, device=dev, generator=g)
-    right = torch.randn(B, 3, H, W, device=dev, generator=g)
-    gt = 190.0 * torch.rand(B, H, W, device=dev, generator=g)
-
+    g.manual_seed(1000 + rank)                     # every rank draws its own shard (trainer_torchrun.py:88)
     timer = KernelTimer()
-    timer.install()
 
-    def step():
-        sync.detach_grads()
-        preds = model(left, right)
-        loss = smooth_l1_multi(preds, gt, args.maxdisp)
-        loss.backward()
-        sync.pack()
-        sync.all_reduce()
-        opt.step()
+    if mode == "volume":
+        L = torch.randn(B, 32, H // 4, W // 4, device=dev, generator=g)
+        R = torch.randn(B, 32, H // 4, W // 4, device=dev, generator=g)
+        timer.install_volume()
 
-    if args.graph:
+        def step():
+            return ops.cost_volume(None, None, L, R, D // 4, 0, mask_left=True)
+    else:
+        model = getattr(models, model_name)(D)
+        sd = model.state_dict()
+        fill_state_dict(sd)
+        model.load_state_dict(sd)
+        model = model.to(dev)
+        broadcast_parameters(model)
+        left = torch.randn(B, 3, H, W, device=dev, generator=g)
+        right = torch.randn(B, 3, H, W, device=dev, generator=g)
+        timer.install_conv()
+        if mode == "train":
+            model.train()
+            overlap = not args.no_overlap and not args.graph
+            gsync = FlatGradSync(model, buckets=args.buckets if overlap else 1, overlap=overlap)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
+            gt = 190.0 * torch.rand(B, H, W, device=dev, generator=g)
+
+            def step():
+                gsync.detach_grads()
+                preds = model(left, right)
+                loss = smooth_l1_multi(preds, gt, D)
+                loss.backward()
+                gsync.finish()
+                opt.step()
+        else:
+            model.eval()
+
+            def step():
+                with torch.no_grad():
+                    return model(left, right)
+
+    if args.graph and mode == "train":
         # hipGraph path: warm up on a side stream (MIOpen search, workspaces), then capture one step.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -177,21 +339,20 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        sync.detach_grads()
+        gsync.detach_grads()
         with torch.cuda.graph(graph):
             step()
-        eager_step = step
         step = graph.replay            # noqa: F811
     for _ in range(args.warmup):
         step()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = not args.graph   # per-launch HIP events cannot be recorded inside a replayed graph
+    sync()
+    timer.enabled = not (args.graph or emu)   # per-launch HIP events cannot be recorded inside a replayed graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -204,19 +365,34 @@ def main():
     if rank == 0:
         ks = timer.summary()
         roof = None
-        if ks:
-            ach = ks["flops_total"] / (ks["ms_total"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3d_march_kernel<1,16,2> (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA)",
-                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
-                    "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate "
-                                    "passes (profiles/r01_pmc_conv3d_march.txt); algorithmic 424 MB",
+        if ks and mode == "volume":
+            ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e9
+            src = first_existing("r02_pmc_cost_volume_fwd_psm.txt", "r02_pmc_cost_volume_fwd.txt")
+            roof = {"bound": "hbm", "kernel": "cost_volume_fwd (PSMNet concat volume, fp32 copy/shift/mask)",
+                    "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+                    "traffic": committed_pmc_traffic(src), "traffic_source": f"profiles/{src} (committed PMC summary of an "
+                    "earlier profiled session of this kernel; constant, not measured by this run)",
+                    "algorithmic_bytes_per_launch": int(ks["units_total"] / ks["launches"]),
                     "launches_per_step": ks["launches"] // max(1, args.steps),
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
+        elif ks:
+            ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e12
+            src = first_existing("r02_pmc_conv3d_march.txt", "r01_pmc_conv3d_march.txt")
+            roof = {"bound": "mfma", "kernel": "conv3d_march_kernel<1,*,2> (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA)",
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": committed_pmc_traffic(src),
+                    "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
+                                      "576x960 launch; a committed-profile constant of the same kernel, not measured by this "
+                                      "run (algorithmic: 424 MB)",
+                    "launches_per_step": ks["launches"] // max(1, args.steps),
+                    "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
+        work = {"train": f"{model_name}(maxdisp={D}) train step: fwd+bwd+allreduce+Adam",
+                "eval": f"{model_name}(maxdisp={D}) inference (eval forward, no_grad), batch-parallel",
+                "volume": f"build_concat_volume (PSMNet semantics) features {B}x32x{H // 4}x{W // 4}, D'={D // 4}, fwd only"}[mode]
         out = {
-            "metric": "stereo pairs/sec @ 540x960 D=192 (GwcNet_GC fwd+bwd)",
+            "metric": metric,
             "value": round(world * B * args.steps / dt, 4),
-            "unit": "pairs/s",
+            "unit": "pairs/s" if mode != "volume" else "volumes/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -226,15 +402,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GwcNet_GC(maxdisp={args.maxdisp}) train step: fwd+bwd+allreduce+Adam, "
-                                   f"{H}x{W} (540x960 padded by pad_to_2x) pairs, batch {B}/GPU, fp32, "
+            "config": {"name": args.config,
+                       "workload": f"{work}, {H}x{W} pairs (reference pad_to_2x shape), batch {B}/GPU, fp32, "
                                    "synthetic randn inputs, deterministic filler weights",
                        "global_batch": world * B, "parallelism": f"dp{world}",
+                       "grad_sync": (f"flat fp32 buffer, {args.buckets} overlapped all-reduce range(s)"
+                                     if mode == "train" and not (args.no_overlap or args.graph) else
+                                     ("flat fp32 buffer, 1 all-reduce after backward" if mode == "train" else "none")),
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.maxdisp)
+            out["cpu_baseline"] = cpu_baseline(args.config, D)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

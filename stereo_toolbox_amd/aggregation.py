@@ -36,16 +36,19 @@ def _conv_cfg(conv):
 
 
 def _fold(bn):
-    """Eval-mode BN as per-channel (scale, bias); cached on the module, keyed by tensor versions."""
+    """Eval-mode BN as per-channel (scale, bias); cached on the module, keyed by tensor versions and storage addresses
+    (in-place edits through `.data` move neither: ops.invalidate_caches / ops.set_weight_cache).  A train() <-> eval()
+    transition of the module drops the entry."""
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_var.data_ptr())
-    hit = bn.__dict__.get("_stx_fold")
+           bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr())
+    hit = bn.__dict__.get("_stx_fold") if ops._CACHE_ENABLED else None
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     with torch.no_grad():
         scale = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
         bias = (bn.bias - bn.running_mean * scale).contiguous()
-    bn.__dict__["_stx_fold"] = (key, scale, bias)
+    if ops._CACHE_ENABLED:
+        bn.__dict__["_stx_fold"] = (key, scale, bias)
     return scale, bias
 
 
@@ -83,9 +86,18 @@ def _bn_state(bn, partials, count):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(bn.process_group) > 1:
             sync = (bn.process_group, dist.get_world_size(bn.process_group))
+    if training:
+        bn.__dict__.pop("_stx_fold", None)          # the running statistics are about to move
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    momentum = bn.momentum if bn.momentum is not None else 0.1
+    if bn.momentum is not None:
+        momentum = bn.momentum
+    elif training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        # momentum=None is torch's cumulative moving average: factor 1 / num_batches_tracked (after the increment);
+        # one host read per layer and step -- only for modules built that way (the reference's models never are)
+        momentum = 1.0 / float(bn.num_batches_tracked.item())
+    else:
+        momentum = 0.0
     return {"training": training, "partials": partials, "count": count, "running_mean": bn.running_mean,
             "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps, "sync": sync}
 

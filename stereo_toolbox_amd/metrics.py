@@ -38,8 +38,10 @@ class DisparityMetrics:
         """pred, gt: [B,H,W] or [B,1,H,W]; noc_mask (optional): same shape, non-zero where the pixel is non-occluded."""
         pred = pred.reshape(pred.shape[0], -1).float()
         gt = gt.reshape(gt.shape[0], -1).float()
-        err = (pred - gt).abs()
-        valid = (gt > 0) & (gt < self.maxdisp - 1)
+        valid = (gt > 0) & (gt < self.maxdisp - 1)            # NaN / inf ground truth (missing pixels) is excluded here
+        # select, never multiply: the reference indexes (`error_map[mask]`), so non-finite gt outside the mask must not
+        # reach a sum (NaN * 0 = NaN)
+        err = torch.where(valid, (pred - gt).abs(), torch.zeros_like(pred))
         thr = self.thresholds.to(err.device).view(1, -1, 1)
 
         def rates(mask):
@@ -50,7 +52,7 @@ class DisparityMetrics:
             return cnt, has, pct
 
         cnt, has, pct = rates(valid)
-        epe = torch.where(has, (err * valid).sum(1).double() / cnt.clamp(min=1), torch.zeros_like(cnt))
+        epe = torch.where(has, err.sum(1).double() / cnt.clamp(min=1), torch.zeros_like(cnt))
         self.seen += pred.shape[0]
         self.epe_sum += epe.sum()
         self.out_sum += pct.sum(0)

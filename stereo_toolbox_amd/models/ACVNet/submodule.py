@@ -32,6 +32,27 @@ class attention_block(nn.Module):
         self.qkv_3d = nn.Linear(self.dim_3d, self.dim_3d * 3, bias=True)
         self.final1x1 = torch.nn.Conv3d(self.dim_3d, self.dim_3d, 1)
 
+    def _pad_bias(self, H, W, pad_b, pad_r, d, device):
+        """Additive attention bias [1, d*h*w, nb, nb] that separates padded from real voxels inside a window:
+        -1000 between two tokens of different kind, 0 otherwise (reference submodule.py:405-413).  A token is
+        "padded" if it lies in the bottom pad rows or the right pad columns; the reference's slices `-pad_b:` /
+        `-pad_r:` select EVERYTHING when that pad is 0, i.e. with padding on one axis only every token counts as
+        padded and the bias vanishes -- kept, it is what trained checkpoints saw.  Cached per shape."""
+        key = (H, W, pad_b, pad_r, d, str(device))
+        hit = self.__dict__.get("_stx_bias")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        b0, b1, b2 = self.block
+        rows = torch.arange(H, device=device) >= (H - pad_b if pad_b > 0 else 0)
+        cols = torch.arange(W, device=device) >= (W - pad_r if pad_r > 0 else 0)
+        padded = rows.view(H, 1) | cols.view(1, W)                                           # [H, W] bool
+        win = padded.view(H // b1, b1, W // b2, b2).permute(0, 2, 1, 3).reshape(-1, b1 * b2)   # [h*w, b1*b2]
+        differ = win.unsqueeze(2) != win.unsqueeze(1)                                        # [h*w, b1*b2, b1*b2]
+        bias = torch.where(differ, -1000.0, 0.0).to(torch.float32)
+        bias = bias.repeat(d, b0, b0).unsqueeze(0)             # every window along D, every (dz, dz') pair of a window
+        self.__dict__["_stx_bias"] = (key, bias)
+        return bias
+
     def forward(self, x):
         B, D, H0, W0, C = x.shape
         b0, b1, b2 = self.block
@@ -49,13 +70,7 @@ class attention_block(nn.Module):
         q, k, v = qkv[0], qkv[1], qkv[2]                                  # [B, windows, heads, nb, hd]
         attn = (q @ k.transpose(-2, -1)) * self.scale_3d
         if pad_r > 0 or pad_b > 0:
-            mask = torch.zeros((1, H, W), device=x.device)
-            mask[:, -pad_b:, :].fill_(1)
-            mask[:, :, -pad_r:].fill_(1)
-            mask = mask.reshape(1, h, b1, w, b2).transpose(2, 3).reshape(1, h * w, b1 * b2)
-            am = mask.unsqueeze(2) - mask.unsqueeze(3)
-            am = am.masked_fill(am != 0, float(-1000.0)).masked_fill(am == 0, float(0.0))
-            attn = attn + am.repeat(1, d, b0, b0).unsqueeze(2)
+            attn = attn + self._pad_bias(H, W, pad_b, pad_r, d, x.device).unsqueeze(2)
         attn = torch.softmax(attn, dim=-1)
         y = attn @ v                                                      # [B, windows, heads, nb, hd]
         # channel index of the reference after its permute/reshape is (head, hd)

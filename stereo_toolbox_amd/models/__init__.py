@@ -8,20 +8,20 @@ from .PCWNet import PCWNet_G, PCWNet_GC  # noqa: F401
 
 
 def load_checkpoint_flexible(model, checkpoint_path, state_dict_key=None):
-    """reference models/__init__.py:20-51: load a checkpoint, adding/stripping the DDP `module.`
-    prefix as needed and keeping only keys the model has."""
+    """reference models/__init__.py:20-51: load a checkpoint, adding/stripping the DDP `module.` prefix as needed,
+    keeping only keys the model has, and reporting missing / unexpected keys like the reference does."""
     ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
     sd = ckpt[state_dict_key] if state_dict_key is not None else ckpt
     target = model.state_dict()
-    model_has_prefix = any(k.startswith("module.") for k in target)
-    fixed = {}
+    renamed = {}
     for k, v in sd.items():
-        has = k.startswith("module.")
-        if has and not model_has_prefix:
-            k = k[len("module."):]
-        elif not has and model_has_prefix:
-            k = "module." + k
-        if k in target:
-            fixed[k] = v
-    model.load_state_dict(fixed, strict=False)
+        if k not in target:
+            k = k[len("module."):] if k.startswith("module.") else "module." + k
+        renamed[k] = v
+    target.update({k: v for k, v in renamed.items() if k in target})
+    missing, unexpected = model.load_state_dict(target)
+    if missing:
+        print("Missing keys: ", ",".join(missing))
+    if unexpected:
+        print("Unexpected keys: ", ",".join(unexpected))
     return model

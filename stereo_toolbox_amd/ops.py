@@ -8,6 +8,7 @@ Activation convention inside the 3-D path: dense channels-last tensors of shape 
 ("NDHWC").  `to_ncdhw` / `to_ndhwc` give zero-copy logical views for the public API.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -17,12 +18,25 @@ _P = ctypes.c_void_p
 
 
 # --------------------------------------------------------------------------------------- plumbing
-def _stream():
-    return _P(torch.cuda.current_stream().cuda_stream)
+class _ArgDevices(threading.local):
+    """Devices of the tensors converted by _p() since the last launch (per host thread)."""
+
+    def __init__(self):
+        self.devs = []
+
+
+_ARGS = _ArgDevices()
+
+
+def _stream(dev=None):
+    return _P(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _p(t):
-    return None if t is None else _P(t.data_ptr())
+    if t is None:
+        return None
+    _ARGS.devs.append(t.device)
+    return _P(t.data_ptr())
 
 
 def _chk(t, name, dims=None):
@@ -40,7 +54,19 @@ def _chk(t, name, dims=None):
 
 
 def _call(name, *args):
-    get_lib().call(name, *args, _stream())
+    """Launch one C-ABI entry point on the device that OWNS the operands, on that device's current stream
+    (`model.to('cuda:1')` without `torch.cuda.set_device(1)` -- the way evaluation/sceneflow_test.py:22 and
+    generalization_eval.py use `device=` -- must not launch on cuda:0's stream).  Operands on different devices raise."""
+    devs, _ARGS.devs = _ARGS.devs, []
+    dev = devs[0] if devs else None
+    for d in devs:
+        if d != dev:
+            raise StxError(f"{name}: operands live on different devices ({dev} and {d})")
+    if dev is not None and dev.type == "cuda" and dev.index != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            get_lib().call(name, *args, _stream(dev))
+    else:
+        get_lib().call(name, *args, _stream(dev))
 
 
 def to_ncdhw(x):
@@ -54,13 +80,16 @@ def to_ndhwc(x):
 
 
 class _Workspace:
-    """Grow-only scratch buffers per (device, tag): wgrad slabs, BN partial sums."""
+    """Grow-only scratch buffers per (device, stream, tag): wgrad slabs, BN partial sums."""
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, tag, nfloats, device):
-        key = (device.index, tag)
+        # keyed by the launching stream as well: two streams (or autograd threads on different streams) must not
+        # share a slab whose contents live from one launch to the next
+        sid = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+        key = (device.index, sid, tag)
         b = self.bufs.get(key)
         if b is None or b.numel() < nfloats:
             b = torch.empty(int(nfloats), dtype=torch.float32, device=device)
@@ -71,14 +100,36 @@ class _Workspace:
 _WS = _Workspace()
 
 
+_CACHE_ENABLED = True
+
+
+def set_weight_cache(enabled):
+    """Turn the inference-time caches (packed conv weights, folded eval-mode BatchNorm) on or off.  They are keyed by
+    the owner tensors' autograd version counters and storage addresses, which every regular update moves (optimizer
+    steps, `load_state_dict`, `copy_`, in-place ops on the parameter).  An in-place edit THROUGH `.data`
+    (`p.data.mul_()`, `bn.running_var.data.fill_()`: EMA / weight-surgery code) does not move them: call
+    `invalidate_caches(model)` after such edits, or switch the caches off here while doing them."""
+    global _CACHE_ENABLED
+    _CACHE_ENABLED = bool(enabled)
+
+
+def invalidate_caches(model):
+    """Drop every cached packed weight / folded BatchNorm of `model` (see set_weight_cache)."""
+    for m in model.modules():
+        m.__dict__.pop("_stx_fold", None)
+    for p in model.parameters():
+        p.__dict__.pop("_stx_packed", None)
+
+
 def pack_weight(w, mode, owner=None):
     """Device-side re-layout of a torch conv weight [A][B][k,k,k] into MFMA B-operand order.
     mode 0: conv fwd / deconv dgrad;  1: stride-1 conv dgrad;  2: deconv fwd / stride-2 conv dgrad.
     `owner` (the nn.Parameter) enables caching for inference: the packed copy is stored ON the
     parameter object (so it dies with it -- a dict keyed by data_ptr would hand stale weights to a
-    new model whose storage reuses the address) and is refreshed when the version counter moves."""
+    new model whose storage reuses the address) and is refreshed when the version counter moves
+    (`.data` edits do not move it: see set_weight_cache / invalidate_caches)."""
     _chk(w, "weight", 5)
-    if owner is not None:
+    if owner is not None and _CACHE_ENABLED:
         cache = owner.__dict__.setdefault("_stx_packed", {})
         hit = cache.get(mode)
         if hit is not None and hit[0] == (owner._version, owner.data_ptr()):
@@ -89,7 +140,7 @@ def pack_weight(w, mode, owner=None):
     n = get_lib().raw("stx_conv3d_packed_floats")(K, N, T)
     wp = torch.empty(n, dtype=torch.float32, device=w.device)
     _call("stx_conv3d_pack_weight", _p(w), _p(wp), A, Bd, T, mode)
-    if owner is not None:
+    if owner is not None and _CACHE_ENABLED:
         cache[mode] = ((owner._version, owner.data_ptr()), wp)
     return wp
 
@@ -273,9 +324,8 @@ class ConvRawFn(torch.autograd.Function):
 def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps):
     C = partials.shape[-1]
     outs = [torch.empty(C, dtype=torch.float32, device=partials.device) for _ in range(4)]
-    lib = get_lib()
-    lib.call("stx_bn_finalize", _p(partials), partials.shape[0], C, float(count), _p(gamma), _p(beta),
-             _p(running_mean), _p(running_var), float(momentum), float(eps), *[_p(o) for o in outs], _stream())
+    _call("stx_bn_finalize", _p(partials), partials.shape[0], C, float(count), _p(gamma), _p(beta),
+          _p(running_mean), _p(running_var), float(momentum), float(eps), *[_p(o) for o in outs])
     return outs   # scale, shift, mean, invstd
 
 

@@ -1,0 +1,74 @@
+"""bench.py's launch contract: `--gpus N` spawns N ranks itself when no torchrun environment is present, refuses to
+oversubscribe devices, and rejects a WORLD_SIZE that disagrees with --gpus.  The N = 2 path runs here on CPU: gloo
+backend + the host-emulator build of the kernels (STX_BENCH_EMU=1, a test hook of bench.py), tiny shapes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "STX_BENCH_EMU")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() >= 2, reason="needs a box with < 2 devices")
+def test_bench_gpus2_refuses_without_devices():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "refusing to run 2 ranks" in (r.stderr + r.stdout)
+
+
+def test_bench_world_size_mismatch():
+    r = _run(["--gpus", "1", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_gpus2_spawns_two_gloo_ranks_emulated():
+    """`python bench.py --gpus 2` with no torchrun environment: self-spawn through torch.distributed.run, rank binding,
+    broadcast, overlapped 2-range gradient all-reduce, barrier / max-over-ranks timing, one JSON line from rank 0."""
+    from tests.emu_util import emu_lib
+    emu_lib()                                       # build the emulator library once, before the ranks race for it
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64", "--maxdisp", "32",
+              "--no-cpu-baseline"], {"STX_BENCH_EMU": "1", "OMP_NUM_THREADS": "2"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
+    assert "overlapped" in out["config"]["grad_sync"]
+
+
+def test_bench_psm_volume_config_emulated():
+    r = _run(["--config", "psm_volume", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64", "--maxdisp", "32",
+              "--no-cpu-baseline"], {"STX_BENCH_EMU": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["config"]["name"] == "psm_volume" and out["unit"] == "volumes/s" and out["n_gpus"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_rccl():
+    """Two ranks over RCCL on a node with >= 2 GPUs (skipped on the 1-GPU test box, where the refusal test runs instead)."""
+    if torch.cuda.device_count() < 2:
+        r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert r.returncode != 0 and "refusing to run 2 ranks" in (r.stderr + r.stdout)
+        return
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "64", "--width", "128", "--maxdisp", "64",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["value"] > 0

@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -25,7 +26,7 @@ def _net():
     return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 4, 3, padding=1))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,11 +37,20 @@ def _worker(rank, world, port, q):
             for p in model.parameters():
                 p.add_(1.0)
     broadcast_parameters(model)
-    sync = FlatGradSync(model)
+    sync = FlatGradSync(model, buckets=2, overlap=True) if overlap else FlatGradSync(model)
     torch.manual_seed(100)
     data = torch.randn(4, 3, 6, 6)                 # global batch; each rank takes its shard
     shard = data[rank * 2:(rank + 1) * 2]
     for it in range(2):                            # two steps: the bucket views must survive
+        if overlap:
+            # ranges of the flat buffer are all-reduced from autograd hooks while backward() is still running;
+            # both step flavours (accumulate into the views / assign fresh gradients) end with finish()
+            assert sync.nb == 2 and sync.overlap
+            (sync.zero_grad if it == 0 else sync.detach_grads)()
+            model(shard).square().mean().backward()
+            sync.finish()
+            assert sync.views_intact() and all(sync._launched)
+            continue
         if it == 0:
             sync.zero_grad()                       # accumulate-in-place flavour
             model(shard).square().mean().backward()
@@ -57,11 +67,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_flat_grad_sync_two_ranks_gloo():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_flat_grad_sync_two_ranks_gloo(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])

@@ -66,6 +66,14 @@ int stx_argmax_fwd(const float* x, long long* out, int B, int D, int HW, void* s
  * reference. */
 int stx_unimodal_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
 int stx_dominant_modal_fwd(const float* x, float* out, int B, int D, int HW, void* stream);
+/* The same two estimators with their backward pass (kind 0: unimodal, 1: dominant-modal).  The reference functions are
+ * differentiable w.r.t. x inside the mode mask, which is a constant of the graph (`x * mask.data`,
+ * unimodal_disparity_estimator.py:20; boolean masks, dominant_modal_disparity_estimator.py:45-49; twin logic in
+ * loss_functions/split_mode.py:9-35): d out / d x_k = m_k (k - out) / S.  stx_modal_fwd optionally writes
+ * aux [B][5][HW] = (lo, hi, xlo, xhi, S): support [lo, hi] minus [xlo, xhi] and its probability mass S;
+ * stx_modal_bwd turns g [B][HW], out and aux into gx [B][D][HW] (zero outside the support). */
+int stx_modal_fwd(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream);
+int stx_modal_bwd(const float* g, const float* out, const float* aux, float* gx, int B, int D, int HW, void* stream);
 /* F.softmax over the disparity axis of [B][D][HW] (ACVNet attention weights, acv.py:196) */
 int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream);
 

@@ -62,8 +62,21 @@ __device__ __forceinline__ float es_expect(const float* __restrict__ p, size_t H
     return a;
 }
 
+// aux (optional, for the backward pass): [B][5][HW] = lo, hi, xlo, xhi (support = [lo, hi] minus [xlo, xhi]) and the
+// mass S of the support.
+__device__ __forceinline__ void es_write_aux(float* aux, size_t b, int HW, int i, int lo, int hi, int xlo, int xhi,
+                                             const float* p, size_t hw) {
+    if (!aux) return;
+    float S = 0.f;
+    for (int d = lo; d <= hi; ++d)
+        if (d < xlo || d > xhi) S += p[(size_t)d * hw];
+    float* a = aux + b * 5 * (size_t)HW + i;
+    a[0] = (float)lo; a[(size_t)HW] = (float)hi; a[2 * (size_t)HW] = (float)xlo; a[3 * (size_t)HW] = (float)xhi;
+    a[4 * (size_t)HW] = S;
+}
+
 __global__ __launch_bounds__(ES_THREADS) void unimodal_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             int D, int HW) {
+                                                             float* __restrict__ aux, int D, int HW) {
     const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
     if (i >= HW) return;
     const float* p = x + (size_t)b * D * HW + i;
@@ -77,6 +90,7 @@ __global__ __launch_bounds__(ES_THREADS) void unimodal_kernel(const float* __res
     auto f = [&](int d) { return p[(size_t)d * hw]; };
     const ModeRange m = es_mode_bounds(f, D, bi, best);
     out[(size_t)b * HW + i] = es_expect(p, hw, m.lo, m.hi, 1, 0);
+    es_write_aux(aux, b, HW, i, m.lo, m.hi, 1, 0, p, hw);
 }
 
 // 5-tap box blur along D with zero padding (conv1d, padding='same', weight 1/5), entries of [zlo, zhi] forced to 0
@@ -133,7 +147,8 @@ __device__ __forceinline__ void es_modal_range(const BlurSeq& s, int* lo, int* h
 }
 
 __global__ __launch_bounds__(ES_THREADS) void dominant_modal_kernel(const float* __restrict__ x,
-                                                                   float* __restrict__ out, int D, int HW) {
+                                                                   float* __restrict__ out, float* __restrict__ aux,
+                                                                   int D, int HW) {
     const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
     if (i >= HW) return;
     const float* p = x + (size_t)b * D * HW + i;
@@ -149,6 +164,28 @@ __global__ __launch_bounds__(ES_THREADS) void dominant_modal_kernel(const float*
     for (int d = a2; d <= b2; ++d)
         if (d < a1 || d > b1) sz += p[(size_t)d * hw];
     out[(size_t)b * HW + i] = (sy >= sz) ? es_expect(p, hw, a1, b1, 1, 0) : es_expect(p, hw, a2, b2, a1, b1);
+    if (sy >= sz) es_write_aux(aux, b, HW, i, a1, b1, 1, 0, p, hw);
+    else es_write_aux(aux, b, HW, i, a2, b2, a1, b1, p, hw);
+}
+
+// Backward of both estimators.  The support mask is a constant of the graph (`x * mask.data`,
+// unimodal_disparity_estimator.py:20; boolean masks in dominant_modal_disparity_estimator.py:45-49), so with
+// out = sum_d d x_d m_d / S, S = sum_d x_d m_d:   d out / d x_k = m_k (k - out) / S.
+// One thread per pixel writes its D gradients (zero outside the support): lanes along W, coalesced rows.
+__global__ __launch_bounds__(ES_THREADS) void modal_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                              const float* __restrict__ aux, float* __restrict__ gx,
+                                                              int D, int HW) {
+    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    const float* a = aux + (size_t)b * 5 * HW + i;
+    const int lo = (int)a[0], hi = (int)a[(size_t)HW], xlo = (int)a[2 * (size_t)HW], xhi = (int)a[3 * (size_t)HW];
+    const float S = a[4 * (size_t)HW];
+    const float o = out[(size_t)b * HW + i], gg = g[(size_t)b * HW + i];
+    float* q = gx + (size_t)b * D * HW + i;
+    for (int d = 0; d < D; ++d) {
+        const bool in = d >= lo && d <= hi && (d < xlo || d > xhi);
+        q[(size_t)d * HW] = in ? gg * (((float)d - o) / S) : 0.f;
+    }
 }
 
 }  // namespace
@@ -157,7 +194,7 @@ extern "C" int stx_unimodal_fwd(const float* x, float* out, int B, int D, int HW
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "unimodal_fwd: bad shape");
     hipLaunchKernelGGL(unimodal_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0, (hipStream_t)stream, x,
-                       out, D, HW);
+                       out, (float*)nullptr, D, HW);
     return stx_check_launch("unimodal_fwd");
 }
 
@@ -165,6 +202,25 @@ extern "C" int stx_dominant_modal_fwd(const float* x, float* out, int B, int D, 
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "dominant_modal_fwd: bad shape");
     hipLaunchKernelGGL(dominant_modal_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0,
-                       (hipStream_t)stream, x, out, D, HW);
+                       (hipStream_t)stream, x, out, (float*)nullptr, D, HW);
     return stx_check_launch("dominant_modal_fwd");
+}
+
+// kind 0: unimodal, 1: dominant-modal; aux [B][5][HW] is what stx_modal_bwd needs (may be null: plain forward)
+extern "C" int stx_modal_fwd(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0 && (kind == 0 || kind == 1), "modal_fwd: bad arguments");
+    const dim3 grid(stx_cdiv(HW, ES_THREADS), B);
+    if (kind == 0) hipLaunchKernelGGL(unimodal_kernel, grid, dim3(ES_THREADS), 0, (hipStream_t)stream, x, out, aux, D, HW);
+    else hipLaunchKernelGGL(dominant_modal_kernel, grid, dim3(ES_THREADS), 0, (hipStream_t)stream, x, out, aux, D, HW);
+    return stx_check_launch("modal_fwd");
+}
+
+extern "C" int stx_modal_bwd(const float* g, const float* out, const float* aux, float* gx, int B, int D, int HW,
+                             void* stream) {
+    stx_begin();
+    STX_REQUIRE(g && out && aux && gx && B > 0 && D > 0 && HW > 0, "modal_bwd: bad arguments");
+    hipLaunchKernelGGL(modal_bwd_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0, (hipStream_t)stream, g,
+                       out, aux, gx, D, HW);
+    return stx_check_launch("modal_bwd");
 }

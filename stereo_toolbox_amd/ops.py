@@ -670,31 +670,56 @@ def argmax_disparity(x):
     return out
 
 
-def _modal_estimator(entry, x, maxdisp):
+class _ModalFn(torch.autograd.Function):
+    """Modal estimators with autograd: the support mask is a constant of the graph (the reference multiplies by
+    `mask.data` / boolean masks), so d out / d x_k = m_k (k - out) / S; the forward pass saves the support and its
+    mass per pixel ([B,5,H,W]) for the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        B, D, H, W = x.shape
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        aux = torch.empty(B, 5, H, W, dtype=torch.float32, device=x.device)
+        _call("stx_modal_fwd", _p(x), _p(out), _p(aux), B, D, H * W, kind)
+        ctx.save_for_backward(out, aux)
+        ctx.D = D
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, aux = ctx.saved_tensors
+        B, _, H, W = out.shape
+        g = g.contiguous()
+        gx = torch.empty(B, ctx.D, H, W, dtype=torch.float32, device=out.device)
+        _call("stx_modal_bwd", _p(g), _p(out), _p(aux), _p(gx), B, ctx.D, H * W)
+        return gx, None
+
+
+def _modal_estimator(kind, x, maxdisp):
     assert len(x.shape) == 4
-    if torch.is_grad_enabled() and x.requires_grad:
-        # the reference is differentiable w.r.t. x inside the (detached) mode mask; only the forward pass is
-        # implemented here (the toolbox calls these estimators at inference time) -- fail loudly rather than cut the graph
-        raise StxError(f"{entry}: forward only; call it under torch.no_grad() or on a detached volume")
+    name = ("unimodal", "dominant_modal")[kind]
     x = x.contiguous()
     _chk(x, "x", 4)
     B, D, H, W = x.shape
     if D != maxdisp:
-        raise StxError(f"{entry}: volume has {D} disparities, maxdisp={maxdisp}")
+        raise StxError(f"{name}_disparity_estimator: volume has {D} disparities, maxdisp={maxdisp}")
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ModalFn.apply(x, kind)
     out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
-    _call(entry, _p(x), _p(out), B, D, H * W)
+    _call("stx_modal_fwd", _p(x), _p(out), None, B, D, H * W, kind)
     return out
 
 
 def unimodal_disparity(x, maxdisp):
-    """Expectation over the mode containing the arg-max (unimodal_disparity_estimator.py:4-25) -> [B,1,H,W]."""
-    return _modal_estimator("stx_unimodal_fwd", x, maxdisp)
+    """Expectation over the mode containing the arg-max (unimodal_disparity_estimator.py:4-25) -> [B,1,H,W];
+    differentiable w.r.t. x inside the (constant) mode mask, like the reference."""
+    return _modal_estimator(0, x, maxdisp)
 
 
 def dominant_modal_disparity(x, maxdisp):
     """Expectation over the heavier of the two main modes of the blurred volume
-    (dominant_modal_disparity_estimator.py:35-54) -> [B,1,H,W]."""
-    return _modal_estimator("stx_dominant_modal_fwd", x, maxdisp)
+    (dominant_modal_disparity_estimator.py:35-54) -> [B,1,H,W]; differentiable like the reference."""
+    return _modal_estimator(1, x, maxdisp)
 
 
 def softmax_over_d(x):

@@ -18,3 +18,34 @@ def emu():
     """Host SIMT-emulator build of the kernel sources (tests only, see tests/hipemu)."""
     from tests.emu_util import emu_lib
     return emu_lib()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Parity report: tests that measure an error against the oracle / the reference fixtures record it here; the numbers
+# are printed in the terminal summary (also under -q, where captured stdout of passing tests is not shown) and
+# appended to gpurun_out/parity_report.jsonl when that directory exists (GPU box runs).
+_PARITY = []
+
+
+@pytest.fixture
+def parity_log():
+    def add(name, **fields):
+        _PARITY.append({"test": name, **fields})
+    return add
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _PARITY:
+        return
+    import json
+    terminalreporter.section("parity report (achieved errors)")
+    for rec in _PARITY:
+        terminalreporter.write_line(json.dumps(rec))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+                for rec in _PARITY:
+                    f.write(json.dumps(rec) + "\n")
+        except OSError:
+            pass

@@ -33,6 +33,15 @@ def main():
     peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
     out["uni_peaky"] = ref_est.unimodal_disparity_estimator(peaky, 16).numpy()
     out["dom_peaky"] = ref_est.dominant_modal_disparity_estimator(peaky, 16).numpy()
+    # gradients of the reference estimators w.r.t. the volume (they are differentiable inside the constant mode mask:
+    # unimodal_disparity_estimator.py:20-25), upstream gradient = deterministic pattern re-made by the tests
+    for tag in ("a", "b"):
+        B, D, H, W, seed = CASES[tag]
+        for name, fn in (("uni", ref_est.unimodal_disparity_estimator), ("dom", ref_est.dominant_modal_disparity_estimator)):
+            x = synthetic_modal_volume(B, D, H, W, seed).requires_grad_()
+            gy = synthetic_tensor((B, 1, H, W), 40 + seed)
+            fn(x, D).backward(gy)
+            out[f"{name}_grad_{tag}"] = x.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "estimators_modal.npz"), **out)
     print("wrote estimators_modal.npz", {k: v.shape for k, v in out.items()})
 

@@ -163,6 +163,29 @@ def test_modal_estimators(be, case):
         assert bad <= (0 if entry == "stx_unimodal_fwd" else B * H * W // 100), f"{entry}: {bad} pixels differ"
 
 
+@pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22)])
+def test_modal_estimators_backward(be, case):
+    """stx_modal_fwd (+aux) / stx_modal_bwd vs autograd through the oracle (whose gradients are pinned to the
+    reference's, tests/golden/estimators_modal.npz)."""
+    from stereo_toolbox_amd.utils import synthetic_modal_volume, synthetic_tensor
+    B, D, H, W, seed = case
+    x = synthetic_modal_volume(B, D, H, W, seed)
+    gy = synthetic_tensor((B, 1, H, W), 40 + seed)
+    d = be.dev(x)
+    for kind, ref in ((0, O.unimodal_disparity_estimator), (1, O.dominant_modal_disparity_estimator)):
+        o, aux, gx = be.empty(B, H * W), be.empty(B, 5, H * W), be.empty(B, D, H * W)
+        be.call("stx_modal_fwd", ptr(d), ptr(o), ptr(aux), B, D, H * W, kind)
+        be.call("stx_modal_bwd", ptr(be.dev(gy)), ptr(o), ptr(aux), ptr(gx), B, D, H * W)
+        xr = x.clone().requires_grad_()
+        want = ref(xr, D)
+        want.backward(gy)
+        assert ((o.cpu() - want.detach().reshape(B, H * W)).abs() > 1e-4 * (1 + want.abs().max())).sum().item() == 0
+        err = (gx.cpu().view_as(xr.grad) - xr.grad).abs()
+        tol = 1e-4 * (1 + xr.grad.abs())
+        bad_px = (err > tol).any(1).sum().item()          # a pixel whose mode choice flipped differs everywhere
+        assert bad_px <= (0 if kind == 0 else B * H * W // 100), f"kind {kind}: {bad_px} pixels differ"
+
+
 # ------------------------------------------------------------------------------ convolutions
 def pack(be, w, mode):
     A, Bd = w.shape[0], w.shape[1]

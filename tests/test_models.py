@@ -287,34 +287,109 @@ def test_product_path_has_no_cpu_fallback():
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json full-size configurations (GPU only): parity at the headline shapes and
 # size-independent properties of the builders.
+def _gold(name):
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(576, 960), (384, 1248)])    # SceneFlow 540x960 / KITTI 375x1242 after pad_to_2x
-def test_gwcnet_gc_full_size_eval_parity(shape):
-    """configs[2]/[4] shape: GwcNet_GC(192) eval forward at the padded full resolution vs the CPU oracle."""
-    from stereo_toolbox_amd.models import GwcNet_GC
+@pytest.mark.parametrize("tag", ["gwc_gc_576x960", "gwc_gc_384x1248", "acv_576x960"])
+def test_full_size_eval_parity(tag, parity_log):
+    """BASELINE.json configs[2]/[3]/[4] shapes, eval forward at the padded full resolution (SceneFlow 540x960 ->
+    576x960, KITTI 375x1242 -> 384x1248), D=192.  Two yard-sticks, both reported:
+      * the REFERENCE itself (tests/golden/fullsize_eval.npz: its fp64 output sampled every 4th pixel, and the max-abs
+        distance of its own fp32 run from fp64 over all pixels), and
+      * the CPU oracle run on this box over ALL pixels.
+    Bar: 1e-3 max-abs (north_star).  If -- and only if -- a correct fp32 implementation cannot meet it at this size
+    (the reference's own fp32 run is further than 0.5e-3 from fp64), the product must instead be no further from fp64
+    than 2x the reference's fp32 run; the branch taken is part of the report."""
+    from stereo_toolbox_amd.models import ACVNet, GwcNet_GC
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
-    H, W = shape
-    m, sd = _filled(GwcNet_GC, 192)
+    gold = _gold("fullsize_eval.npz")
+    H, W = (int(v) for v in tag.split("_")[-1].split("x"))
+    acv = tag.startswith("acv")
+    m, sd = _filled(ACVNet if acv else GwcNet_GC, 192)
     m = m.cuda().eval()
     left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
     with torch.no_grad():
         got = m(left.cuda(), right.cuda()).cpu()
-        ref = O.gwcnet_forward(sd, left, right, 192, True)
+        ref = O.acvnet_forward(sd, left, right, 192) if acv else O.gwcnet_forward(sd, left, right, 192, True)
     assert got.shape == (1, H, W)
     assert ref.std() > 1.0
-    err = (got - ref).abs().max().item()
-    if err >= 1e-3:
-        # 553k pixels, disparities up to ~190 (fp32 ulp 1.5e-5), ~30 fp32 conv layers: the worst pixel of
-        # two correct fp32 implementations sits right at the 1e-3 bar.  Arbitrate with an fp64 oracle run:
-        # the product must be no further from fp64 than 2x the fp32 CPU oracle itself is.
-        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        with torch.no_grad():
-            ref64 = O.gwcnet_forward(sd64, left.double(), right.double(), 192, True)
-        e_prod = (got.double() - ref64).abs().max().item()
-        e_orc = (ref.double() - ref64).abs().max().item()
-        assert e_prod < max(1e-3, 2 * e_orc), (err, e_prod, e_orc)
-    assert (got - ref).abs().mean().item() < 3e-4
+    s = int(gold["stride"])
+    ref64 = torch.from_numpy(gold[tag + "_64"])
+    e_prod64 = (got[:, ::s, ::s].double() - ref64).abs().max().item()      # product vs reference fp64 (sample)
+    e_orc64 = (ref[:, ::s, ::s].double() - ref64).abs().max().item()       # this box's oracle vs reference fp64 (sample)
+    e_ref32 = float(gold[tag + "_e32"])                                    # reference fp32 vs fp64 (all pixels)
+    e_full = (got - ref).abs().max().item()                                # product vs oracle, all pixels
+    e_mean = (got - ref).abs().mean().item()
+    flat = e_full < 1e-3 and e_prod64 < 1e-3
+    parity_log(f"full_size_eval[{tag}]", max_abs_vs_oracle_all_px=e_full, mean_abs_vs_oracle=e_mean,
+               max_abs_vs_reference_fp64_sampled=e_prod64, oracle_vs_reference_fp64_sampled=e_orc64,
+               reference_fp32_vs_fp64_all_px=e_ref32, branch="flat 1e-3" if flat else "fp64-calibrated (2x reference fp32 error)")
+    assert e_orc64 < max(1e-3, 2 * e_ref32), "oracle on this box disagrees with the reference fixture"
+    if not flat:
+        assert e_ref32 > 0.5e-3, (e_full, e_prod64, e_ref32)               # the escape exists only where fp32 itself is at the bar
+        assert e_prod64 < 2 * e_ref32 and e_full < 2e-3, (e_full, e_prod64, e_ref32)
+    assert e_mean < 3e-4
+
+
+@pytest.mark.gpu
+def test_gwcnet_gc_full_size_train_step_parity(parity_log):
+    """The BENCHMARKED workload (BASELINE.json configs[2]): one GwcNet_GC(192) train step on a 576x960 pair, batch 1 --
+    4 predictions, loss, 9 named gradients and a BN running mean against the reference's own fp64 run
+    (tests/golden/fullsize_gwc_gc_train.npz, generated from /root/reference).  Tolerances are calibrated with the distance
+    of the reference's fp32 run from its fp64 run (stored per tensor): batch-stat BN amplifies fp32 rounding between two
+    correct implementations, so the product must be as close to fp64 as fp32 arithmetic allows -- 3x (predictions) /
+    20x (gradients, as in _check_grads) the reference's own fp32 distance, floors 1e-3 px and 1 % of the tensor's max."""
+    from stereo_toolbox_amd.models import GwcNet_GC
+    from stereo_toolbox_amd.utils import state_dict_digest
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    gold = _gold("fullsize_gwc_gc_train.npz")
+    H, W, D = 576, 960, 192
+    m, sd = _filled(GwcNet_GC, D)
+    assert state_dict_digest(sd) == int(gold["digest"]), "filler weights differ from the fixture's"
+    m = m.cuda().train()
+    left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
+    gt = synthetic_tensor((1, H, W), 3, lo=0.0, hi=190.0)
+    preds = m(left.cuda(), right.cuda())
+    loss = O.smooth_l1_multi(preds, gt.cuda(), D, LOSS_W)
+    loss.backward()
+    torch.cuda.synchronize()
+    s = int(gold["stride"])
+    rec = {}
+    for i, p in enumerate(preds):
+        ref64 = torch.from_numpy(gold[f"pred{i}_64"])
+        e_prod = (p.detach().cpu()[:, ::s, ::s].double() - ref64).abs().max().item()
+        e_ref32 = float(gold[f"pred{i}_e32"])
+        rec[f"pred{i}"] = (e_prod, e_ref32)
+        assert e_prod < max(1e-3, 3 * e_ref32), (i, e_prod, e_ref32)   # (reference fp32 itself: 1.3e-3 .. 4.6e-3 px here)
+    l64, l32 = float(gold["loss64"]), float(gold["loss32"])
+    rec["loss"] = (abs(loss.item() - l64), abs(l32 - l64))
+    assert abs(loss.item() - l64) < max(1e-4 * abs(l64), 5 * abs(l32 - l64)), (loss.item(), l64, l32)
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for key in gold.files:
+        if not key.startswith("grad64:"):
+            continue
+        k = key[len("grad64:"):]
+        g = named[k].grad.detach().cpu()
+        r64 = torch.from_numpy(gold[key])
+        if g.shape != r64.shape:
+            g = g[:r64.shape[0]]                                            # dres3.conv5.0.weight: first 32 input channels stored
+        e_prod = (g.double() - r64.double()).abs().max().item()
+        e_ref32, scale = float(gold["grad_e32:" + k]), float(gold["grad_scale:" + k])
+        rec["grad:" + k] = (e_prod / scale, e_ref32 / scale)
+        worst = max(worst, e_prod / scale)
+        assert e_prod <= max(1e-2 * scale, 20 * e_ref32) + 1e-6, (k, e_prod, e_ref32, scale)
+    rm = m.dres2.conv4[0][1].running_mean.detach().cpu()
+    rm64 = torch.from_numpy(gold["rm64:dres2.conv4.0.1"])
+    assert (rm - rm64).abs().max().item() < 1e-4 * max(1.0, rm64.abs().max().item())
+    parity_log("full_size_train_step[gwc_gc_576x960]",
+               **{k: {"product_vs_ref_fp64": float(f"{a:.4e}"), "ref_fp32_vs_fp64": float(f"{b:.4e}")} for k, (a, b) in rec.items()})
 
 
 @pytest.mark.gpu
@@ -399,9 +474,7 @@ def test_acvnet_frozen_attention_train(env):
 
 
 # ------------------------------------------------------------------------------ PCWNet
-# Emulator-only this round: the family went in after the round's GPU budget was spent; its GPU parity tests and timings
-# are the first item of the next round (the kernels it runs on are the GPU-validated ones of GwcNet plus Mish and the
-# align_corners=True head, which have their own kernel-level tests in test_kernels.py).
+# Emulator tests at tiny shapes + GPU tests (eval parity, full train step) below.
 def test_pcwnet_gc_eval_parity_emu():
     from tests.emu_util import emu_product_path
     from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
@@ -459,13 +532,7 @@ def test_pcwnet_hourglassup_train_emu():
     assert n == 39
 
 
-_PCW_GPU = pytest.mark.skipif(__import__("os").environ.get("STX_TEST_PCWNET_GPU") != "1",
-                              reason="PCWNet has not had its first GPU run yet (round-1 GPU minutes were spent before it "
-                                     "went in); set STX_TEST_PCWNET_GPU=1 to run")
-
-
 @pytest.mark.gpu
-@_PCW_GPU
 def test_pcwnet_gc_eval_parity_gpu():
     from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
     D = 64
@@ -480,7 +547,6 @@ def test_pcwnet_gc_eval_parity_gpu():
 
 
 @pytest.mark.gpu
-@_PCW_GPU
 def test_pcwnet_gc_train_step_gpu():
     """6 predictions, loss and every parameter gradient against the fp64-calibrated oracle (as for GwcNet_GC)."""
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi

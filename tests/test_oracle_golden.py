@@ -87,6 +87,12 @@ def test_modal_estimators():
     peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
     assert torch.equal(O.unimodal_disparity_estimator(peaky, 16), g["uni_peaky"])
     assert torch.equal(O.dominant_modal_disparity_estimator(peaky, 16), g["dom_peaky"])
+    # gradients w.r.t. the volume (constant mode mask): oracle autograd vs the reference's
+    for tag, (B, D, H, W, seed) in {"a": (2, 32, 5, 9, 21), "b": (1, 48, 4, 7, 22)}.items():
+        for name, fn in (("uni", O.unimodal_disparity_estimator), ("dom", O.dominant_modal_disparity_estimator)):
+            x = synthetic_modal_volume(B, D, H, W, seed).requires_grad_()
+            fn(x, D).backward(synthetic_tensor((B, 1, H, W), 40 + seed))
+            close(x.grad, g[f"{name}_grad_{tag}"], 1e-6)
 
 
 def test_pcwnet():

@@ -25,6 +25,7 @@
 // 1 KiB of contiguous NDHWC bytes per instruction.  The left operand of a
 // gwc quad (4 groups x cpg channels) stays in registers across the disparity loop;
 // the D-shifted right operand comes from the LDS tile.
+#include "cost_volume.h"
 #include "stx_common.h"
 #include <stdlib.h>
 
@@ -547,7 +548,7 @@ constexpr int CVB_ITEMS = CV_WT * CVB_CH / CV_THREADS;   // 10 accumulators per 
 __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     const float* __restrict__ gvol, const float* __restrict__ Lg, const float* __restrict__ Rg,
     int Cg, int G, int Cc, float* __restrict__ gLg, float* __restrict__ gRg,
-    float* __restrict__ gLc, float* __restrict__ gRc, int H, int W, int D, int mask_left) {
+    float* __restrict__ gLc, float* __restrict__ gRc, int H, int W, int D, int mask_left, int pass) {
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * CV_WT;
@@ -569,8 +570,10 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     float* gout = right ? gRg : gLg;
 
     // ---- gwc channels
-    for (int c0 = 0; c0 < Cg; c0 += CVB_CH) {
-        const int nch = (Cg - c0 < CVB_CH) ? (Cg - c0) : CVB_CH;
+    // `pass` <= CVB_CH channels per sweep over the disparities: a whole number of group quads (host: 160 for 4 or 8
+    // channels per group, 144 for 12, 128 for 16)
+    for (int c0 = 0; c0 < Cg; c0 += pass) {
+        const int nch = (Cg - c0 < pass) ? (Cg - c0) : pass;
         const int g0 = c0 / cpg, ng = nch / cpg;           // groups of this pass (ng <= 40)
         float acc[CVB_ITEMS];
 #pragma unroll
@@ -872,7 +875,12 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     }
     if (Cc) STX_REQUIRE(Lc && Rc, "cost_volume_fwd: concat features missing");
     const int cpg = G ? Cg / G : 4;
-    STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, "cost_volume_fwd: channels per group %d not in {4,8,16}", cpg);
+    STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16, "cost_volume_fwd: channels per group %d not in {4,8,12,16}", cpg);
+    {   // second-generation builder (MFMA correlation, LDS-staged voxels): serves every configuration it accepts
+        const int rc = stx_cv_fwd_mfma(Lg, Rg, Cg, G, Lc, Rc, Cc, scale, vol, B, H, W, D, mask_left, stream);
+        if (rc >= 0) return rc;
+    }
+    STX_REQUIRE(cpg != 12, "cost_volume_fwd: 12 channels per group need the MFMA builder (STX_CV_OLD is set?)");
     hipStream_t st0 = (hipStream_t)stream;
     static const int no_row = getenv("STX_CV_NO_ROW") ? 1 : 0;
     const size_t lds_row = ((size_t)(CV_WT + CVR_RING) * (Cg + 4) + (size_t)(CV_WT + CVR_RING) * (Cc + 4)) * 4;
@@ -940,8 +948,7 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
     if (G) {
         STX_REQUIRE(Lg && Rg && gLg && gRg && Cg % G == 0, "cost_volume_bwd: gwc operands missing");
         const int cpg = Cg / G;
-        STX_REQUIRE(CVB_CH % cpg == 0 && (CVB_CH / cpg) % 4 == 0 && (Cg % CVB_CH) % (4 * cpg) == 0,
-                    "cost_volume_bwd: channels per group %d unsupported", cpg);
+        STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16, "cost_volume_bwd: channels per group %d not in {4,8,12,16}", cpg);
     }
     if (Cc) STX_REQUIRE(gLc && gRc, "cost_volume_bwd: concat outputs missing");
     static const int no_g8 = getenv("STX_CVB_GENERIC") ? 1 : 0;
@@ -955,7 +962,9 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
     const size_t lds = ((size_t)CVB_DC * CV_WT * 40 + (size_t)(CV_WT + CVB_DC - 1) * (CVB_CH + 4) +
                         (size_t)CVB_CH * (CV_WT + 1)) * 4;
     dim3 grid(stx_cdiv(W, CV_WT), 2, B * H);
+    const int cpg_ = G ? Cg / G : 8;
+    const int pass = (CVB_CH / (4 * cpg_)) * (4 * cpg_);       // whole group quads per sweep
     hipLaunchKernelGGL(cost_volume_bwd_kernel, grid, dim3(CV_THREADS), lds, (hipStream_t)stream, gvol, Lg, Rg,
-                       G ? Cg : 0, G, Cc, gLg, gRg, gLc, gRc, H, W, D, mask_left);
+                       G ? Cg : 0, G, Cc, gLg, gRg, gLc, gRc, H, W, D, mask_left, pass);
     return stx_check_launch("cost_volume_bwd");
 }

@@ -57,3 +57,13 @@ static inline int stx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float4 stx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// 16-byte store with the non-temporal hint (streamed output that the writing CU never re-reads)
+__device__ __forceinline__ void stx_st4_nt(float* p, float4 v) {
+#ifdef STX_HIPEMU
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    f32x4 t;
+    t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+#endif
+}

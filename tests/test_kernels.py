@@ -28,12 +28,30 @@ CV_CASES = [
     (1, 64, 8, 4, 2, 40, 48, 1),      # D' = 48 > W tile
     (2, 320, 40, 0, 2, 24, 12, 1),    # ACVNet gwc-only volume, batch 2
     (1, 64, 8, 4, 3, 52, 13, 0),      # 8 channels per group, left half unmasked, D not a multiple of 8
+    (1, 96, 8, 0, 2, 50, 20, 1),      # IGEV-style initial volume: 12 channels per group (igev_stereo.py:206)
+    (1, 64, 4, 8, 2, 35, 9, 1),       # 16 channels per group
+    (1, 32, 8, 0, 2, 33, 17, 1),      # 4 channels per group
 ]
 
 
+@pytest.fixture(params=["default", "few_workgroups", "two_quads_per_wave"])
+def cv_variant(request, monkeypatch):
+    """Launch variants of the MFMA builder (environment switches read per call): the default grid gives small test
+    volumes one unit per workgroup; `few_workgroups` forces runs of several units per workgroup (register rotation of
+    the right-feature tiles along a row, row / chunk changes inside a run); `two_quads_per_wave` the fat-wave layout."""
+    if request.param == "few_workgroups":
+        monkeypatch.setenv("STX_CV_GRID", "2")
+    elif request.param == "two_quads_per_wave":
+        monkeypatch.setenv("STX_CV_QPW", "2")
+        monkeypatch.setenv("STX_CV_GRID", "3")
+    return request.param
+
+
 @pytest.mark.parametrize("case", CV_CASES)
-def test_cost_volume_fwd_bwd(be, case):
+def test_cost_volume_fwd_bwd(be, case, cv_variant):
     B, Cg, G, Cc, H, W, D, ml = case
+    if cv_variant != "default" and be.name == "hip" and case is not CV_CASES[1]:
+        pytest.skip("launch variants are covered on the emulator; one GPU case each")
     torch.manual_seed(1)
     Lg = torch.randn(B, Cg, H, W) if G else None
     Rg = torch.randn(B, Cg, H, W) if G else None

@@ -234,6 +234,163 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
 }
 
 // ------------------------------------------------------------------------------------------
+// Persistent, software-pipelined variant of conv3d_igemm_kernel (same tile geometry, operand feed and epilogue).
+//
+// conv3d_igemm_kernel runs "stage the halo tile of a K chunk -> barrier -> 27 taps of MFMAs" once per workgroup and
+// leaves the overlap of one workgroup's staging with the other's MFMAs to chance (two workgroups per CU): measured
+// 0.41-0.62 of the fp32-MFMA peak, worst where a chunk carries few MFMAs per staged byte (stride 2: 8-channel chunks).
+// Here a workgroup is persistent: it owns a contiguous run of output tiles and walks the flattened (tile, K chunk)
+// sequence; the halo tile of item i+1 is loaded global -> registers right before the MFMA loop of item i and only
+// written to LDS after it, between the two barriers that separate the items.  The global-memory latency of the
+// staging is therefore always covered by a full tap loop; what stays exposed is the register -> LDS copy.
+template <int KS, int S, int TD, int TH, int NT, int CK>
+__global__ __launch_bounds__(CONV_THREADS) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
+    constexpr int PAD = KS / 2;
+    constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
+    constexpr int EWH = (EW + 1) / 2;
+    constexpr int EWS = (S == 2) ? 2 * EWH : EW;
+    constexpr int MT = TD * TH / 4;
+    constexpr int VS = CK + 4;
+    constexpr int NF4 = CK / 4;
+    constexpr int NE = ED * EH * EW * NF4;                       // float4 elements of a staged tile
+    constexpr int NST = (NE + CONV_THREADS - 1) / CONV_THREADS;  // per thread
+    constexpr int T = KS * KS * KS, NQC = CK / 8;
+    static_assert(TD * TH % 4 == 0, "tile must split over 4 waves");
+    STX_DYN_SMEM(smem);
+    float* tile = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int NQ = a.Cin / 8, nchunk = a.Cin / CK;
+    const int tiles_per_b = a.nDt * a.nHt * a.nWt;
+    // contiguous run of tiles (XCD-aware: neighbouring runs share halos in one L2)
+    const long long wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int t_lo = __builtin_amdgcn_readfirstlane((int)((long long)ntiles_total * wg / gridDim.x));
+    const int t_hi = __builtin_amdgcn_readfirstlane((int)((long long)ntiles_total * (wg + 1) / gridDim.x));
+
+    int abase[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mtile = wave * MT + m;
+        const int td = mtile / TH, th = mtile % TH;
+        abase[m] = ((td * S * EH + th * S) * EWS + i) * VS + 4 * half;
+    }
+    // staging map of this thread: element e = tid + k*256 -> (voxel v, float4 f); voxel -> (dz, hy, wx)
+    float4 stg[NST];
+    auto tile_origin = [&](int t, int& b, int& od0, int& oh0, int& ow0) {
+        b = t / tiles_per_b;
+        const int r = t - b * tiles_per_b;
+        const int wt = r % a.nWt, ht = (r / a.nWt) % a.nHt, dt = r / (a.nWt * a.nHt);
+        od0 = dt * TD; oh0 = ht * TH; ow0 = wt * 32;
+    };
+    auto load_item = [&](int t, int c0) {
+        int b, od0, oh0, ow0;
+        tile_origin(t, b, od0, oh0, ow0);
+        const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * CONV_THREADS;
+            const int v = e / NF4, f = e - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < NE && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
+            stg[k] = val;
+        }
+    };
+    auto store_item = [&]() {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * CONV_THREADS;
+            const int v = e / NF4, f = e - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+            if (e < NE) stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, stg[k]);
+        }
+    };
+
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    f32x16 acc[MT][NT];
+    if (t_lo < t_hi) load_item(t_lo, 0);
+    for (int t = t_lo; t < t_hi; ++t) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            __syncthreads();                   // every wave is done reading the previous item's tile
+            store_item();
+            __syncthreads();
+            {                                  // next item's halo tile: in flight during this item's tap loop
+                const int nch = ch + 1 < nchunk ? ch + 1 : 0;
+                const int ntl = ch + 1 < nchunk ? t : t + 1;
+                if (ntl < t_hi) load_item(ntl, nch * CK);
+            }
+            const float* wq = a.wp + ((size_t)(ch * (CK / 8)) * NT * 64 + lane) * 4;
+            float4 bcur[NQC][NT], bnxt[NQC][NT], acur[NQC][MT], anxt[NQC][MT];
+            auto load_tap = [&](int tap, float4 (&av)[NQC][MT], float4 (&bv)[NQC][NT]) {
+                const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+                const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
+                                          : ((kd * EH + kh) * EWS + kw) * VS;
+                const float* wtap = wq + (size_t)tap * NQ * NT * 256;
+#pragma unroll
+                for (int q = 0; q < NQC; ++q) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
+                }
+            };
+            load_tap(0, acur, bcur);
+            for (int tap = 0; tap < T; ++tap) {
+                if (tap + 1 < T) load_tap(tap + 1, anxt, bnxt);
+                STX_SCHED_BARRIER();
+#pragma unroll
+                for (int q = 0; q < NQC; ++q)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
+                        }
+                STX_SCHED_BARRIER();
+#pragma unroll
+                for (int q = 0; q < NQC; ++q) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acur[q][m] = anxt[q][m];
+                }
+            }
+        }
+        int b, od0, oh0, ow0;
+        tile_origin(t, b, od0, oh0, ow0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int mtile = wave * MT + m;
+            const int od = od0 + mtile / TH, oh = oh0 + mtile % TH;
+            int nrows = (od < a.Do && oh < a.Ho) ? (a.Wo - ow0) : 0;
+            nrows = nrows > 32 ? 32 : nrows;
+            const size_t vox0 = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + i;
+                const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+                const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+                conv_epilogue_block(a, acc[m][nt], vox0, 1, nrows, n, sc, bs, lane, s1[nt], s2[nt]);
+            }
+        }
+    }
+    if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
 // 3x3x3 stride-1 convolution with Cin = 32, software-pipelined along D ("march" kernel).
 //
 // conv3d_igemm_kernel above stages a tile, computes, stages the next: co-resident workgroups run in
@@ -250,12 +407,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
 // MW = 16 variant: the 32 voxels of a row block are 2 rows x 16 columns (workgroup column 8 x 16), for widths
 // like W' = 240 = 15 x 16 = 7.5 x 32 where 32-wide blocks waste 6 % of the MFMAs; its planes are 10 x 18 voxels.
 constexpr int MARCH_VS = 36;
-constexpr int MARCH_THREADS = 512;
-template <int MW, int NRB> struct MarchGeo {     // NRB row blocks (of 32 voxels) per workgroup column
+template <int MW, int NRB, int NTHR> struct MarchGeo {     // NRB row blocks (of 32 voxels) per workgroup column
     static constexpr int R = 32 / MW;              // rows per 32-voxel row block
     static constexpr int TH = NRB * R, EH = TH + 2, EW = MW + 2;
     static constexpr int SLOT = EH * EW * MARCH_VS;                 // floats per ring slot
-    static constexpr int NF4 = (EH * EW * 8 + MARCH_THREADS - 1) / MARCH_THREADS;
+    static constexpr int NF4 = (EH * EW * 8 + NTHR - 1) / NTHR;
 };
 
 struct MarchArgs {
@@ -267,10 +423,14 @@ struct MarchArgs {
 // NQ = 8-channel K steps a wave multiplies per tap: 2 = wave pairs split K as described above (4 row blocks per
 // column); 4 = every wave owns a whole row block (8 row blocks per column: 16 x 16 or 8 x 32 voxels), no
 // accumulator exchange, twice the MFMAs per plane and barrier pair.
-template <int NT, int MW, int NQ>
-__global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs ma) {
+// NWV = waves per workgroup.  8: one workgroup per CU (LDS ring 78-87 KB + exchange buffer).  4 (whole-K waves only): a
+// column of 4 row blocks, no exchange buffer -> TWO independent workgroups per CU, one wave of each per SIMD: while one
+// workgroup sits in its per-plane barriers / epilogue stores, the other one's wave keeps the SIMD's matrix pipe busy.
+template <int NT, int MW, int NQ, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64) void conv3d_march_kernel(MarchArgs ma) {
     constexpr bool KSPLIT = (NQ == 2);
-    using G = MarchGeo<MW, KSPLIT ? 4 : 8>;
+    constexpr int MARCH_THREADS = NWV * 64;
+    using G = MarchGeo<MW, KSPLIT ? NWV / 2 : NWV, MARCH_THREADS>;
     constexpr int MARCH_TH = G::TH, MARCH_EH = G::EH, MARCH_EW = G::EW, MARCH_SLOT = G::SLOT, MARCH_NF4 = G::NF4;
     const ConvArgs& a = ma.c;
     STX_DYN_SMEM(smem);
@@ -466,7 +626,7 @@ __global__ __launch_bounds__(MARCH_THREADS) void conv3d_march_kernel(MarchArgs m
         if (tid < NT * 32 && tid < a.Cout) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < NWV; ++w) {
                 t1 += ring[((w * NT) * 32 + tid) * 2 + 0];
                 t2 += ring[((w * NT) * 32 + tid) * 2 + 1];
             }
@@ -825,6 +985,34 @@ size_t conv_lds_bytes(int CK, int NT) {
     return t > red ? t : red;
 }
 
+// Persistent pipelined launch: 256 * (workgroups per CU the LDS tile admits, at most 2) workgroups share the tiles evenly.
+template <typename K>
+int launch_persistent(K kernel, size_t lds, hipStream_t st, ConvArgs a, int ntiles) {
+    if (lds > 160 * 1024) return stx_set_error(STX_ERR_ARG, "conv3d: LDS tile of %zu B exceeds 160 KiB", lds);
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const int env = getenv("STX_CONV_PIPE_WGS") ? atoi(getenv("STX_CONV_PIPE_WGS")) : 0;
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    if (env > 0) per_cu = env;
+    int grid = 256 * per_cu;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(CONV_THREADS), lds, st, a, ntiles);
+    return 0;
+}
+
+template <int KS, int S>
+int conv_dispatch_pipe(const ConvArgs& a, int NT, int CK, int ntiles, hipStream_t st) {
+    const size_t lds = conv_lds_bytes<KS, S>(CK, NT);
+#define CONVP_CASE(NT_, CK_)                                                                                       \
+    if (NT == NT_ && CK == CK_)                                                                                    \
+        return launch_persistent(conv3d_pgemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, lds, st, a, ntiles);
+    CONVP_CASE(1, 32) CONVP_CASE(2, 32) CONVP_CASE(4, 16)
+    CONVP_CASE(1, 8) CONVP_CASE(2, 8) CONVP_CASE(4, 8)
+#undef CONVP_CASE
+    return -1;
+}
+
 template <int KS, int S>
 int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) {
     const size_t lds = conv_lds_bytes<KS, S>(CK, NT);
@@ -872,9 +1060,9 @@ static int march_mw(int W) {
 }
 // Workgroups of the march kernel: one per CU (its LDS ring admits only one), fewer for tiny volumes so that a
 // workgroup still gets a few planes per 2-plane prologue.
-static int march_wgs(long long units) {
+static int march_wgs(long long units, int per_cu) {
     static const int env = getenv("STX_MARCH_WGS") ? atoi(getenv("STX_MARCH_WGS")) : 0;
-    long long g = env > 0 ? env : 256;
+    long long g = env > 0 ? env : 256 * per_cu;
     if (g > units / 3) g = units / 3;
     return g < 1 ? 1 : (int)g;
 }
@@ -921,38 +1109,59 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         const int mw = march_mw(a.Wo);
         // whole-K waves (NQ = 4) are a tuning switch: measured 1.19 ms vs 1.07 ms for the K split on 32->32 L0
         static const int wholek_env = getenv("STX_MARCH_WHOLEK") ? 1 : 0;
-        const bool ksplit = !wholek_env || NT == 2;      // NT = 2 without the K split does not fit 256 VGPRs
-        const int nrb = ksplit ? 4 : 8;
+        // STX_MARCH_W4: 4-wave whole-K workgroups, two per CU (tuning switch, NT = 1 only)
+        static const int w4_env = getenv("STX_MARCH_W4") ? atoi(getenv("STX_MARCH_W4")) : 0;
+        const bool w4 = w4_env && NT == 1;
+        const bool ksplit = !w4 && (!wholek_env || NT == 2);      // NT = 2 without the K split does not fit 256 VGPRs
+        const int nrb = (ksplit || w4) ? 4 : 8;
         ma.c.nHt = stx_cdiv(a.Ho, nrb * 32 / mw);
         ma.c.nWt = stx_cdiv(a.Wo, mw);
         ma.ncols = B * ma.c.nHt * ma.c.nWt;
         STX_REQUIRE((long long)ma.ncols * a.Do < (1ll << 31), "conv3d_fwd: volume too large");
         static const int ablate = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
         ma.ablate = ablate;
-        const int nblk = march_wgs((long long)ma.ncols * a.Do);
+        const int nblk = march_wgs((long long)ma.ncols * a.Do, w4 ? 2 : 1);
         const size_t slot = (size_t)(nrb * 32 / mw + 2) * (mw + 2) * MARCH_VS;
         const size_t lds = ((size_t)3 * slot + (ksplit ? (size_t)4 * 2 * NT * 8 * 64 : 0)) * 4;
         hipStream_t st = (hipStream_t)stream;
-#define MARCH_LAUNCH(NT_, MW_, NQ_)                                                                                     \
+#define MARCH_LAUNCH_W(NT_, MW_, NQ_, NWV_)                                                                             \
     {                                                                                                                   \
-        hipFuncSetAttribute((const void*)conv3d_march_kernel<NT_, MW_, NQ_>,                                           \
+        hipFuncSetAttribute((const void*)conv3d_march_kernel<NT_, MW_, NQ_, NWV_>,                                     \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-        hipLaunchKernelGGL((conv3d_march_kernel<NT_, MW_, NQ_>), dim3(nblk), dim3(MARCH_THREADS), lds, st, ma);        \
+        hipLaunchKernelGGL((conv3d_march_kernel<NT_, MW_, NQ_, NWV_>), dim3(nblk), dim3(NWV_ * 64), lds, st, ma);      \
     }
-        if (NT == 2 && mw == 32) MARCH_LAUNCH(2, 32, 2)
+#define MARCH_LAUNCH(NT_, MW_, NQ_) MARCH_LAUNCH_W(NT_, MW_, NQ_, 8)
+        if (w4 && mw == 32) MARCH_LAUNCH_W(1, 32, 4, 4)
+        else if (w4) MARCH_LAUNCH_W(1, 16, 4, 4)
+        else if (NT == 2 && mw == 32) MARCH_LAUNCH(2, 32, 2)
         else if (NT == 2) MARCH_LAUNCH(2, 16, 2)
         else if (ksplit && mw == 32) MARCH_LAUNCH(1, 32, 2)
         else if (ksplit) MARCH_LAUNCH(1, 16, 2)
         else if (mw == 32) MARCH_LAUNCH(1, 32, 4)
         else MARCH_LAUNCH(1, 16, 4)
 #undef MARCH_LAUNCH
+#undef MARCH_LAUNCH_W
         return stx_check_launch("conv3d_fwd(march)");
     }
     // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: keep it to 8-channel K chunks (79 KB).
-    const int CK = (stride == 2) ? 8 : conv_pick_ck(Cin);
+    int CK = (stride == 2) ? 8 : conv_pick_ck(Cin);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    // persistent software-pipelined kernel for the 3x3x3 convolutions (STX_CONV_PIPE=0: first-generation kernel)
+    static const int pipe_env = getenv("STX_CONV_PIPE") ? atoi(getenv("STX_CONV_PIPE")) : 1;
+    if (pipe_env && ks == 3 && Cin % 8 == 0) {
+        int ckp = CK;
+        if (NT == 4 && ckp == 32) ckp = 16;      // 128 output channels: 16-channel chunks keep the operand buffers in registers
+        const long long nt_all = (long long)grid.x * B;
+        if (nt_all < (1ll << 31) && Cin % ckp == 0) {
+            // the stats slab has stx_conv3d_fwd_blocks() rows per batch item and this kernel writes row blockIdx.x
+            rc = (stride == 1) ? conv_dispatch_pipe<3, 1>(a, NT, ckp, (int)nt_all, st)
+                               : conv_dispatch_pipe<3, 2>(a, NT, ckp, (int)nt_all, st);
+            if (rc == 0) return stx_check_launch("conv3d_fwd(pipelined)");
+            if (rc > 0) return rc;
+        }
+    }
     if (ks == 3 && stride == 1) rc = conv_dispatch<3, 1>(a, NT, CK, grid, st);
     else if (ks == 3) rc = conv_dispatch<3, 2>(a, NT, CK, grid, st);
     else rc = conv_dispatch<1, 1>(a, NT, CK, grid, st);

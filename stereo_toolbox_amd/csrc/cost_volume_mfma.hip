@@ -65,32 +65,24 @@ __device__ __forceinline__ f32x4 cvm_zero4() {
 // dword writes of consecutive columns spread over 8 bank groups
 __host__ __device__ inline int cvm_cs(int Cc) { return ((Cc / 4) & 1) ? Cc + 8 : Cc + 4; }
 
-template <int CPG, int QPW, int NW>
-__global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a) {
-    constexpr int NTHR = NW * 64;
+template <int CPG, int QPW, int NCW, int NSW>
+__global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a) {
+    constexpr int NCTHR = NCW * 64, NSTHR = NSW * 64;
     constexpr int KK = CPG / 4;                                   // MFMA K steps per group
-    constexpr int NCL = (CVM_MAXCC * 48 + NTHR - 1) / NTHR;       // concat table elements per thread
+    constexpr int NCL = (CVM_MAXCC * 48 + NCTHR - 1) / NCTHR;     // concat table elements per compute thread
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xl = lane & 15, kq = lane >> 4;
     const int H = a.H, W = a.W, D = a.D, G = a.G, Cc = a.Cc;
     const int HW = H * W, Cg = G * CPG, CT = G + 2 * Cc;
     const int GQ = G >> 2, CQ = Cc >> 2, Q = CT >> 2;
     const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc);
-    float* stage = reinterpret_cast<float*>(smem);                 // [16 dd][DS]: voxel (dd, wl) at dd*DS + wl*VS
-    float* Lc_s = stage + (G ? CVM_T * DS : 0);                    // [16 cols][CS]
-    float* Rc_s = Lc_s + (Cc ? CVM_T * CS : 0);                    // [32 cols][CS]: column xi <-> x = w0 - d0 - 16 + xi
-    const float inv = 1.0f / (float)CPG;
+    // two LDS images (double buffer): [16 dd][DS] gwc voxels | [16 cols][CS] left table | [32 cols][CS] right table
+    const int IMG = G ? CVM_T * DS : 0, BUF = IMG + (Cc ? 48 * CS : 0);
+    float* lds = reinterpret_cast<float*>(smem);
 
     const long long wg = cvm_xcd_remap(blockIdx.x, gridDim.x);
     const int u0 = __builtin_amdgcn_readfirstlane((int)((long long)a.units * wg / gridDim.x));
     const int u1 = __builtin_amdgcn_readfirstlane((int)((long long)a.units * (wg + 1) / gridDim.x));
-
-    // operands of my quads: A = left tile, B0 = right tile of the unit's first x-tile, B1 = of the second one
-    float A[QPW][4][KK], B0[QPW][4][KK], B1[QPW][4][KK], nA[QPW][4][KK], nB0[QPW][4][KK];
-    float ct[NCL];
-    unsigned ctok = 0;                                             // validity bits of ct[]
-    bool n_okw = false, n_okx = false, okx1 = false;               // validity of the prefetched / the rotated tiles' columns
     auto decode = [&](int u, int& b, int& h, int& k, int& t) {
         t = u % a.nt;
         int r = u / a.nt;
@@ -99,10 +91,71 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
         h = r % H;
         b = r / H;
     };
+
+    if (wave >= NCW) {
+        // ================= store waves: flush the image of unit i while the compute waves build unit i+1.
+        // They never wait on a memory counter: the store stream of a CU is bounded by the hardware queues only.
+        const int stid = tid - NCTHR;
+        const int rowq = CVM_T * Q, total = CVM_T * rowq;
+        const size_t dstride = (size_t)HW * CT;
+        for (int u = u0; u < u1; ++u) {
+            __syncthreads();                                           // image (u - u0) & 1 is complete
+            int b, h, k, t;
+            decode(u, b, h, k, t);
+            const int w0 = t * CVM_T, d0 = k * CVM_T;
+            const float* stage = lds + ((u - u0) & 1) * BUF;
+            const int lc_off = IMG, rc_off = IMG + (Cc ? CVM_T * CS : 0);
+            float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
+            const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
+            for (int base = 0; base < total; base += 4 * NSTHR) {
+                float4 v[4];
+                int off[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = base + stid + j * NSTHR;
+                    const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
+                    const int rem = idx - dd * rowq;
+                    const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
+                    const int q = rem - wl * Q;
+                    const bool ok = idx < total && d0 + dd < D && w0 + wl < W;
+                    // LDS source of this quad: gwc image | left table | right table at x = w - d
+                    int src = dd * DS + wl * VS + 4 * q;
+                    const int sl = lc_off + wl * CS + 4 * (q - GQ);
+                    const int sr = rc_off + (wl - dd + CVM_T) * CS + 4 * (q - GQ - CQ);
+                    src = q < GQ ? src : (q < GQ + CQ ? sl : sr);
+                    float4 tv = stx_ld4(stage + (ok ? src : 0));
+                    if (a.mask_left && q >= GQ && q < GQ + CQ && w0 + wl < d0 + dd) tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (srow) {
+                        const float m = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
+                        tv.x *= m; tv.y *= m; tv.z *= m; tv.w *= m;
+                    }
+                    v[j] = tv;
+                    off[j] = ok ? dd * 65536 + rem : -1;             // (dd < 16, rem < 16 Q <= 1024)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (off[j] >= 0) {
+                        float* dst = vrow + (size_t)(off[j] >> 16) * dstride + 4 * (off[j] & 0xffff);
+                        if (a.nontemporal) stx_st4_nt(dst, v[j]);
+                        else stx_st4(dst, v[j]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ================= compute waves: feature tiles -> MFMA -> LDS image; concat features -> LDS tables
+    const int xl = lane & 15, kq = lane >> 4;
+    const float inv = 1.0f / (float)CPG;
+    // operands of my quads: A = left tile, B0 = right tile of the unit's first x-tile, B1 = of the second one
+    float A[QPW][4][KK], B0[QPW][4][KK], B1[QPW][4][KK], nA[QPW][4][KK], nB0[QPW][4][KK];
+    float ct[NCL];
+    unsigned ctok = 0;                                             // validity bits of ct[]
+    bool n_okw = false, n_okx = false, okx1 = false;               // validity of the prefetched / the rotated tiles' columns
     // loads of one 16-column tile of both gwc features for my quads: column base cw (left), cx (right).  Branch-free:
-    // out-of-image columns read a clamped address and are zeroed by a select, so the 16 loads of a quad issue back to back
-    // (the zeroing select is applied where the values are consumed -- applied here it would make the wave wait for
-    // its own prefetch right away)
+    // out-of-image columns read a clamped address and are zeroed by a select where the values are consumed (applied
+    // here it would make the wave wait for its own prefetch right away)
     auto load_tiles = [&](int b, int h, int cw, int cx, float (&dA)[QPW][4][KK], float (&dB)[QPW][4][KK], bool wantA,
                           bool& okw, bool& okx) {
         const int colw = cw + xl, colx = cx + xl;
@@ -111,7 +164,7 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
         const int cwc = colw < W ? colw : W - 1, cxc = okx ? colx : 0;
 #pragma unroll
         for (int j = 0; j < QPW; ++j) {
-            const int q = wave + j * NW;
+            const int q = wave + j * NCW;
             if (q < GQ) {                                          // wave-uniform
                 const size_t base = ((size_t)(b * Cg + 4 * q * CPG + kq) * H + h) * W;
                 const float* pl = a.Lg + base + cwc;
@@ -130,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
     auto load_tables = [&](int b, int h, int w0, int xbase) {        // concat features of the unit -> registers
 #pragma unroll
         for (int i = 0; i < NCL; ++i) {
-            const int idx = tid + i * NTHR;
+            const int idx = tid + i * NCTHR;
             const int c = idx / 48, col = idx - c * 48;
             const bool left = col < CVM_T;
             const int x = left ? w0 + col : xbase + (col - CVM_T);
@@ -140,10 +193,12 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
             if (ok) ctok |= 1u << i; else ctok &= ~(1u << i);
         }
     };
-    auto store_tables = [&]() {
+    auto store_tables = [&](float* img) {
+        float* Lc_s = img + IMG;
+        float* Rc_s = Lc_s + CVM_T * CS;
 #pragma unroll
         for (int i = 0; i < NCL; ++i) {
-            const int idx = tid + i * NTHR;
+            const int idx = tid + i * NCTHR;
             const int c = idx / 48, col = idx - c * 48;
             const float v = ((ctok >> i) & 1u) ? ct[i] : 0.f;
             if (c < Cc) {
@@ -173,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
     for (int u = u0; u < u1; ++u) {
         int b, h, k, t;
         decode(u, b, h, k, t);
-        const int w0 = t * CVM_T, d0 = k * CVM_T;
+        float* stage = lds + ((u - u0) & 1) * BUF;     // free: the store waves passed barrier (u - u0 - 1) after flushing it
         if (G) {
             // rotate: the previous unit's first x-tile is this unit's second one (same row and chunk, t-1);
             // at t = 0 the second tile lies left of the image: zeros
@@ -190,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
                     }
 #pragma unroll
             for (int j = 0; j < QPW; ++j) {
-                const int q = wave + j * NW;
+                const int q = wave + j * NCW;
                 if (q < GQ) {
                     f32x4 acc0[4], acc1[4];
 #pragma unroll
@@ -218,9 +273,9 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
                 }
             }
         }
-        if (Cc) store_tables();
-        // operands of the next unit: issued before this unit's stores, so that waiting for them later does not
-        // drain the store stream (loads and stores retire through one in-order counter)
+        if (Cc) store_tables(stage);
+        // operands of the next unit: in flight while the store waves flush this one (these waves issue loads only, so
+        // their memory counter never waits for a store)
         if (u + 1 < u1) {
             int nb, nh, nk, ntl;
             decode(u + 1, nb, nh, nk, ntl);
@@ -228,60 +283,18 @@ __global__ __launch_bounds__(NW * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a
             if (G) load_tiles(nb, nh, nw0, nx0, nA, nB0, true, n_okw, n_okx);
             if (Cc) load_tables(nb, nh, nw0, nx0 - CVM_T);
         }
-        __syncthreads();
-
-        // ---- flush: 16 d-rows x (16 voxels x Q float4), memory order; 4 LDS reads in flight per lane, branch-free
-        const int rowq = CVM_T * Q, total = CVM_T * rowq;
-        float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
-        const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
-        const size_t dstride = (size_t)HW * CT;
-        for (int base = 0; base < total; base += 4 * NTHR) {
-            float4 v[4];
-            int off[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = base + tid + j * NTHR;
-                const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
-                const int rem = idx - dd * rowq;
-                const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
-                const int q = rem - wl * Q;
-                const bool ok = idx < total && d0 + dd < D && w0 + wl < W;
-                // LDS source of this quad: gwc image | left table | right table at x = w - d
-                int src = dd * DS + wl * VS + 4 * q;
-                const int sl = (int)(Lc_s - stage) + wl * CS + 4 * (q - GQ);
-                const int sr = (int)(Rc_s - stage) + (wl - dd + CVM_T) * CS + 4 * (q - GQ - CQ);
-                src = q < GQ ? src : (q < GQ + CQ ? sl : sr);
-                float4 t = stx_ld4(stage + (ok ? src : 0));
-                if (a.mask_left && q >= GQ && q < GQ + CQ && w0 + wl < d0 + dd) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (srow) {
-                    const float m = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
-                    t.x *= m; t.y *= m; t.z *= m; t.w *= m;
-                }
-                v[j] = t;
-                off[j] = ok ? dd : -1;
-                if (ok) off[j] = dd * 65536 + rem;      // (dd < 16, rem < 16 Q <= 1024)
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (off[j] >= 0) {
-                    float* dst = vrow + (size_t)(off[j] >> 16) * dstride + 4 * (off[j] & 0xffff);
-                    if (a.nontemporal) stx_st4_nt(dst, v[j]);
-                    else stx_st4(dst, v[j]);
-                }
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                               // image (u - u0) & 1 handed to the store waves
     }
 }
 
-template <int CPG, int QPW, int NW>
+template <int CPG, int QPW, int NCW, int NSW>
 int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NW>;
+    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256 * wgs_per_cu;
     if (const char* e = getenv("STX_CV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force multi-unit runs
     if (grid > a.units) grid = a.units;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + NSW) * 64), lds, st, a);
     return stx_check_launch("cost_volume_fwd(mfma)");
 }
 
@@ -297,8 +310,8 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
     if (Q < 1 || Q > 64) return -1;
     const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc);
-    const size_t lds = ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? 48 * CS : 0)) * 4;
-    if (lds > 150 * 1024) return -1;
+    const size_t lds = 2 * ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? 48 * CS : 0)) * 4;      // double-buffered image
+    if (lds > 160 * 1024) return -1;
     CvmArgs a;
     a.Lg = Lg; a.Rg = Rg; a.Lc = Lc; a.Rc = Rc; a.scale = scale; a.vol = vol;
     a.B = B; a.H = H; a.W = W; a.D = D; a.G = G; a.Cc = Cc; a.mask_left = mask_left;
@@ -310,22 +323,30 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     a.magic_q = (unsigned)(0x100000000ULL / (unsigned)Q + 1);
     static const int nt_env = getenv("STX_CV_NT") ? atoi(getenv("STX_CV_NT")) : 0;
     a.nontemporal = nt_env;
-    // workgroups per CU: as many as the LDS image admits, at most 3 (tuning switch STX_CV_WGS)
+    // workgroups per CU: what the LDS images admit, at most 2 (tuning switch STX_CV_WGS); the wave layouts below are
+    // sized for <= 16 waves per workgroup
     static const int wgs_env = getenv("STX_CV_WGS") ? atoi(getenv("STX_CV_WGS")) : 0;
     int wgs = (int)((160 * 1024) / (lds + 1024));
-    wgs = wgs < 1 ? 1 : (wgs > 3 ? 3 : wgs);
+    wgs = wgs < 1 ? 1 : (wgs > 2 ? 2 : wgs);
     if (wgs_env > 0) wgs = wgs_env;
     const int qpw_env = getenv("STX_CV_QPW") ? atoi(getenv("STX_CV_QPW")) : 0;
+    static const int nsw_env = getenv("STX_CV_NSW") ? atoi(getenv("STX_CV_NSW")) : 0;
     hipStream_t st = (hipStream_t)stream;
-    // wave layout: one quad per wave up to 10 waves, two beyond (tuning switch STX_CV_QPW = 2: five fat waves)
-#define CVM_CASE(CPG_)                                                                     \
-    if (cpg == CPG_) {                                                                     \
-        if (GQ == 0) return cvm_launch<CPG_, 1, 8>(a, wgs, lds, st);                       \
-        if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4>(a, wgs, lds, st);       \
-        if (GQ <= 10 && qpw_env != 2) return cvm_launch<CPG_, 1, 10>(a, wgs, lds, st);     \
-        if (GQ <= 10) return cvm_launch<CPG_, 2, 5>(a, wgs, lds, st);                      \
-        if (GQ <= 20) return cvm_launch<CPG_, 2, 10>(a, wgs, lds, st);                     \
-        return -1;                                                                         \
+    // wave layouts <channels per group, quads per compute wave, compute waves, store waves>; STX_CV_QPW = 2 selects the
+    // fat-wave layouts, STX_CV_NSW = 4 / 8 fewer / more store waves (tuning switches)
+#define CVM_CASE(CPG_)                                                                               \
+    if (cpg == CPG_) {                                                                               \
+        if (GQ == 0) return nsw_env == 4 ? cvm_launch<CPG_, 1, 4, 4>(a, wgs, lds, st)                \
+                          : (nsw_env == 12 ? cvm_launch<CPG_, 1, 4, 12>(a, wgs, lds, st)             \
+                                           : cvm_launch<CPG_, 1, 4, 8>(a, wgs, lds, st));            \
+        if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4, 4>(a, wgs, lds, st);              \
+        if (GQ <= 10 && qpw_env != 2)                                                                \
+            return nsw_env == 4 ? cvm_launch<CPG_, 1, 10, 4>(a, wgs, lds, st)                        \
+                                : cvm_launch<CPG_, 1, 10, 6>(a, wgs, lds, st);                       \
+        if (GQ <= 10) return nsw_env == 4 ? cvm_launch<CPG_, 2, 5, 4>(a, wgs, lds, st)               \
+                                          : cvm_launch<CPG_, 2, 5, 8>(a, wgs, lds, st);              \
+        if (GQ <= 16) return cvm_launch<CPG_, 2, 8, 8>(a, wgs, lds, st);                             \
+        return -1;                                                                                   \
     }
     CVM_CASE(4) CVM_CASE(8) CVM_CASE(12) CVM_CASE(16)
 #undef CVM_CASE

@@ -34,24 +34,42 @@ CV_CASES = [
 ]
 
 
-@pytest.fixture(params=["default", "few_workgroups", "two_quads_per_wave"])
-def cv_variant(request, monkeypatch):
-    """Launch variants of the MFMA builder (environment switches read per call): the default grid gives small test
+def _cv_inputs(case):
+    B, Cg, G, Cc, H, W, D, ml = case
+    torch.manual_seed(1)
+    Lg = torch.randn(B, Cg, H, W) if G else None
+    Rg = torch.randn(B, Cg, H, W) if G else None
+    Lc = torch.randn(B, Cc, H, W) if Cc else None
+    Rc = torch.randn(B, Cc, H, W) if Cc else None
+    parts = []
+    if G:
+        parts.append(O.build_gwc_volume(Lg, Rg, D, G))
+    if Cc:
+        parts.append(O.build_concat_volume(Lc, Rc, D, mask_left=bool(ml)))
+    return Lg, Rg, Lc, Rc, torch.cat(parts, 1)
+
+
+@pytest.mark.parametrize("variant", ["few_workgroups", "fat_waves"])
+def test_cost_volume_fwd_launch_variants(be, variant, monkeypatch):
+    """Launch variants of the MFMA builder (environment switches read per call).  The default grid gives small test
     volumes one unit per workgroup; `few_workgroups` forces runs of several units per workgroup (register rotation of
-    the right-feature tiles along a row, row / chunk changes inside a run); `two_quads_per_wave` the fat-wave layout."""
-    if request.param == "few_workgroups":
-        monkeypatch.setenv("STX_CV_GRID", "2")
-    elif request.param == "two_quads_per_wave":
+    the right-feature tiles along a row, row / chunk changes inside a run, double-buffered LDS image); `fat_waves`
+    two channel quads per compute wave.  All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
+    monkeypatch.setenv("STX_CV_GRID", "2" if variant == "few_workgroups" else "3")
+    if variant == "fat_waves":
         monkeypatch.setenv("STX_CV_QPW", "2")
-        monkeypatch.setenv("STX_CV_GRID", "3")
-    return request.param
+    for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
+        B, Cg, G, Cc, H, W, D, ml = case
+        Lg, Rg, Lc, Rc, ref = _cv_inputs(case)
+        vol = be.empty(B, D, H, W, G + 2 * Cc)
+        be.call("stx_cost_volume_fwd", ptr(be.dev(Lg)), ptr(be.dev(Rg)), Cg, G, ptr(be.dev(Lc)), ptr(be.dev(Rc)), Cc, None,
+                ptr(vol), B, H, W, D, ml)
+        _close(ncdhw(vol), ref, rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("case", CV_CASES)
-def test_cost_volume_fwd_bwd(be, case, cv_variant):
+def test_cost_volume_fwd_bwd(be, case):
     B, Cg, G, Cc, H, W, D, ml = case
-    if cv_variant != "default" and be.name == "hip" and case is not CV_CASES[1]:
-        pytest.skip("launch variants are covered on the emulator; one GPU case each")
     torch.manual_seed(1)
     Lg = torch.randn(B, Cg, H, W) if G else None
     Rg = torch.randn(B, Cg, H, W) if G else None

@@ -142,7 +142,7 @@ def main():
         del x, out
 
     for name, lv, Cin, Cout in [("deconv_128_64_L2", 2, 128, 64), ("deconv_64_32_L1", 1, 64, 32)]:
-        if not want(name):
+        if not want(name + "_fwd"):
             continue
         D, Hh, Ww = L[lv]
         x = torch.randn(B, D, Hh, Ww, Cin, device=dev)

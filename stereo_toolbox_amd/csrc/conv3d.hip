@@ -1110,7 +1110,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         // whole-K waves (NQ = 4) are a tuning switch: measured 1.19 ms vs 1.07 ms for the K split on 32->32 L0
         static const int wholek_env = getenv("STX_MARCH_WHOLEK") ? 1 : 0;
         // STX_MARCH_W4: 4-wave whole-K workgroups, two per CU (tuning switch, NT = 1 only)
-        static const int w4_env = getenv("STX_MARCH_W4") ? atoi(getenv("STX_MARCH_W4")) : 0;
+        // (measured on 32->32 L0: 0.969 -> 0.932 ms; default on, STX_MARCH_W4=0 selects the 8-wave K-split kernel)
+        static const int w4_env = getenv("STX_MARCH_W4") ? atoi(getenv("STX_MARCH_W4")) : 1;
         const bool w4 = w4_env && NT == 1;
         const bool ksplit = !w4 && (!wholek_env || NT == 2);      // NT = 2 without the K split does not fit 256 VGPRs
         const int nrb = (ksplit || w4) ? 4 : 8;
@@ -1148,9 +1149,12 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    // persistent software-pipelined kernel for the 3x3x3 convolutions (STX_CONV_PIPE=0: first-generation kernel)
+    // Persistent software-pipelined kernel.  Its staging registers cost the second resident workgroup (254 VGPRs), so it
+    // wins only where the first-generation kernel overlaps poorly: measured (576x960 shapes, same session) 128->128 L2
+    // 0.283 -> 0.245 ms, stride-2 64->128 0.176 -> 0.154 ms, but 64->64 L1 0.470 -> 0.537 ms, 64->32 L0 2.13 -> 2.21 ms,
+    // stride-2 32->64 0.327 -> 0.353 ms.  Policy: 128 output channels only; STX_CONV_PIPE = 0 never / 2 always (tuning).
     static const int pipe_env = getenv("STX_CONV_PIPE") ? atoi(getenv("STX_CONV_PIPE")) : 1;
-    if (pipe_env && ks == 3 && Cin % 8 == 0) {
+    if ((pipe_env == 2 || (pipe_env == 1 && NT == 4)) && ks == 3 && Cin % 8 == 0) {
         int ckp = CK;
         if (NT == 4 && ckp == 32) ckp = 16;      // 128 output channels: 16-channel chunks keep the operand buffers in registers
         const long long nt_all = (long long)grid.x * B;

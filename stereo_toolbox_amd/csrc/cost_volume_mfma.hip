@@ -1,34 +1,42 @@
 // Cost-volume builder, second generation: group-wise correlation on the matrix cores, whole voxels staged in LDS,
-// the volume written as one uninterrupted stream of 1-KiB wave stores.
+// the volume written as one uninterrupted stream of 1-KiB wave stores by waves that never wait on memory.
 //
 // Replaces the same reference functions as cost_volume.hip (build_gwc_volume GwcNet/submodule.py:53-63,
 // build_concat_volume GwcNet/submodule.py:30-41 / PSMNet/stackhourglass.py:111-120 / ACVNet/submodule.py:180-191,
 // torch.cat gwcnet.py:180, softmax(att) * concat_volume acv.py:196) for every group configuration with 4, 8, 12 or
 // 16 channels per group (GwcNet / ACVNet: 320 ch in 40 groups; IGEV-style volumes: 96 ch in 8 groups) and for
-// concat-only volumes (PSMNet).
+// concat-only volumes (PSMNet), D' <= 96.
 //
 // Why.  The builder is HBM-bound on paper (516 MB per GwcNet_GC pair, 1 GFLOP), but the first-generation kernels were
-// VALU/LDS-latency-bound: one lane per voxel channel = ~25 instructions and 3 LDS reads per 256-byte voxel
-// (0.156 ms = 41 % of the HBM roofline).  Here the correlation of one image row is a banded batch of tiny GEMMs:
+// VALU/LDS-latency-bound: one lane per voxel channel = ~25 instructions and 3 LDS reads per 256-byte voxel, every
+// feature element re-staged once per 16-disparity chunk (0.156-0.175 ms = 37-41 % of the HBM roofline; a plain
+// 425 MB store stream reaches 6.6 TB/s on this chip, tools/ubench/store_stream.hip).
+// Here the correlation of one image row is a banded batch of tiny GEMMs:
 //   for group g:  C_g[w][x] = sum_{c in g} L[c][w] * R[c][x],   vol[d = w - x][w][g] = C_g[w][x] / cpg,  0 <= w - x < D'
-// A work UNIT is (b, h, 16 disparities d0.., 16 columns w0..).  Its x-range [w0 - d0 - 15, w0 - d0 + 15] lies in two
-// aligned 16-column tiles of R, so a wave computes, per group, two 16x16 tiles with v_mfma_f32_16x16x4_f32 (K = the
-// group's channels, exact fp32, k-ordered fmaf chain) and every lane keeps, of the two results it holds for a (w, x)
-// pair, the one whose d = w - x falls into the unit (lane (x, w): tile 0 if w_l >= x_l else tile 1).  The MFMA A/B
-// operands are ONE dword per lane, loaded straight from the NCHW features (64-byte row segments, L2-resident: every
-// feature row is re-read by the 3 d-chunks x 2 tiles that need it) -- no transposing LDS image of the features at all.
-// A wave owns QPW channel quads (4 groups each); the right tile of unit t is the left tile... of nothing: the second
-// R tile of unit (.., t) is the first R tile of unit (.., t-1), so walking t keeps it in registers (8 new loads for
-// L, 8 for R per quad and unit, issued one unit ahead).
 //
-// Data path of a unit:  MFMA -> select -> ds_write_b128 into an LDS image [16 d][16 w][G] of the gwc channels
-// (conflict-free: voxel stride G+4, d-row stride 16(G+4)+4 dwords) | concat features -> small LDS tables
-// [col][Cc] -> barrier -> FLUSH: all waves walk the unit's 16 x 16 voxels in memory order, one float4 per lane
-// (gwc quads from the image, left quads from the left table (masked), right quads from the right table at x = w - d;
-// optional attention scale), so a wave stores 1 KiB contiguous and a d-row of the unit is one 4-KiB run -> barrier.
-// Invalid entries (w < d, i.e. x < 0) are zero by construction: features left of the image are loaded as zeros.
-// Several workgroups per CU (48 KB of LDS each) run out of phase, so the store stream never pauses for the MFMA /
-// staging part of a unit.  Units are dealt in equal contiguous runs to exactly gridDim.x workgroups (no tail round).
+// Work decomposition.  A MACRO-UNIT is (b, h, 16 columns w0..): all D' disparities of one 16-column tile; it consists of
+// nd = D'/16 UNITS (16 disparities each).  The x-range of unit k, [w0 - 16k - 15, w0 - 16k + 15], lies in the aligned
+// 16-column tiles t-k and t-k-1 of R, so a macro-unit needs the left tile t and the right tiles t .. t-nd, and the next
+// macro-unit of the row needs ONE new left and ONE new right tile: the right tiles rotate through a register ring.
+// Every feature element is therefore loaded from memory exactly once per image row, straight into the MFMA operand
+// layout (one dword per lane, 64-byte row segments of the NCHW features) -- there is no transposing LDS image of the
+// features and no reliance on L2 reuse, and the loads of macro-unit m+1 are in flight during the nd units of m.
+//
+// Roles inside a workgroup (one per CU for the 64-channel volumes):
+//   * COMPUTE waves (one or two channel quads = 4 or 8 groups each): loads -> per unit and group two 16x16 tiles with
+//     v_mfma_f32_16x16x4_f32 (K = the group's channels, exact fp32, k-ordered fmaf chain) -> every lane keeps, of the
+//     two results it holds for a (w, x) pair, the one whose d = w - x falls into the unit (tile 0 if w_l >= x_l else
+//     tile 1) -> ds_write_b128 into an LDS image [16 d][16 w][G] (conflict-free: voxel stride G+4, d-row stride
+//     16(G+4)+4 dwords).  Concat features go through small LDS tables [column][Cc], once per macro-unit.
+//   * STORE waves: walk the image of the previous unit in memory order, one float4 per lane (gwc quads from the image,
+//     left quads from the left table (masked), right quads from the right table at x = w - d; optional attention
+//     scale): a wave stores 1 KiB contiguous, a d-row of a unit is one 4-KiB run.  They issue nothing but LDS reads
+//     and global stores and never wait on a memory counter, so the store stream of a CU is limited by the hardware
+//     queues only (loads and stores of a wave retire through one in-order counter: a wave that does both ends up
+//     draining its stores whenever it waits for a load).
+//   The LDS image is double buffered: one barrier per unit hands image i to the store waves while the compute waves
+//   build image i+1.  Invalid entries (w < d, i.e. x < 0) are zero by construction: tiles left of the image are zeros.
+// Macro-units are dealt in equal contiguous runs to exactly gridDim.x workgroups (no tail round).
 //
 // Roofline: HBM; algorithmic bytes = features once + volume once (516 464 640 B GwcNet_GC, 433 520 640 B
 // PSMNet concat, 576x960, D' = 48).
@@ -45,8 +53,9 @@ struct CvmArgs {
     const float *Lg, *Rg, *Lc, *Rc, *scale;
     float* vol;
     int B, H, W, D, G, Cc, mask_left;
-    int nd, nt, units;
+    int nd, nt, macros;             // d-chunks per macro-unit, w-tiles per row, B*H*nt
     unsigned magic_rowq, magic_q;   // ceil(2^32 / (16 Q)), ceil(2^32 / Q)
+    unsigned magic_tc;              // ceil(2^32 / table columns)
     int nontemporal;
 };
 
@@ -65,79 +74,85 @@ __device__ __forceinline__ f32x4 cvm_zero4() {
 // dword writes of consecutive columns spread over 8 bank groups
 __host__ __device__ inline int cvm_cs(int Cc) { return ((Cc / 4) & 1) ? Cc + 8 : Cc + 4; }
 
-template <int CPG, int QPW, int NCW, int NSW>
+// ND = compile-time bound of nd (register ring of ND + 1 right tiles)
+template <int CPG, int QPW, int NCW, int NSW, int ND>
 __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a) {
     constexpr int NCTHR = NCW * 64, NSTHR = NSW * 64;
     constexpr int KK = CPG / 4;                                   // MFMA K steps per group
-    constexpr int NCL = (CVM_MAXCC * 48 + NCTHR - 1) / NCTHR;     // concat table elements per compute thread
+    constexpr int TCMAX = CVM_T * (ND + 2);                        // table columns: 16 left + 16 (nd + 1) right
+    constexpr int NCL = (CVM_MAXCC * TCMAX + NCTHR - 1) / NCTHR;   // concat table elements per compute thread
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = a.H, W = a.W, D = a.D, G = a.G, Cc = a.Cc;
+    const int H = a.H, W = a.W, D = a.D, G = a.G, Cc = a.Cc, nd = a.nd;
     const int HW = H * W, Cg = G * CPG, CT = G + 2 * Cc;
     const int GQ = G >> 2, CQ = Cc >> 2, Q = CT >> 2;
     const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc);
-    // two LDS images (double buffer): [16 dd][DS] gwc voxels | [16 cols][CS] left table | [32 cols][CS] right table
-    const int IMG = G ? CVM_T * DS : 0, BUF = IMG + (Cc ? 48 * CS : 0);
+    const int TC = CVM_T * (nd + 2);                               // table columns in use
+    // LDS: two images [16 dd][DS] (double buffer over units) | two table sets [TC cols][CS] (double buffer over macros)
+    const int IMG = G ? CVM_T * DS : 0, TAB = Cc ? TC * CS : 0;
     float* lds = reinterpret_cast<float*>(smem);
+    float* tabs = lds + 2 * IMG;
 
     const long long wg = cvm_xcd_remap(blockIdx.x, gridDim.x);
-    const int u0 = __builtin_amdgcn_readfirstlane((int)((long long)a.units * wg / gridDim.x));
-    const int u1 = __builtin_amdgcn_readfirstlane((int)((long long)a.units * (wg + 1) / gridDim.x));
-    auto decode = [&](int u, int& b, int& h, int& k, int& t) {
-        t = u % a.nt;
-        int r = u / a.nt;
-        k = r % a.nd;
-        r /= a.nd;
+    const int m0 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * wg / gridDim.x));
+    const int m1 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * (wg + 1) / gridDim.x));
+    auto decode = [&](int m, int& b, int& h, int& t) {
+        t = m % a.nt;
+        const int r = m / a.nt;
         h = r % H;
         b = r / H;
     };
 
     if (wave >= NCW) {
-        // ================= store waves: flush the image of unit i while the compute waves build unit i+1.
-        // They never wait on a memory counter: the store stream of a CU is bounded by the hardware queues only.
+        // ================= store waves: flush the image of unit i while the compute waves build unit i+1
         const int stid = tid - NCTHR;
         const int rowq = CVM_T * Q, total = CVM_T * rowq;
         const size_t dstride = (size_t)HW * CT;
-        for (int u = u0; u < u1; ++u) {
-            __syncthreads();                                           // image (u - u0) & 1 is complete
-            int b, h, k, t;
-            decode(u, b, h, k, t);
-            const int w0 = t * CVM_T, d0 = k * CVM_T;
-            const float* stage = lds + ((u - u0) & 1) * BUF;
-            const int lc_off = IMG, rc_off = IMG + (Cc ? CVM_T * CS : 0);
-            float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
-            const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
-            for (int base = 0; base < total; base += 4 * NSTHR) {
-                float4 v[4];
-                int off[4];
+        int ui = 0;
+        for (int m = m0; m < m1; ++m) {
+            int b, h, t;
+            decode(m, b, h, t);
+            const int w0 = t * CVM_T;
+            const float* tab = tabs + ((m - m0) & 1) * TAB;          // left table at column 0, right table from column 16
+            for (int k = 0; k < nd; ++k, ++ui) {
+                __syncthreads();                                       // image ui & 1 is complete
+                const int d0 = k * CVM_T;
+                const float* stage = lds + (ui & 1) * IMG;
+                float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
+                const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
+                const int xi0 = CVM_T + CVM_T * (nd - k);              // table column of x = w0 - d0
+                for (int base = 0; base < total; base += 4 * NSTHR) {
+                    float4 v[4];
+                    int off[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = base + stid + j * NSTHR;
-                    const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
-                    const int rem = idx - dd * rowq;
-                    const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
-                    const int q = rem - wl * Q;
-                    const bool ok = idx < total && d0 + dd < D && w0 + wl < W;
-                    // LDS source of this quad: gwc image | left table | right table at x = w - d
-                    int src = dd * DS + wl * VS + 4 * q;
-                    const int sl = lc_off + wl * CS + 4 * (q - GQ);
-                    const int sr = rc_off + (wl - dd + CVM_T) * CS + 4 * (q - GQ - CQ);
-                    src = q < GQ ? src : (q < GQ + CQ ? sl : sr);
-                    float4 tv = stx_ld4(stage + (ok ? src : 0));
-                    if (a.mask_left && q >= GQ && q < GQ + CQ && w0 + wl < d0 + dd) tv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (srow) {
-                        const float m = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
-                        tv.x *= m; tv.y *= m; tv.z *= m; tv.w *= m;
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = base + stid + j * NSTHR;
+                        const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
+                        const int rem = idx - dd * rowq;
+                        const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
+                        const int q = rem - wl * Q;
+                        const bool ok = idx < total && d0 + dd < D && w0 + wl < W;
+                        // LDS source of this quad: gwc image | left table | right table at x = w - d
+                        const int sg = dd * DS + wl * VS + 4 * q;
+                        const int sl = wl * CS + 4 * (q - GQ);
+                        const int sr = (xi0 + wl - dd) * CS + 4 * (q - GQ - CQ);
+                        const float* src = q < GQ ? stage + sg : (q < GQ + CQ ? tab + sl : tab + sr);
+                        float4 tv = stx_ld4(ok ? src : lds);
+                        if (a.mask_left && q >= GQ && q < GQ + CQ && w0 + wl < d0 + dd) tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (srow) {
+                            const float mm = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
+                            tv.x *= mm; tv.y *= mm; tv.z *= mm; tv.w *= mm;
+                        }
+                        v[j] = tv;
+                        off[j] = ok ? dd * 65536 + rem : -1;             // (dd < 16, rem < 16 Q <= 1024)
                     }
-                    v[j] = tv;
-                    off[j] = ok ? dd * 65536 + rem : -1;             // (dd < 16, rem < 16 Q <= 1024)
-                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (off[j] >= 0) {
-                        float* dst = vrow + (size_t)(off[j] >> 16) * dstride + 4 * (off[j] & 0xffff);
-                        if (a.nontemporal) stx_st4_nt(dst, v[j]);
-                        else stx_st4(dst, v[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (off[j] >= 0) {
+                            float* dst = vrow + (size_t)(off[j] >> 16) * dstride + 4 * (off[j] & 0xffff);
+                            if (a.nontemporal) stx_st4_nt(dst, v[j]);
+                            else stx_st4(dst, v[j]);
+                        }
                     }
                 }
             }
@@ -145,155 +160,153 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
         return;
     }
 
-    // ================= compute waves: feature tiles -> MFMA -> LDS image; concat features -> LDS tables
+    // ================= compute waves
     const int xl = lane & 15, kq = lane >> 4;
     const float inv = 1.0f / (float)CPG;
-    // operands of my quads: A = left tile, B0 = right tile of the unit's first x-tile, B1 = of the second one
-    float A[QPW][4][KK], B0[QPW][4][KK], B1[QPW][4][KK], nA[QPW][4][KK], nB0[QPW][4][KK];
+    // operands of my quads: A = left tile t, Rt[j] = right tile t - j (register ring), nA / nR = prefetched tile t + 1
+    float A[QPW][4][KK], Rt[ND + 1][QPW][4][KK], nA[QPW][4][KK], nR[QPW][4][KK];
     float ct[NCL];
     unsigned ctok = 0;                                             // validity bits of ct[]
-    bool n_okw = false, n_okx = false, okx1 = false;               // validity of the prefetched / the rotated tiles' columns
-    // loads of one 16-column tile of both gwc features for my quads: column base cw (left), cx (right).  Branch-free:
-    // out-of-image columns read a clamped address and are zeroed by a select where the values are consumed (applied
-    // here it would make the wave wait for its own prefetch right away)
-    auto load_tiles = [&](int b, int h, int cw, int cx, float (&dA)[QPW][4][KK], float (&dB)[QPW][4][KK], bool wantA,
-                          bool& okw, bool& okx) {
-        const int colw = cw + xl, colx = cx + xl;
-        if (wantA) okw = colw < W;
-        okx = colx >= 0 && colx < W;
-        const int cwc = colw < W ? colw : W - 1, cxc = okx ? colx : 0;
+    bool n_okw = false, n_okx = false;                             // validity of the prefetched tiles' columns
+    // one 16-column tile of the gwc features for my quads, branch-free: out-of-image columns read a clamped address and
+    // are zeroed by a select where the values are consumed (a select here would make the wave wait for its own prefetch)
+    auto load_tile = [&](const float* __restrict__ F, int b, int h, int c0, float (&dst)[QPW][4][KK], bool& ok) {
+        const int col = c0 + xl;
+        ok = col >= 0 && col < W;
+        const int cc = ok ? col : 0;
 #pragma unroll
         for (int j = 0; j < QPW; ++j) {
             const int q = wave + j * NCW;
             if (q < GQ) {                                          // wave-uniform
-                const size_t base = ((size_t)(b * Cg + 4 * q * CPG + kq) * H + h) * W;
-                const float* pl = a.Lg + base + cwc;
-                const float* pr = a.Rg + base + cxc;
+                const float* p = F + ((size_t)(b * Cg + 4 * q * CPG + kq) * H + h) * W + cc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) {
-                        const size_t o = (size_t)(g * CPG + 4 * kk) * HW;
-                        if (wantA) dA[j][g][kk] = pl[o];
-                        dB[j][g][kk] = pr[o];
-                    }
+                    for (int kk = 0; kk < KK; ++kk) dst[j][g][kk] = p[(size_t)(g * CPG + 4 * kk) * HW];
             }
         }
     };
-    auto load_tables = [&](int b, int h, int w0, int xbase) {        // concat features of the unit -> registers
+    auto mask_tile = [&](float (&dst)[QPW][4][KK], const float (&src)[QPW][4][KK], bool ok) {
+#pragma unroll
+        for (int j = 0; j < QPW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) dst[j][g][kk] = ok ? src[j][g][kk] : 0.f;
+    };
+    // concat features of a macro-unit -> registers: columns [w0, w0+16) of Lc and [w0 - 16 nd, w0 + 16) of Rc
+    auto load_tables = [&](int b, int h, int w0) {
 #pragma unroll
         for (int i = 0; i < NCL; ++i) {
             const int idx = tid + i * NCTHR;
-            const int c = idx / 48, col = idx - c * 48;
+            const int c = (int)__umulhi((unsigned)idx, a.magic_tc), col = idx - c * TC;
             const bool left = col < CVM_T;
-            const int x = left ? w0 + col : xbase + (col - CVM_T);
+            const int x = left ? w0 + col : w0 - CVM_T * nd + (col - CVM_T);
             const bool ok = c < Cc && x >= 0 && x < W;
             const float* src = left ? a.Lc : a.Rc;
             ct[i] = src[((size_t)(b * Cc + (c < Cc ? c : 0)) * H + h) * W + (ok ? x : 0)];
             if (ok) ctok |= 1u << i; else ctok &= ~(1u << i);
         }
     };
-    auto store_tables = [&](float* img) {
-        float* Lc_s = img + IMG;
-        float* Rc_s = Lc_s + CVM_T * CS;
+    auto store_tables = [&](float* tab) {
 #pragma unroll
         for (int i = 0; i < NCL; ++i) {
             const int idx = tid + i * NCTHR;
-            const int c = idx / 48, col = idx - c * 48;
-            const float v = ((ctok >> i) & 1u) ? ct[i] : 0.f;
-            if (c < Cc) {
-                if (col < CVM_T) Lc_s[col * CS + c] = v;
-                else Rc_s[(col - CVM_T) * CS + c] = v;
-            }
+            const int c = (int)__umulhi((unsigned)idx, a.magic_tc), col = idx - c * TC;
+            if (c < Cc) tab[col * CS + c] = ((ctok >> i) & 1u) ? ct[i] : 0.f;
         }
     };
 
-    if (u0 < u1) {
-        int b, h, k, t;
-        decode(u0, b, h, k, t);
-        const int w0 = t * CVM_T, x0 = w0 - k * CVM_T;
+    if (m0 < m1) {
+        int b, h, t;
+        decode(m0, b, h, t);
+        const int w0 = t * CVM_T;
         if (G) {
-            load_tiles(b, h, w0, x0 - CVM_T, nA, B0, false, n_okw, okx1);   // second x-tile of the first unit -> (future) B1
+            // the ring of the first macro-unit: tiles t-1 .. t-ND straight into Rt[1..ND] (zeros left of the image)
 #pragma unroll
-            for (int j = 0; j < QPW; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) B0[j][g][kk] = okx1 ? B0[j][g][kk] : 0.f;
-            load_tiles(b, h, w0, x0, nA, nB0, true, n_okw, n_okx);
+            for (int j = 1; j <= ND; ++j) {
+                bool ok;
+                load_tile(a.Rg, b, h, w0 - CVM_T * j, Rt[j], ok);
+                mask_tile(Rt[j], Rt[j], ok);
+            }
+            load_tile(a.Lg, b, h, w0, nA, n_okw);
+            load_tile(a.Rg, b, h, w0, nR, n_okx);
         }
-        if (Cc) load_tables(b, h, w0, x0 - CVM_T);
+        if (Cc) load_tables(b, h, w0);
     }
 
-    for (int u = u0; u < u1; ++u) {
-        int b, h, k, t;
-        decode(u, b, h, k, t);
-        float* stage = lds + ((u - u0) & 1) * BUF;     // free: the store waves passed barrier (u - u0 - 1) after flushing it
+    int ui = 0;
+    for (int m = m0; m < m1; ++m) {
+        int b, h, t;
+        decode(m, b, h, t);
         if (G) {
-            // rotate: the previous unit's first x-tile is this unit's second one (same row and chunk, t-1);
-            // at t = 0 the second tile lies left of the image: zeros
-            const bool fresh = (u == u0);
+            if (m > m0) {
+                // rotate the ring; a new image row (t = 0) starts with every older tile left of the image
 #pragma unroll
-            for (int j = 0; j < QPW; ++j)
+                for (int j = ND; j >= 1; --j) mask_tile(Rt[j], Rt[j - 1], t != 0);
+            }
+            mask_tile(A, nA, n_okw);
+            mask_tile(Rt[0], nR, n_okx);
+        }
+        if (Cc) store_tables(tabs + ((m - m0) & 1) * TAB);   // free: the store waves finished macro m-2 before barrier ui-1
+        if (m + 1 < m1) {                                    // tiles of the next macro-unit: in flight during the nd units of this one
+            int nb, nh, ntl;
+            decode(m + 1, nb, nh, ntl);
+            if (G) {
+                load_tile(a.Lg, nb, nh, ntl * CVM_T, nA, n_okw);
+                load_tile(a.Rg, nb, nh, ntl * CVM_T, nR, n_okx);
+            }
+            if (Cc) load_tables(nb, nh, ntl * CVM_T);
+        }
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < ND; ++k) {
+            if (k < nd) {
+                float* stage = lds + (ui & 1) * IMG;           // free: the store waves passed barrier ui-1 after flushing it
+                if (G) {
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) {
-                        B1[j][g][kk] = (t == 0 && !fresh) ? 0.f : B0[j][g][kk];
-                        A[j][g][kk] = n_okw ? nA[j][g][kk] : 0.f;
-                        B0[j][g][kk] = n_okx ? nB0[j][g][kk] : 0.f;
-                    }
+                    for (int j = 0; j < QPW; ++j) {
+                        const int q = wave + j * NCW;
+                        if (q < GQ) {
+                            f32x4 acc0[4], acc1[4];
 #pragma unroll
-            for (int j = 0; j < QPW; ++j) {
-                const int q = wave + j * NCW;
-                if (q < GQ) {
-                    f32x4 acc0[4], acc1[4];
+                            for (int g = 0; g < 4; ++g) { acc0[g] = cvm_zero4(); acc1[g] = cvm_zero4(); }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) { acc0[g] = cvm_zero4(); acc1[g] = cvm_zero4(); }
+                            for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk)
+                                for (int g = 0; g < 4; ++g) {
+                                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], Rt[k][j][g][kk], acc0[g], 0, 0, 0);
+                                    acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], Rt[k + 1][j][g][kk], acc1[g], 0, 0, 0);
+                                }
+                            // lane holds C[w_l = 4 kq + r][x_l = xl] of both tiles: d - 16k = w_l - x_l (tile t-k) or + 16 (tile t-k-1)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], B0[j][g][kk], acc0[g], 0, 0, 0);
-                            acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], B1[j][g][kk], acc1[g], 0, 0, 0);
+                            for (int r = 0; r < 4; ++r) {
+                                const int wl = 4 * kq + r;
+                                const int dd = (wl - xl) & (CVM_T - 1);
+                                const bool t0 = wl >= xl;
+                                float4 v;
+                                v.x = (t0 ? acc0[0][r] : acc1[0][r]) * inv;
+                                v.y = (t0 ? acc0[1][r] : acc1[1][r]) * inv;
+                                v.z = (t0 ? acc0[2][r] : acc1[2][r]) * inv;
+                                v.w = (t0 ? acc0[3][r] : acc1[3][r]) * inv;
+                                stx_st4(stage + dd * DS + wl * VS + 4 * q, v);
+                            }
                         }
-                    // lane holds C[w_l = 4 kq + r][x_l = xl] of both tiles: d - d0 = w_l - x_l (tile 0) or + 16 (tile 1)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int wl = 4 * kq + r;
-                        const int dd = (wl - xl) & (CVM_T - 1);
-                        const bool t0 = wl >= xl;
-                        float4 v;
-                        v.x = (t0 ? acc0[0][r] : acc1[0][r]) * inv;
-                        v.y = (t0 ? acc0[1][r] : acc1[1][r]) * inv;
-                        v.z = (t0 ? acc0[2][r] : acc1[2][r]) * inv;
-                        v.w = (t0 ? acc0[3][r] : acc1[3][r]) * inv;
-                        stx_st4(stage + dd * DS + wl * VS + 4 * q, v);
                     }
                 }
+                __syncthreads();                                   // image ui & 1 handed to the store waves
+                ++ui;
             }
         }
-        if (Cc) store_tables(stage);
-        // operands of the next unit: in flight while the store waves flush this one (these waves issue loads only, so
-        // their memory counter never waits for a store)
-        if (u + 1 < u1) {
-            int nb, nh, nk, ntl;
-            decode(u + 1, nb, nh, nk, ntl);
-            const int nw0 = ntl * CVM_T, nx0 = nw0 - nk * CVM_T;
-            if (G) load_tiles(nb, nh, nw0, nx0, nA, nB0, true, n_okw, n_okx);
-            if (Cc) load_tables(nb, nh, nw0, nx0 - CVM_T);
-        }
-        __syncthreads();                                               // image (u - u0) & 1 handed to the store waves
     }
 }
 
-template <int CPG, int QPW, int NCW, int NSW>
+template <int CPG, int QPW, int NCW, int NSW, int ND>
 int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW>;
+    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256 * wgs_per_cu;
     if (const char* e = getenv("STX_CV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force multi-unit runs
-    if (grid > a.units) grid = a.units;
+    if (grid > a.macros) grid = a.macros;
     hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + NSW) * 64), lds, st, a);
     return stx_check_launch("cost_volume_fwd(mfma)");
 }
@@ -309,19 +322,24 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
     if (Q < 1 || Q > 64) return -1;
-    const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc);
-    const size_t lds = 2 * ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? 48 * CS : 0)) * 4;      // double-buffered image
+    const int nd = stx_cdiv(D, CVM_T);
+    if (nd > 6) return -1;
+    const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc), TC = CVM_T * (nd + 2);
+    const size_t lds = 2 * ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? TC * CS : 0)) * 4;      // double-buffered image + tables
     if (lds > 160 * 1024) return -1;
     CvmArgs a;
     a.Lg = Lg; a.Rg = Rg; a.Lc = Lc; a.Rc = Rc; a.scale = scale; a.vol = vol;
     a.B = B; a.H = H; a.W = W; a.D = D; a.G = G; a.Cc = Cc; a.mask_left = mask_left;
-    a.nd = stx_cdiv(D, CVM_T); a.nt = stx_cdiv(W, CVM_T);
-    const long long units = (long long)B * H * a.nd * a.nt;
-    if (units >= (1ll << 31) || (long long)B * (Cg > Cc ? Cg : Cc) * H * W >= (1ll << 31)) return -1;
-    a.units = (int)units;
+    a.nd = nd; a.nt = stx_cdiv(W, CVM_T);
+    const long long macros = (long long)B * H * a.nt;
+    if (macros >= (1ll << 31) || (long long)B * (Cg > Cc ? Cg : Cc) * H * W >= (1ll << 31)) return -1;
+    a.macros = (int)macros;
     a.magic_rowq = (unsigned)(0x100000000ULL / (unsigned)(CVM_T * Q) + 1);
     a.magic_q = (unsigned)(0x100000000ULL / (unsigned)Q + 1);
-    static const int nt_env = getenv("STX_CV_NT") ? atoi(getenv("STX_CV_NT")) : 0;
+    a.magic_tc = (unsigned)(0x100000000ULL / (unsigned)TC + 1);
+    // non-temporal stores keep the streamed volume from evicting the (small, re-read) feature rows from L2:
+    // measured 0.173 -> 0.141 ms on the GwcNet_GC build; STX_CV_NT=0 switches them off (tuning)
+    static const int nt_env = getenv("STX_CV_NT") ? atoi(getenv("STX_CV_NT")) : 1;
     a.nontemporal = nt_env;
     // workgroups per CU: what the LDS images admit, at most 2 (tuning switch STX_CV_WGS); the wave layouts below are
     // sized for <= 16 waves per workgroup
@@ -332,23 +350,27 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     const int qpw_env = getenv("STX_CV_QPW") ? atoi(getenv("STX_CV_QPW")) : 0;
     static const int nsw_env = getenv("STX_CV_NSW") ? atoi(getenv("STX_CV_NSW")) : 0;
     hipStream_t st = (hipStream_t)stream;
-    // wave layouts <channels per group, quads per compute wave, compute waves, store waves>; STX_CV_QPW = 2 selects the
-    // fat-wave layouts, STX_CV_NSW = 4 / 8 fewer / more store waves (tuning switches)
-#define CVM_CASE(CPG_)                                                                               \
-    if (cpg == CPG_) {                                                                               \
-        if (GQ == 0) return nsw_env == 4 ? cvm_launch<CPG_, 1, 4, 4>(a, wgs, lds, st)                \
-                          : (nsw_env == 12 ? cvm_launch<CPG_, 1, 4, 12>(a, wgs, lds, st)             \
-                                           : cvm_launch<CPG_, 1, 4, 8>(a, wgs, lds, st));            \
-        if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4, 4>(a, wgs, lds, st);              \
+    // wave layouts <channels per group, quads per compute wave, compute waves, store waves, ring bound>; STX_CV_QPW = 2
+    // selects the fat-wave layouts, STX_CV_NSW = 4 fewer store waves (tuning switches)
+#define CVM_LAYOUT(CPG_, ND_)                                                                        \
+    {                                                                                                \
+        if (GQ == 0) return nsw_env == 4 ? cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st)           \
+                                         : cvm_launch<CPG_, 1, 4, 8, ND_>(a, wgs, lds, st);          \
+        if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st);         \
         if (GQ <= 10 && qpw_env != 2)                                                                \
-            return nsw_env == 4 ? cvm_launch<CPG_, 1, 10, 4>(a, wgs, lds, st)                        \
-                                : cvm_launch<CPG_, 1, 10, 6>(a, wgs, lds, st);                       \
-        if (GQ <= 10) return nsw_env == 4 ? cvm_launch<CPG_, 2, 5, 4>(a, wgs, lds, st)               \
-                                          : cvm_launch<CPG_, 2, 5, 8>(a, wgs, lds, st);              \
-        if (GQ <= 16) return cvm_launch<CPG_, 2, 8, 8>(a, wgs, lds, st);                             \
+            return nsw_env == 4 ? cvm_launch<CPG_, 1, 10, 4, ND_>(a, wgs, lds, st)                   \
+                                : cvm_launch<CPG_, 1, 10, 6, ND_>(a, wgs, lds, st);                  \
+        if (GQ <= 10) return nsw_env == 4 ? cvm_launch<CPG_, 2, 5, 4, ND_>(a, wgs, lds, st)          \
+                                          : cvm_launch<CPG_, 2, 5, 8, ND_>(a, wgs, lds, st);         \
+        if (GQ <= 16) return cvm_launch<CPG_, 2, 8, 8, ND_>(a, wgs, lds, st);                        \
         return -1;                                                                                   \
+    }
+#define CVM_CASE(CPG_)                                          \
+    if (cpg == CPG_) {                                          \
+        if (nd <= 3) CVM_LAYOUT(CPG_, 3) else CVM_LAYOUT(CPG_, 6) \
     }
     CVM_CASE(4) CVM_CASE(8) CVM_CASE(12) CVM_CASE(16)
 #undef CVM_CASE
+#undef CVM_LAYOUT
     return -1;
 }

@@ -31,6 +31,7 @@ CV_CASES = [
     (1, 96, 8, 0, 2, 50, 20, 1),      # IGEV-style initial volume: 12 channels per group (igev_stereo.py:206)
     (1, 64, 4, 8, 2, 35, 9, 1),       # 16 channels per group
     (1, 32, 8, 0, 2, 33, 17, 1),      # 4 channels per group
+    (1, 32, 4, 4, 1, 100, 80, 1),     # D' = 80: five 16-disparity units per macro-unit (long register ring)
 ]
 
 

@@ -157,6 +157,15 @@ int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const flo
                      const float* gamma2, const float* sums, float* dz1, float* dz2, float* gout, long long nvox, int C,
                      int relu, void* stream);
 
+/* ---- Evaluation-path input step on the device --------------------------------------------------------
+ * pad_to_2x (datasets/data_augmentation/__init__.py:57-80: zero padding on top and to the right, to multiples of 96)
+ * + get_transform (datasets/utils.py:62-69: torchvision ToTensor and Normalize) of one view, fused:
+ *   img uint8 [B][H][W][3] -> out fp32 [B][3][Hp][Wp],  out = ((inside ? img : 0) / 255 - mean[c]) / std[c],
+ * top = Hp - H rows of padding above the image, Wp - W columns to its right; mean3 / std3 are HOST arrays of 3 floats.
+ * Bit-identical to the reference arithmetic (IEEE fp32 division by 255, subtraction, division by std). */
+int stx_pad_normalize_u8(const unsigned char* img, float* out, int B, int H, int W, int Hp, int Wp, int top,
+                         const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

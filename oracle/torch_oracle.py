@@ -599,3 +599,51 @@ def smooth_l1_multi(preds, gt, maxdisp, weights):
         p = p.squeeze(1) if p.dim() == 4 else p
         loss = loss + w * F.smooth_l1_loss(p[mask], gt[mask], reduction="mean")
     return loss
+
+
+# ----------------------------------------------------------------------------- evaluation-path input step
+def pad_to_2x(left, right, disp=None, mask=None, scale=96):
+    """datasets/data_augmentation/__init__.py:57-80 on torch tensors: left/right [H,W,C] zero-padded on TOP and to the
+    RIGHT up to multiples of 96; disp [H,W] (disparity) or [D,H,W] (distribution) and mask [H,W] likewise."""
+    H, W, _ = left.shape
+    top = int(math.ceil(H / scale) * scale - H)
+    rp = int(math.ceil(W / scale) * scale - W)
+    left = F.pad(left, (0, 0, 0, rp, top, 0))
+    right = F.pad(right, (0, 0, 0, rp, top, 0))
+    if disp is not None:
+        disp = F.pad(disp, (0, rp, top, 0))
+    if mask is not None:
+        assert disp.dim() == 2
+        mask = F.pad(mask, (0, rp, top, 0))
+    return left, right, disp, mask
+
+
+def to_tensor_normalize(img_u8, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """datasets/utils.py:62-69 `get_transform()` = torchvision.transforms.ToTensor + Normalize.  torchvision is a
+    third-party dependency of the reference (setup.py:24, no version pinned) that is absent from this image; its
+    published algorithm is restated: ToTensor = HWC uint8 -> CHW float32 `.div(255)`; Normalize =
+    `tensor.sub_(mean[:,None,None]).div_(std[:,None,None])` with mean / std as float32 tensors.  [H,W,3] -> [3,H,W]."""
+    t = img_u8.permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    m = torch.as_tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+    s = torch.as_tensor(std, dtype=torch.float32).view(-1, 1, 1)
+    return t.sub_(m).div_(s)
+
+
+def prepare_view(img_u8):
+    """pad_to_2x followed by get_transform on one uint8 [H,W,3] view (what the datasets' test branch does)."""
+    padded, _, _, _ = pad_to_2x(img_u8, img_u8)
+    return to_tensor_normalize(padded)
+
+
+# ----------------------------------------------------------------------------- IGEV-family initial volume (SURVEY 8f rank 4)
+def igev_init_volume(match_left, match_right, maxdisp):
+    """IGEVStereo/igev_stereo.py:206: `build_gwc_volume(match_left, match_right, max_disp // 4, 8)` on the 96-channel
+    matching features (12 channels per group); IGEVStereo/submodule.py:153-171 is the same arithmetic as GwcNet's."""
+    return build_gwc_volume(match_left, match_right, maxdisp // 4, 8)
+
+
+def igev_init_disparity(cost, maxdisp):
+    """igev_stereo.py:211-212: prob = softmax(classifier(volume).squeeze(1), dim=1); init_disp =
+    disparity_regression(prob, max_disp // 4) at 1/4 resolution, keepdim (IGEVStereo/submodule.py:221-225)."""
+    prob = F.softmax(cost.squeeze(1), dim=1)
+    return disparity_regression(prob, maxdisp // 4, keepdim=True)

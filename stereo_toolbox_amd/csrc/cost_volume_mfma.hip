@@ -104,10 +104,31 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     };
 
     if (wave >= NCW) {
-        // ================= store waves: flush the image of unit i while the compute waves build unit i+1
+        // ================= store waves: flush the image of unit i while the compute waves build unit i+1.
+        // Everything that does not depend on the unit is computed once per lane: slot s of a lane is float4 number
+        // stid + s * NSTHR of the unit's 16 x 16 voxels in memory order -> (dd, wl, quad), its LDS source (gwc image /
+        // left table / right table) and its offset in the volume.  A unit then costs a lane one LDS read, a few
+        // selects and one 16-byte store per slot.
+        constexpr int NSLOT = (CVM_T * CVM_T * 16 + NSTHR - 1) / NSTHR;      // Q <= 16 (checked by the host)
         const int stid = tid - NCTHR;
         const int rowq = CVM_T * Q, total = CVM_T * rowq;
         const size_t dstride = (size_t)HW * CT;
+        int pk[NSLOT], soff[NSLOT];
+        unsigned goff[NSLOT];
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int idx = stid + sl * NSTHR;
+            const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
+            const int rem = idx - dd * rowq;
+            const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
+            const int q = rem - wl * Q;
+            const int ty = q < GQ ? 0 : (q < GQ + CQ ? 1 : 2);
+            const bool live = idx < total;
+            pk[sl] = live ? ((ty << 16) | (dd << 8) | wl) : -1;
+            soff[sl] = ty == 0 ? dd * DS + wl * VS + 4 * q
+                               : (ty == 1 ? wl * CS + 4 * (q - GQ) : (wl - dd) * CS + 4 * (q - GQ - CQ));
+            goff[sl] = (unsigned)((size_t)dd * dstride + 4 * (size_t)rem);   // < 2^32 floats (checked by the host)
+        }
         int ui = 0;
         for (int m = m0; m < m1; ++m) {
             int b, h, t;
@@ -118,41 +139,30 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                 __syncthreads();                                       // image ui & 1 is complete
                 const int d0 = k * CVM_T;
                 const float* stage = lds + (ui & 1) * IMG;
+                const float* tabr = tab + (CVM_T + CVM_T * (nd - k)) * CS;   // right-table column of x = w0 - d0
                 float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
                 const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
-                const int xi0 = CVM_T + CVM_T * (nd - k);              // table column of x = w0 - d0
-                for (int base = 0; base < total; base += 4 * NSTHR) {
-                    float4 v[4];
-                    int off[4];
+                const int dlim = D - d0, wlim = W - w0, mthr = a.mask_left ? d0 - w0 : -1000;
+                float4 v[NSLOT];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int idx = base + stid + j * NSTHR;
-                        const int dd = (int)__umulhi((unsigned)idx, a.magic_rowq);
-                        const int rem = idx - dd * rowq;
-                        const int wl = (Q == 1) ? rem : (int)__umulhi((unsigned)rem, a.magic_q);   // (2^32 / 1 does not fit the magic)
-                        const int q = rem - wl * Q;
-                        const bool ok = idx < total && d0 + dd < D && w0 + wl < W;
-                        // LDS source of this quad: gwc image | left table | right table at x = w - d
-                        const int sg = dd * DS + wl * VS + 4 * q;
-                        const int sl = wl * CS + 4 * (q - GQ);
-                        const int sr = (xi0 + wl - dd) * CS + 4 * (q - GQ - CQ);
-                        const float* src = q < GQ ? stage + sg : (q < GQ + CQ ? tab + sl : tab + sr);
-                        float4 tv = stx_ld4(ok ? src : lds);
-                        if (a.mask_left && q >= GQ && q < GQ + CQ && w0 + wl < d0 + dd) tv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (srow) {
-                            const float mm = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
-                            tv.x *= mm; tv.y *= mm; tv.z *= mm; tv.w *= mm;
-                        }
-                        v[j] = tv;
-                        off[j] = ok ? dd * 65536 + rem : -1;             // (dd < 16, rem < 16 Q <= 1024)
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    const int info = pk[sl], ty = info >> 16, dd = (info >> 8) & 0xff, wl = info & 0xff;
+                    const bool ok = info >= 0 && dd < dlim && wl < wlim;
+                    const float* bp = ty == 0 ? stage : (ty == 1 ? tab : tabr);
+                    float4 tv = stx_ld4(ok ? bp + soff[sl] : lds);
+                    if (ty == 1 && wl - dd < mthr) tv = make_float4(0.f, 0.f, 0.f, 0.f);   // left half masked where w < d
+                    if (srow) {
+                        const float mm = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
+                        tv.x *= mm; tv.y *= mm; tv.z *= mm; tv.w *= mm;
                     }
+                    v[sl] = tv;
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (off[j] >= 0) {
-                            float* dst = vrow + (size_t)(off[j] >> 16) * dstride + 4 * (off[j] & 0xffff);
-                            if (a.nontemporal) stx_st4_nt(dst, v[j]);
-                            else stx_st4(dst, v[j]);
-                        }
+                for (int sl = 0; sl < NSLOT; ++sl) {
+                    const int info = pk[sl], dd = (info >> 8) & 0xff, wl = info & 0xff;
+                    if (info >= 0 && dd < dlim && wl < wlim) {
+                        if (a.nontemporal) stx_st4_nt(vrow + goff[sl], v[sl]);
+                        else stx_st4(vrow + goff[sl], v[sl]);
                     }
                 }
             }
@@ -321,7 +331,7 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     const int cpg = G ? Cg / G : 8;
     if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
-    if (Q < 1 || Q > 64) return -1;
+    if (Q < 1 || Q > 16) return -1;                       // voxels of <= 64 channels (store-wave slot table)
     const int nd = stx_cdiv(D, CVM_T);
     if (nd > 6) return -1;
     const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc), TC = CVM_T * (nd + 2);
@@ -333,6 +343,7 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     a.nd = nd; a.nt = stx_cdiv(W, CVM_T);
     const long long macros = (long long)B * H * a.nt;
     if (macros >= (1ll << 31) || (long long)B * (Cg > Cc ? Cg : Cc) * H * W >= (1ll << 31)) return -1;
+    if (16ll * H * W * CT >= (1ll << 32)) return -1;      // 32-bit offsets inside a unit's 16 d-planes
     a.macros = (int)macros;
     a.magic_rowq = (unsigned)(0x100000000ULL / (unsigned)(CVM_T * Q) + 1);
     a.magic_q = (unsigned)(0x100000000ULL / (unsigned)Q + 1);

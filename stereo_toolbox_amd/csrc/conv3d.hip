@@ -638,6 +638,225 @@ __global__ __launch_bounds__(NWV * 64) void conv3d_march_kernel(MarchArgs ma) {
 }
 
 // ------------------------------------------------------------------------------------------
+// 3x3x3 stride-1 convolution 32 -> 32, second-generation march kernel: the WEIGHTS live in LDS and the planes are
+// input-stationary.
+//
+// conv3d_march_kernel above streams the packed weights from L2 for every tap of every plane (each wave fetches 4 KB
+// per 16 MFMAs: ~31 B/clk/CU of L2 traffic, and its two barriers + accumulator exchange per plane leave the matrix pipe
+// idle: 0.60-0.63 of the fp32-MFMA peak).  Here a workgroup is 4 waves, ONE per SIMD, and
+//   * the 27 x 32 x 32 packed weights (110 592 B, MFMA B-operand order) are loaded into LDS once per workgroup; both
+//     operands of every MFMA then come from LDS (8 ds_read_b128 per 16 MFMAs per wave = 12 % of the LDS bandwidth);
+//   * LDS holds two input planes (double buffer, 10 x 18 voxels x 36 dwords = 25 920 B each: a column of 8 x 16 output
+//     voxels, one 2 x 16 row block per wave).  Input plane p is multiplied by ALL 27 taps while it is resident: its
+//     kd = 2 / 1 / 0 tap planes accumulate into the outputs p-1 / p / p+1, whose three accumulator sets rotate through
+//     registers (48 VGPRs).  Plane p+1 is in flight into registers meanwhile and is written to the other buffer at the
+//     end of the step: ONE barrier per plane, no accumulator exchange;
+//   * output p-1 is complete after the first 9 taps of step p: its epilogue (affine / residual / ReLU / BN partial
+//     sums / stores) is emitted in slices between the remaining 18 taps' MFMA groups, i.e. in the shadow of the pipe.
+// 110 592 + 2 x 25 920 = 162 432 B of the CU's 163 840 B of LDS: one workgroup per CU, 432 MFMAs per wave and plane.
+constexpr int MW2_MW = 16, MW2_R = 2, MW2_TH = 8, MW2_EH = 10, MW2_EW = 18, MW2_VS = 36;
+constexpr int MW2_SLOT = MW2_EH * MW2_EW * MW2_VS;                  // floats per plane buffer
+constexpr int MW2_NF4 = (MW2_EH * MW2_EW * 8 + 255) / 256;          // staging float4 per thread
+constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed weights [tap][q][lane][4]
+
+__global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
+    const ConvArgs& a = ma.c;
+    STX_DYN_SMEM(smem);
+    float* wl = reinterpret_cast<float*>(smem);                      // [27][4][64][4]
+    float* planes = wl + MW2_WFLOATS;                                // [2][MW2_SLOT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    const int th = wave;                                             // row block of this wave
+
+    // weights -> LDS (once)
+    for (int e = tid; e < MW2_WFLOATS / 4; e += 256) stx_st4(wl + 4 * e, stx_ld4(a.wp + 4 * e));
+
+    int b = 0, oh0 = 0, ow0 = 0;
+    const long long units = (long long)ma.ncols * a.Do;
+    const long long wg = xcd_remap(blockIdx.x, gridDim.x);
+    int u = __builtin_amdgcn_readfirstlane((int)(units * wg / gridDim.x));
+    const int u_end = __builtin_amdgcn_readfirstlane((int)(units * (wg + 1) / gridDim.x));
+
+    float4 stg[MW2_NF4];
+    auto load_plane = [&](int pd) {
+#pragma unroll
+        for (int k = 0; k < MW2_NF4; ++k) {
+            const int idx = tid + k * 256;
+            const int v = idx >> 3, f = idx & 7;
+            const int wx = v % MW2_EW, hy = v / MW2_EW;
+            const int gh = oh0 - 1 + hy, gw = ow0 - 1 + wx;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < MW2_EH * MW2_EW && pd >= 0 && pd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * 32 + 4 * f);
+            stg[k] = val;
+        }
+    };
+    auto store_plane = [&](float* buf) {
+#pragma unroll
+        for (int k = 0; k < MW2_NF4; ++k) {
+            const int idx = tid + k * 256;
+            const int v = idx >> 3, f = idx & 7;
+            if (v < MW2_EH * MW2_EW) stx_st4(buf + v * MW2_VS + 4 * f, stg[k]);
+        }
+    };
+
+    float s1 = 0.f, s2 = 0.f;
+    const int abase = ((th * MW2_R + i / MW2_MW) * MW2_EW + i % MW2_MW) * MW2_VS + 4 * half;
+    const float* wlane = wl + lane * 4;
+    const int n = i;                                                 // output channel of this lane
+    const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
+    const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+
+    // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
+    // (the finished output plane dprev) interleaved with the MFMA groups
+    auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done, int dprev, int epi0) {
+        float4 av[2][4], bv[2][4];
+        auto load_tap = [&](int t9, int buf) {
+            const int kh = t9 / 3, kw = t9 % 3;
+            const float* sl = pbuf + abase + (kh * MW2_EW + kw) * MW2_VS;
+            const float* wt = wlane + (kd * 9 + t9) * 1024;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                av[buf][q] = stx_ld4(sl + 8 * q);
+                bv[buf][q] = stx_ld4(wt + q * 256);
+            }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+            if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
+            STX_SCHED_BARRIER();
+            const int cb = t9 & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, acc, 0, 0, 0);
+            }
+            if (with_epi) {
+                // rows epi0 + t9 (and the last slice takes what is left of its half): 16 rows over 18 taps
+                const int r = epi0 + t9;
+                if (r < 16) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
+                    if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
+                        const size_t idx = ((((size_t)b * a.Do + dprev) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
+                        float v = done[r];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                        v = fmaf(v, sc, bs);
+                        if (a.residual) v += a.residual[idx];
+                        if (a.relu) v = v > 0.f ? v : 0.f;
+                        a.out[idx] = v;
+                    }
+                }
+            }
+            STX_SCHED_BARRIER();
+        }
+    };
+    // one input plane p (resident in `pbuf`): kd = 2 -> aOld (output p-1, finished here), kd = 1 -> aMid (output p),
+    // kd = 0 -> aNew (output p+1, starts here)
+    auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, f32x16& aOld, f32x16& aMid, f32x16& aNew) {
+        aNew = zero16();
+        const bool live = p >= 0 && p < a.Di;                        // planes outside the volume are zero padding
+        const bool vOld = p - 1 >= d_lo && p - 1 < d_hi, vMid = p >= d_lo && p < d_hi, vNew = p + 1 >= d_lo && p + 1 < d_hi;
+        if (live && vOld) tap_plane(pbuf, 2, aOld, false, aOld, 0, 0);
+        // output p-1 is complete: its 16 rows leave in the shadow of the next 18 taps (or on their own at the edges)
+        if (live && vMid) tap_plane(pbuf, 1, aMid, vOld, aOld, p - 1, 0);
+        else if (vOld) {
+            // no MFMAs to hide behind: plain epilogue of rows 0..8
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
+                if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
+                    const size_t idx = ((((size_t)b * a.Do + (p - 1)) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
+                    float v = aOld[r];
+                    s1 += v; s2 = fmaf(v, v, s2);
+                    v = fmaf(v, sc, bs);
+                    if (a.residual) v += a.residual[idx];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    a.out[idx] = v;
+                }
+            }
+        }
+        if (live && vNew) tap_plane(pbuf, 0, aNew, vOld, aOld, p - 1, 9);
+        else if (vOld) {
+#pragma unroll
+            for (int r = 9; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
+                if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
+                    const size_t idx = ((((size_t)b * a.Do + (p - 1)) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
+                    float v = aOld[r];
+                    s1 += v; s2 = fmaf(v, v, s2);
+                    v = fmaf(v, sc, bs);
+                    if (a.residual) v += a.residual[idx];
+                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    a.out[idx] = v;
+                }
+            }
+        }
+    };
+
+    __syncthreads();                                                 // weights are in LDS
+    f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16();
+    while (u < u_end) {
+        int d_lo, d_hi;
+        {
+            const int col = u / a.Do;
+            d_lo = u - col * a.Do;
+            const int left = u_end - u;
+            d_hi = (a.Do - d_lo < left) ? a.Do : d_lo + left;
+            u += d_hi - d_lo;
+            const int wt = col % a.nWt, ht = (col / a.nWt) % a.nHt;
+            b = col / (a.nWt * a.nHt);
+            oh0 = ht * MW2_TH; ow0 = wt * MW2_MW;
+        }
+        // input planes d_lo-1 .. d_hi feed the outputs d_lo .. d_hi-1
+        __syncthreads();                                             // the previous run is done with both buffers
+        load_plane(d_lo - 1);
+        store_plane(planes);
+        __syncthreads();
+        int par = 0;
+        auto advance = [&](int p, f32x16& aOld, f32x16& aMid, f32x16& aNew) {
+            if (p + 1 <= d_hi && ma.ablate != 1) load_plane(p + 1);  // in flight during this plane's 27 taps
+            step(p, d_lo, d_hi, planes + par * MW2_SLOT, aOld, aMid, aNew);
+            if (p + 1 <= d_hi && ma.ablate != 1) store_plane(planes + (par ^ 1) * MW2_SLOT);
+            __syncthreads();                                         // plane p+1 is resident, plane p's buffer is free
+            par ^= 1;
+        };
+        for (int p = d_lo - 1; p <= d_hi; p += 3) {
+            advance(p, acc0, acc1, acc2);
+            if (p + 1 <= d_hi) advance(p + 1, acc1, acc2, acc0);
+            if (p + 2 <= d_hi) advance(p + 2, acc2, acc0, acc1);
+        }
+    }
+    if (a.stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        __syncthreads();
+        if (lane < 32) {
+            planes[(wave * 32 + lane) * 2 + 0] = s1;
+            planes[(wave * 32 + lane) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (tid < 32 && tid < a.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t1 += planes[(w * 32 + tid) * 2 + 0];
+                t2 += planes[(w * 32 + tid) * 2 + 1];
+            }
+            const size_t slab = (size_t)blockIdx.x;
+            a.stats[slab * 2 * a.Cout + tid] = t1;
+            a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Transposed convolution k3, stride 2, padding 1, output_padding 1 (out = 2 x in), computed as its
 // 8 output-parity classes with 1/2/2/2/4/4/4/8 taps: true MACs only, no zero insertion.
 //   out[2m+p] (per axis): p=0 -> tap k=1 at input m;  p=1 -> tap k=0 at input m+1 and k=2 at m.
@@ -1121,6 +1340,21 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         STX_REQUIRE((long long)ma.ncols * a.Do < (1ll << 31), "conv3d_fwd: volume too large");
         static const int ablate = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
         ma.ablate = ablate;
+        // second-generation march kernel (weights resident in LDS, input-stationary planes): Cout <= 32 only
+        static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
+        if (v2_env && NT == 1) {
+            MarchArgs m2 = ma;
+            m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);
+            m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
+            m2.ncols = B * m2.c.nHt * m2.c.nWt;
+            if ((long long)m2.ncols * a.Do < (1ll << 31)) {
+                const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
+                const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
+                hipFuncSetAttribute((const void*)conv3d_marchw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL(conv3d_marchw_kernel, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m2);
+                return stx_check_launch("conv3d_fwd(march v2)");
+            }
+        }
         const int nblk = march_wgs((long long)ma.ncols * a.Do, w4 ? 2 : 1);
         const size_t slot = (size_t)(nrb * 32 / mw + 2) * (mw + 2) * MARCH_VS;
         const size_t lds = ((size_t)3 * slot + (ksplit ? (size_t)4 * 2 * NT * 8 * 64 : 0)) * 4;

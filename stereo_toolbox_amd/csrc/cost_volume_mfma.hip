@@ -75,7 +75,7 @@ __device__ __forceinline__ f32x4 cvm_zero4() {
 __host__ __device__ inline int cvm_cs(int Cc) { return ((Cc / 4) & 1) ? Cc + 8 : Cc + 4; }
 
 // ND = compile-time bound of nd (register ring of ND + 1 right tiles)
-template <int CPG, int QPW, int NCW, int NSW, int ND>
+template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE>
 __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a) {
     constexpr int NCTHR = NCW * 64, NSTHR = NSW * 64;
     constexpr int KK = CPG / 4;                                   // MFMA K steps per group
@@ -141,28 +141,46 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                 const float* stage = lds + (ui & 1) * IMG;
                 const float* tabr = tab + (CVM_T + CVM_T * (nd - k)) * CS;   // right-table column of x = w0 - d0
                 float* vrow = a.vol + (((size_t)b * D + d0) * H + h) * (size_t)W * CT + (size_t)w0 * CT;
-                const float* srow = a.scale ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
+                const float* srow = SCALE ? a.scale + (((size_t)b * D + d0) * H + h) * (size_t)W + w0 : nullptr;
                 const int dlim = D - d0, wlim = W - w0, mthr = a.mask_left ? d0 - w0 : -1000;
+                // all LDS reads of the unit in flight first, then the masks, then the stores (a wave never waits
+                // between two of its reads)
                 float4 v[NSLOT];
 #pragma unroll
                 for (int sl = 0; sl < NSLOT; ++sl) {
                     const int info = pk[sl], ty = info >> 16, dd = (info >> 8) & 0xff, wl = info & 0xff;
                     const bool ok = info >= 0 && dd < dlim && wl < wlim;
                     const float* bp = ty == 0 ? stage : (ty == 1 ? tab : tabr);
-                    float4 tv = stx_ld4(ok ? bp + soff[sl] : lds);
-                    if (ty == 1 && wl - dd < mthr) tv = make_float4(0.f, 0.f, 0.f, 0.f);   // left half masked where w < d
-                    if (srow) {
-                        const float mm = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
-                        tv.x *= mm; tv.y *= mm; tv.z *= mm; tv.w *= mm;
+                    v[sl] = stx_ld4(ok ? bp + soff[sl] : lds);
+                }
+                STX_SCHED_BARRIER();          // (hipcc otherwise re-serialises read -> wait -> mask per slot)
+                if (SCALE) {
+                    float mm[NSLOT];
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        const int info = pk[sl], dd = (info >> 8) & 0xff, wl = info & 0xff;
+                        const bool ok = info >= 0 && dd < dlim && wl < wlim;
+                        mm[sl] = srow[(size_t)(ok ? dd : 0) * HW + (ok ? wl : 0)];
                     }
-                    v[sl] = tv;
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) { v[sl].x *= mm[sl]; v[sl].y *= mm[sl]; v[sl].z *= mm[sl]; v[sl].w *= mm[sl]; }
                 }
 #pragma unroll
                 for (int sl = 0; sl < NSLOT; ++sl) {
-                    const int info = pk[sl], dd = (info >> 8) & 0xff, wl = info & 0xff;
-                    if (info >= 0 && dd < dlim && wl < wlim) {
-                        if (a.nontemporal) stx_st4_nt(vrow + goff[sl], v[sl]);
-                        else stx_st4(vrow + goff[sl], v[sl]);
+                    const int info = pk[sl], ty = info >> 16, dd = (info >> 8) & 0xff, wl = info & 0xff;
+                    if (ty == 1 && wl - dd < mthr) v[sl] = make_float4(0.f, 0.f, 0.f, 0.f);   // left half masked where w < d
+                }
+                if (a.nontemporal) {
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        const int info = pk[sl], dd = (info >> 8) & 0xff, wl = info & 0xff;
+                        if (info >= 0 && dd < dlim && wl < wlim) stx_st4_nt(vrow + goff[sl], v[sl]);
+                    }
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < NSLOT; ++sl) {
+                        const int info = pk[sl], dd = (info >> 8) & 0xff, wl = info & 0xff;
+                        if (info >= 0 && dd < dlim && wl < wlim) stx_st4(vrow + goff[sl], v[sl]);
                     }
                 }
             }
@@ -310,9 +328,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     }
 }
 
-template <int CPG, int QPW, int NCW, int NSW, int ND>
+template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE = false>
 int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND>;
+    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND, SCALE>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256 * wgs_per_cu;
     if (const char* e = getenv("STX_CV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force multi-unit runs
@@ -331,6 +349,7 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     const int cpg = G ? Cg / G : 8;
     if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
+    if (scale && G) return -1;                            // the attention scale comes with concat-only volumes (acv.py:196)
     if (Q < 1 || Q > 16) return -1;                       // voxels of <= 64 channels (store-wave slot table)
     const int nd = stx_cdiv(D, CVM_T);
     if (nd > 6) return -1;
@@ -365,6 +384,7 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     // selects the fat-wave layouts, STX_CV_NSW = 4 fewer store waves (tuning switches)
 #define CVM_LAYOUT(CPG_, ND_)                                                                        \
     {                                                                                                \
+        if (GQ == 0 && scale) return cvm_launch<CPG_, 1, 4, 8, ND_, true>(a, wgs, lds, st);          \
         if (GQ == 0) return nsw_env == 4 ? cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st)           \
                                          : cvm_launch<CPG_, 1, 4, 8, ND_>(a, wgs, lds, st);          \
         if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st);         \

@@ -418,6 +418,11 @@ struct MarchArgs {
     ConvArgs c;
     int ncols;           // B * nHt * nWt workgroup columns; the (column, d) plane list is split evenly over the grid
     int ablate;          // profiling only (STX_MARCH_ABLATE): 1 = no plane staging, 2 = no epilogue stores
+    // channel slicing of the second-generation kernel (32 x 32 slices of wider layers):
+    int xs, xo;          // floats per input voxel, first input channel of the slice
+    int os, oo, ncout;   // floats per output voxel, first output channel, valid output channels of the slice (<= 32)
+    int wq_total, wq_off, wnt_total, wnt_off;   // slice of the packed weights [tap][K/8][N/32][lane][4]
+    const float* acc_in; // partial sums of an earlier K slice (same layout as out), or null
 };
 
 // NQ = 8-channel K steps a wave multiplies per tap: 2 = wave pairs split K as described above (4 row blocks per
@@ -668,8 +673,13 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const int i = lane & 31, half = lane >> 5;
     const int th = wave;                                             // row block of this wave
 
-    // weights -> LDS (once)
-    for (int e = tid; e < MW2_WFLOATS / 4; e += 256) stx_st4(wl + 4 * e, stx_ld4(a.wp + 4 * e));
+    // weights -> LDS (once): slice [tap][wq_off .. +4][wnt_off] of the packed tensor
+    for (int e = tid; e < MW2_WFLOATS / 4; e += 256) {
+        const int tq = e >> 6, l4 = e & 63;                          // (tap * 4 + q), lane
+        const int tap = tq >> 2, q = tq & 3;
+        const size_t src = (((size_t)tap * ma.wq_total + ma.wq_off + q) * ma.wnt_total + ma.wnt_off) * 256 + 4 * l4;
+        stx_st4(wl + 4 * e, stx_ld4(a.wp + src));
+    }
 
     int b = 0, oh0 = 0, ow0 = 0;
     const long long units = (long long)ma.ncols * a.Do;
@@ -687,7 +697,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             const int gh = oh0 - 1 + hy, gw = ow0 - 1 + wx;
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             if (v < MW2_EH * MW2_EW && pd >= 0 && pd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * 32 + 4 * f);
+                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * ma.xs + ma.xo + 4 * f);
             stg[k] = val;
         }
     };
@@ -704,8 +714,25 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const int abase = ((th * MW2_R + i / MW2_MW) * MW2_EW + i % MW2_MW) * MW2_VS + 4 * half;
     const float* wlane = wl + lane * 4;
     const int n = i;                                                 // output channel of this lane
-    const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
-    const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
+    const float sc = (a.scale && n < ma.ncout) ? a.scale[ma.oo + n] : 1.f;
+    const float bs = (a.bias && n < ma.ncout) ? a.bias[ma.oo + n] : 0.f;
+
+    // one output row (voxel) of a finished plane: partial sums of an earlier K slice, BN statistics, affine, residual, ReLU
+    auto emit_row = [&](const f32x16& done, int r, int dprev) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
+        if (oh < a.Ho && ow < a.Wo && n < ma.ncout && ma.ablate != 2) {
+            const size_t idx = ((((size_t)b * a.Do + dprev) * a.Ho + oh) * a.Wo + ow) * ma.os + ma.oo + n;
+            float v = done[r];
+            if (ma.acc_in) v += ma.acc_in[idx];
+            s1 += v;
+            s2 = fmaf(v, v, s2);
+            v = fmaf(v, sc, bs);
+            if (a.residual) v += a.residual[idx];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.out[idx] = v;
+        }
+    };
 
     // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
     // (the finished output plane dprev) interleaved with the MFMA groups
@@ -737,66 +764,33 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             if (with_epi) {
                 // rows epi0 + t9 (and the last slice takes what is left of its half): 16 rows over 18 taps
                 const int r = epi0 + t9;
-                if (r < 16) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
-                    if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
-                        const size_t idx = ((((size_t)b * a.Do + dprev) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
-                        float v = done[r];
-                        s1 += v;
-                        s2 = fmaf(v, v, s2);
-                        v = fmaf(v, sc, bs);
-                        if (a.residual) v += a.residual[idx];
-                        if (a.relu) v = v > 0.f ? v : 0.f;
-                        a.out[idx] = v;
-                    }
-                }
+                if (r < 16) emit_row(done, r, dprev);
             }
             STX_SCHED_BARRIER();
         }
     };
     // one input plane p (resident in `pbuf`): kd = 2 -> aOld (output p-1, finished here), kd = 1 -> aMid (output p),
     // kd = 0 -> aNew (output p+1, starts here)
-    auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, f32x16& aOld, f32x16& aMid, f32x16& aNew) {
+    auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, float* nbuf, bool stage, f32x16& aOld, f32x16& aMid,
+                    f32x16& aNew) {
         aNew = zero16();
         const bool live = p >= 0 && p < a.Di;                        // planes outside the volume are zero padding
         const bool vOld = p - 1 >= d_lo && p - 1 < d_hi, vMid = p >= d_lo && p < d_hi, vNew = p + 1 >= d_lo && p + 1 < d_hi;
         if (live && vOld) tap_plane(pbuf, 2, aOld, false, aOld, 0, 0);
+        // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
+        // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
+        if (stage) store_plane(nbuf);
         // output p-1 is complete: its 16 rows leave in the shadow of the next 18 taps (or on their own at the edges)
         if (live && vMid) tap_plane(pbuf, 1, aMid, vOld, aOld, p - 1, 0);
         else if (vOld) {
             // no MFMAs to hide behind: plain epilogue of rows 0..8
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
-                if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
-                    const size_t idx = ((((size_t)b * a.Do + (p - 1)) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
-                    float v = aOld[r];
-                    s1 += v; s2 = fmaf(v, v, s2);
-                    v = fmaf(v, sc, bs);
-                    if (a.residual) v += a.residual[idx];
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    a.out[idx] = v;
-                }
-            }
+            for (int r = 0; r < 9; ++r) emit_row(aOld, r, p - 1);
         }
         if (live && vNew) tap_plane(pbuf, 0, aNew, vOld, aOld, p - 1, 9);
         else if (vOld) {
 #pragma unroll
-            for (int r = 9; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
-                if (oh < a.Ho && ow < a.Wo && n < a.Cout && ma.ablate != 2) {
-                    const size_t idx = ((((size_t)b * a.Do + (p - 1)) * a.Ho + oh) * a.Wo + ow) * a.Cout + n;
-                    float v = aOld[r];
-                    s1 += v; s2 = fmaf(v, v, s2);
-                    v = fmaf(v, sc, bs);
-                    if (a.residual) v += a.residual[idx];
-                    if (a.relu) v = v > 0.f ? v : 0.f;
-                    a.out[idx] = v;
-                }
-            }
+            for (int r = 9; r < 16; ++r) emit_row(aOld, r, p - 1);
         }
     };
 
@@ -821,9 +815,9 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         __syncthreads();
         int par = 0;
         auto advance = [&](int p, f32x16& aOld, f32x16& aMid, f32x16& aNew) {
-            if (p + 1 <= d_hi && ma.ablate != 1) load_plane(p + 1);  // in flight during this plane's 27 taps
-            step(p, d_lo, d_hi, planes + par * MW2_SLOT, aOld, aMid, aNew);
-            if (p + 1 <= d_hi && ma.ablate != 1) store_plane(planes + (par ^ 1) * MW2_SLOT);
+            const bool stage = p + 1 <= d_hi && ma.ablate != 1;
+            if (stage) load_plane(p + 1);                            // in flight during this plane's first 9 taps
+            step(p, d_lo, d_hi, planes + par * MW2_SLOT, planes + (par ^ 1) * MW2_SLOT, stage, aOld, aMid, aNew);
             __syncthreads();                                         // plane p+1 is resident, plane p's buffer is free
             par ^= 1;
         };
@@ -842,7 +836,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             planes[(wave * 32 + lane) * 2 + 1] = s2;
         }
         __syncthreads();
-        if (tid < 32 && tid < a.Cout) {
+        if (tid < 32 && tid < ma.ncout) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -850,8 +844,8 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
                 t2 += planes[(w * 32 + tid) * 2 + 1];
             }
             const size_t slab = (size_t)blockIdx.x;
-            a.stats[slab * 2 * a.Cout + tid] = t1;
-            a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
+            a.stats[slab * 2 * a.Cout + ma.oo + tid] = t1;
+            a.stats[slab * 2 * a.Cout + a.Cout + ma.oo + tid] = t2;
         }
     }
 }
@@ -1322,6 +1316,38 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     // the slab has stx_conv3d_fwd_blocks() rows per batch item; rows no workgroup writes must read 0
     if (stats)
         hipMemsetAsync(stats, 0, (size_t)B * stx_conv3d_fwd_blocks(a.Do, a.Ho, a.Wo) * 2 * Cout * 4, (hipStream_t)stream);
+    // Second-generation march kernel (weights resident in LDS, input-stationary planes) for 3x3x3 stride-1 layers in
+    // 32 x 32 channel slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums
+    // and applies the epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).  STX_MARCH_V2=0: first generation.
+    static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
+    if (v2_env && ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
+        MarchArgs m2;
+        m2.c = a;
+        m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);
+        m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
+        m2.ncols = B * m2.c.nHt * m2.c.nWt;
+        static const int ablate2 = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
+        m2.ablate = ablate2;
+        if ((long long)m2.ncols * a.Do < (1ll << 31)) {
+            const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
+            const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
+            hipFuncSetAttribute((const void*)conv3d_marchw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
+            const int nk = Cin / 32, nn = stx_cdiv(Cout, 32);
+            for (int ns = 0; ns < nn; ++ns)
+                for (int kslice = 0; kslice < nk; ++kslice) {
+                    MarchArgs m = m2;
+                    m.xo = 32 * kslice; m.wq_off = 4 * kslice;
+                    m.oo = 32 * ns; m.wnt_off = ns; m.ncout = Cout - 32 * ns < 32 ? Cout - 32 * ns : 32;
+                    m.acc_in = kslice > 0 ? out : nullptr;
+                    if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
+                        m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
+                    }
+                    hipLaunchKernelGGL(conv3d_marchw_kernel, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
+                }
+            return stx_check_launch("conv3d_fwd(march v2)");
+        }
+    }
     if (use_march(Cin, Cout, ks, stride)) {
         MarchArgs ma;
         ma.c = a;
@@ -1340,21 +1366,6 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         STX_REQUIRE((long long)ma.ncols * a.Do < (1ll << 31), "conv3d_fwd: volume too large");
         static const int ablate = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
         ma.ablate = ablate;
-        // second-generation march kernel (weights resident in LDS, input-stationary planes): Cout <= 32 only
-        static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
-        if (v2_env && NT == 1) {
-            MarchArgs m2 = ma;
-            m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);
-            m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
-            m2.ncols = B * m2.c.nHt * m2.c.nWt;
-            if ((long long)m2.ncols * a.Do < (1ll << 31)) {
-                const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
-                const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
-                hipFuncSetAttribute((const void*)conv3d_marchw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                hipLaunchKernelGGL(conv3d_marchw_kernel, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m2);
-                return stx_check_launch("conv3d_fwd(march v2)");
-            }
-        }
         const int nblk = march_wgs((long long)ma.ncols * a.Do, w4 ? 2 : 1);
         const size_t slot = (size_t)(nrb * 32 / mw + 2) * (mw + 2) * MARCH_VS;
         const size_t lds = ((size_t)3 * slot + (ksplit ? (size_t)4 * 2 * NT * 8 * 64 : 0)) * 4;

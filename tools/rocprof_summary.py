@@ -1,5 +1,9 @@
 """Summarise a rocprofv3 --kernel-trace --stats output directory (csv or rocpd sqlite) into a
-per-kernel table: calls, total ms, avg us, share.  usage: rocprof_summary.py <dir>"""
+per-kernel table: calls, total ms, avg us, share.
+usage: rocprof_summary.py <dir> [--steady MARKER SKIP]
+  --steady MARKER SKIP: only dispatches that start at or after the (SKIP+1)-th dispatch of the kernel whose name contains
+  MARKER (one launch per step, e.g. cost_volume_fwd) are counted -- drops the warm-up steps, in which MIOpen's
+  benchmark-mode solver search of the 2-D feature CNN runs thousands of candidate kernels."""
 import csv
 import glob
 import os
@@ -8,16 +12,24 @@ import sys
 from collections import defaultdict
 
 
-def from_csv(d):
+def from_csv(d, marker=None, skip=0):
     rows = defaultdict(lambda: [0, 0.0])
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    recs = []
     for f in files:
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                n = r.get("Kernel_Name") or r.get("kernel_name")
-                dt = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-                rows[n][0] += 1
-                rows[n][1] += dt
+                recs.append((r.get("Kernel_Name") or r.get("kernel_name"), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    t0 = 0
+    if marker:
+        marks = sorted(s for n, s, e in recs if marker in n)
+        if len(marks) > skip:
+            t0 = marks[skip]
+            print(f"steady state: {len(marks) - skip} of {len(marks)} '{marker}' launches kept")
+    for n, s, e in recs:
+        if s >= t0:
+            rows[n][0] += 1
+            rows[n][1] += (e - s) / 1e6
     return rows if files else None
 
 
@@ -51,7 +63,8 @@ def from_db(d):
 
 def main():
     d = sys.argv[1]
-    rows = from_csv(d) or from_db(d)
+    marker, skip = (sys.argv[3], int(sys.argv[4])) if len(sys.argv) > 4 and sys.argv[2] == "--steady" else (None, 0)
+    rows = from_csv(d, marker, skip) or from_db(d)
     if not rows:
         print("no kernel trace found in", d)
         return

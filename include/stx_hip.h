@@ -156,6 +156,18 @@ int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const flo
                      const float* gamma1, const float* z2, const float* mean2, const float* invstd2,
                      const float* gamma2, const float* sums, float* dz1, float* dz2, float* gout, long long nvox, int C,
                      int relu, void* stream);
+/* The same two passes taking the ReLU mask from the forward pass's per-channel scale / shift instead of the activated
+ * output (y may be NULL): sign(y) = sign(fmaf(z1, scale1, shift1) [+ fmaf(z2, scale2, shift2)]) is recomputed from
+ * operands these passes read anyway -- one volume-sized read less per pass.  (A block with a plain residual still passes y.) */
+int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
+                       const float* z2, const float* mean2, const float* invstd2, const float* scale1,
+                       const float* shift1, const float* scale2, const float* shift2, float* partials, float* sums,
+                       long long nvox, int C, int relu, void* stream);
+int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
+                      const float* gamma1, const float* z2, const float* mean2, const float* invstd2,
+                      const float* gamma2, const float* scale1, const float* shift1, const float* scale2,
+                      const float* shift2, const float* sums, float* dz1, float* dz2, float* gout, long long nvox,
+                      int C, int relu, void* stream);
 
 /* ---- Evaluation-path input step on the device --------------------------------------------------------
  * pad_to_2x (datasets/data_augmentation/__init__.py:57-80: zero padding on top and to the right, to multiples of 96)

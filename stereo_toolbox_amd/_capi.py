@@ -69,6 +69,8 @@ SIGNATURES = {
     "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_bwd_reduce2": [_P] * 14 + [_L, _I, _I, _P],
+    "stx_bn_bwd_apply2": [_P] * 18 + [_L, _I, _I, _P],
 }
 _RET_CHARP = ("stx_last_error", "stx_build_info")
 

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ z1,
     const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ z2,
-    const float* __restrict__ mean2, const float* __restrict__ invstd2, float* __restrict__ partials,
+    const float* __restrict__ mean2, const float* __restrict__ invstd2, const float* __restrict__ sc1,
+    const float* __restrict__ sh1, const float* __restrict__ sc2, const float* __restrict__ sh2, float* __restrict__ partials,
     size_t nvox, int C, int relu) {
     __shared__ float red[BN_THREADS * 12];
     const int tid = threadIdx.x;
@@ -105,23 +106,41 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f), i2 = m2;
     const bool has2 = z2 && mean2;
     if (has2) { m2 = stx_ld4(mean2 + 4 * cq); i2 = stx_ld4(invstd2 + 4 * cq); }
+    // ReLU mask without reading y: the forward pass computed y = relu(fmaf(z1, sc1, sh1) [+ fmaf(z2, sc2, sh2)]) -- the
+    // same expression on the same operands gives the same sign bit for bit, and z1 / z2 are read here anyway
+    const bool remask = relu && !y;
+    float4 a1 = m2, b1 = m2, a2 = m2, b2 = m2;
+    if (remask) {
+        a1 = stx_ld4(sc1 + 4 * cq); b1 = stx_ld4(sh1 + 4 * cq);
+        if (has2) { a2 = stx_ld4(sc2 + 4 * cq); b2 = stx_ld4(sh2 + 4 * cq); }
+    }
     float s[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) s[k] = 0.f;
     for (size_t v = (size_t)blockIdx.x * VPB + vl; v < nvox; v += (size_t)gridDim.x * VPB) {
         const size_t o = v * C + 4 * cq;
         float4 g = stx_ld4(gy + o);
+        const float4 a = stx_ld4(z1 + o);
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has2) c = stx_ld4(z2 + o);
         if (relu) {
-            const float4 yy = stx_ld4(y + o);
+            float4 yy;
+            if (remask) {
+                yy.x = fmaf(a.x, a1.x, b1.x); yy.y = fmaf(a.y, a1.y, b1.y); yy.z = fmaf(a.z, a1.z, b1.z); yy.w = fmaf(a.w, a1.w, b1.w);
+                if (has2) {
+                    yy.x += fmaf(c.x, a2.x, b2.x); yy.y += fmaf(c.y, a2.y, b2.y);
+                    yy.z += fmaf(c.z, a2.z, b2.z); yy.w += fmaf(c.w, a2.w, b2.w);
+                }
+            } else {
+                yy = stx_ld4(y + o);
+            }
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
-        const float4 a = stx_ld4(z1 + o);
         s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
         s[4] = fmaf(g.x, (a.x - m1.x) * i1.x, s[4]); s[5] = fmaf(g.y, (a.y - m1.y) * i1.y, s[5]);
         s[6] = fmaf(g.z, (a.z - m1.z) * i1.z, s[6]); s[7] = fmaf(g.w, (a.w - m1.w) * i1.w, s[7]);
         if (has2) {
-            const float4 c = stx_ld4(z2 + o);
             s[8] = fmaf(g.x, (c.x - m2.x) * i2.x, s[8]); s[9] = fmaf(g.y, (c.y - m2.y) * i2.y, s[9]);
             s[10] = fmaf(g.z, (c.z - m2.z) * i2.z, s[10]); s[11] = fmaf(g.w, (c.w - m2.w) * i2.w, s[11]);
         }
@@ -154,22 +173,38 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ z1,
     const float* __restrict__ mean1, const float* __restrict__ invstd1, const float* __restrict__ gamma1,
     const float* __restrict__ z2, const float* __restrict__ mean2, const float* __restrict__ invstd2,
-    const float* __restrict__ gamma2, const float* __restrict__ sums, float* __restrict__ dz1,
+    const float* __restrict__ gamma2, const float* __restrict__ sc1, const float* __restrict__ sh1,
+    const float* __restrict__ sc2, const float* __restrict__ sh2, const float* __restrict__ sums, float* __restrict__ dz1,
     float* __restrict__ dz2, float* __restrict__ gout, size_t nquads, int C, int relu, float inv_n) {
     const int CQ = C >> 2;
     const bool has2 = z2 && mean2 && dz2;
+    const bool remask = relu && !y;                 // (see bn_bwd_reduce_kernel)
     for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * BN_THREADS) {
         const int c = (int)(i % CQ) * 4;
         float4 g = stx_ld4(gy + i * 4);
+        const float4 a = stx_ld4(z1 + i * 4);
+        float4 a2v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has2) a2v = stx_ld4(z2 + i * 4);
         if (relu) {
-            const float4 yy = stx_ld4(y + i * 4);
+            float4 yy;
+            if (remask) {
+                const float4 p1 = stx_ld4(sc1 + c), q1 = stx_ld4(sh1 + c);
+                yy.x = fmaf(a.x, p1.x, q1.x); yy.y = fmaf(a.y, p1.y, q1.y); yy.z = fmaf(a.z, p1.z, q1.z); yy.w = fmaf(a.w, p1.w, q1.w);
+                if (has2) {
+                    const float4 p2 = stx_ld4(sc2 + c), q2 = stx_ld4(sh2 + c);
+                    yy.x += fmaf(a2v.x, p2.x, q2.x); yy.y += fmaf(a2v.y, p2.y, q2.y);
+                    yy.z += fmaf(a2v.z, p2.z, q2.z); yy.w += fmaf(a2v.w, p2.w, q2.w);
+                }
+            } else {
+                yy = stx_ld4(y + i * 4);
+            }
             g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
             g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
         if (gout) stx_st4(gout + i * 4, g);
         const float4 sg = stx_ld4(sums + c);
         {
-            const float4 a = stx_ld4(z1 + i * 4), m = stx_ld4(mean1 + c), is = stx_ld4(invstd1 + c);
+            const float4 m = stx_ld4(mean1 + c), is = stx_ld4(invstd1 + c);
             const float4 gm = gamma1 ? stx_ld4(gamma1 + c) : make_float4(1.f, 1.f, 1.f, 1.f);
             const float4 sx = stx_ld4(sums + C + c);
             float4 d;
@@ -180,7 +215,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
             stx_st4(dz1 + i * 4, d);
         }
         if (has2) {
-            const float4 a = stx_ld4(z2 + i * 4), m = stx_ld4(mean2 + c), is = stx_ld4(invstd2 + c);
+            const float4 a = a2v, m = stx_ld4(mean2 + c), is = stx_ld4(invstd2 + c);
             const float4 gm = gamma2 ? stx_ld4(gamma2 + c) : make_float4(1.f, 1.f, 1.f, 1.f);
             const float4 sx = stx_ld4(sums + 2 * C + c);
             float4 d;
@@ -225,32 +260,51 @@ extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* s
     return stx_check_launch("bn_apply");
 }
 
-extern "C" int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1,
-                                 const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
-                                 float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
+extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* z1, const float* mean1,
+                                  const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
+                                  const float* scale1, const float* shift1, const float* scale2, const float* shift2,
+                                  float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
     stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && partials && sums && nvox > 0, "bn_bwd_reduce: null operand");
     STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
-    STX_REQUIRE(!relu || y, "bn_bwd_reduce: relu mask needs y");
+    STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2) || (scale2 && shift2))),
+                "bn_bwd_reduce: the relu mask needs y or the forward pass's scale / shift vectors");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_RED_BLOCKS), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
-                       z2, mean2, invstd2, partials, (size_t)nvox, C, relu);
+                       z2, mean2, invstd2, scale1, shift1, scale2, shift2, partials, (size_t)nvox, C, relu);
     int rc = stx_check_launch("bn_bwd_reduce");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, BN_RED_BLOCKS, 3 * C, sums);
     return stx_check_launch("bn_colsum");
 }
 
+extern "C" int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z1, const float* mean1,
+                                 const float* invstd1, const float* gamma1, const float* z2, const float* mean2,
+                                 const float* invstd2, const float* gamma2, const float* scale1, const float* shift1,
+                                 const float* scale2, const float* shift2, const float* sums, float* dz1, float* dz2,
+                                 float* gout, long long nvox, int C, int relu, void* stream) {
+    stx_begin();
+    STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
+    STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2 && dz2) || (scale2 && shift2))),
+                "bn_bwd_apply: the relu mask needs y or the forward pass's scale / shift vectors");
+    const size_t nquads = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
+                       mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, scale1, shift1, scale2, shift2, sums, dz1, dz2,
+                       gout, nquads, C, relu, (float)(1.0 / (double)nvox));
+    return stx_check_launch("bn_bwd_apply");
+}
+
+extern "C" int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1,
+                                 const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
+                                 float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
+    return stx_bn_bwd_reduce2(gy, y, z1, mean1, invstd1, z2, mean2, invstd2, nullptr, nullptr, nullptr, nullptr, partials,
+                              sums, nvox, C, relu, stream);
+}
+
 extern "C" int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const float* mean1,
                                 const float* invstd1, const float* gamma1, const float* z2, const float* mean2,
                                 const float* invstd2, const float* gamma2, const float* sums, float* dz1, float* dz2,
                                 float* gout, long long nvox, int C, int relu, void* stream) {
-    stx_begin();
-    STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
-    STX_REQUIRE(!relu || y, "bn_bwd_apply: relu mask needs y");
-    const size_t nquads = (size_t)nvox * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
-                       mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, sums, dz1, dz2, gout, nquads, C, relu,
-                       (float)(1.0 / (double)nvox));
-    return stx_check_launch("bn_bwd_apply");
+    return stx_bn_bwd_apply2(gy, y, z1, mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, nullptr, nullptr, nullptr,
+                             nullptr, sums, dz1, dz2, gout, nvox, C, relu, stream);
 }

@@ -381,12 +381,19 @@ class BnActFn(torch.autograd.Function):
         ctx.train1 = bn1["training"]
         ctx.train2 = bn2["training"] if two else False
         ctx.sync = bn1.get("sync") or (bn2.get("sync") if two else None)
-        ctx.save_for_backward(z1, gamma1, m1, i1, z2, gamma2, m2, i2, y if relu else None)
+        # ReLU mask for the backward pass: a block without a plain residual recomputes sign(y) from z1 / z2 and the
+        # scale / shift vectors used above (bit-identical expression, operands the backward kernels read anyway), so
+        # the activated volume is not kept alive by this node and not re-read by its two backward passes
+        ctx.remask = relu and residual is None
+        keep_y = y if (relu and not ctx.remask) else None
+        ctx.save_for_backward(z1, gamma1, m1, i1, z2, gamma2, m2, i2, keep_y, sc1 if ctx.remask else None,
+                              sh1 if ctx.remask else None, sc2 if (ctx.remask and two) else None,
+                              sh2 if (ctx.remask and two) else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        z1, gamma1, m1, i1, z2, gamma2, m2, i2, y = ctx.saved_tensors
+        z1, gamma1, m1, i1, z2, gamma2, m2, i2, y, sc1, sh1, sc2, sh2 = ctx.saved_tensors
         gy = gy.contiguous()
         C = z1.shape[-1]
         nvox = z1.numel() // C
@@ -394,8 +401,9 @@ class BnActFn(torch.autograd.Function):
         NB = lib.raw("stx_bn_reduce_blocks")()
         part = _WS.get("bnred", NB * 3 * C, z1.device)
         sums = torch.empty(3, C, dtype=torch.float32, device=z1.device)
-        _call("stx_bn_bwd_reduce", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
-              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(part), _p(sums), nvox, C, int(ctx.relu))
+        _call("stx_bn_bwd_reduce2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
+              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(sc1), _p(sh1), _p(sc2), _p(sh2), _p(part),
+              _p(sums), nvox, C, int(ctx.relu))
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
@@ -410,9 +418,9 @@ class BnActFn(torch.autograd.Function):
         if not ctx.train1 or (ctx.two and not ctx.train2):
             # running-stat BN: no centering terms (mixed train/eval pairs are not used by these models)
             use = torch.zeros_like(sums)
-        _call("stx_bn_bwd_apply", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(gamma1), _p(z2) if ctx.two else None,
-              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(gamma2) if ctx.two else None, _p(use),
-              _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu))
+        _call("stx_bn_bwd_apply2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(gamma1), _p(z2) if ctx.two else None,
+              _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(gamma2) if ctx.two else None, _p(sc1), _p(sh1),
+              _p(sc2), _p(sh2), _p(use), _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu))
         if ctx.has_res and not ctx.relu:
             gres = gy
         return (dz1, sums[1], sums[0], dz2, sums[2] if ctx.two else None, sums[0] if ctx.two else None, gres,

@@ -551,3 +551,19 @@ def test_bn_train_fwd_bwd(be, case):
         _close(sums[2], g2.grad, rtol=1e-4, atol=1e-4)
     if resid:
         _close(gout, z2.grad, rtol=1e-6, atol=1e-6)
+    if relu and not resid:
+        # the y-free entry points: ReLU mask recomputed from z1 / z2 and the forward pass's scale / shift -> identical results
+        part2, sums2 = be.empty(NB, 3, C), be.empty(3, C)
+        be.call("stx_bn_bwd_reduce2", ptr(dgy), None, ptr(dz1_in), ptr(m1), ptr(i1), ptr(dz2_in) if two else None,
+                ptr(m2) if two else None, ptr(i2) if two else None, ptr(sc1), ptr(sh1), ptr(sc2) if two else None,
+                ptr(sh2) if two else None, ptr(part2), ptr(sums2), nvox, C, 1)
+        assert torch.equal(sums2.cpu(), sums.cpu())
+        dz1b = be.empty(nvox, C)
+        dz2b = be.empty(nvox, C) if two else None
+        be.call("stx_bn_bwd_apply2", ptr(dgy), None, ptr(dz1_in), ptr(m1), ptr(i1), ptr(be.dev(g1.detach())),
+                ptr(dz2_in) if two else None, ptr(m2) if two else None, ptr(i2) if two else None,
+                ptr(be.dev(g2.detach())) if two else None, ptr(sc1), ptr(sh1), ptr(sc2) if two else None,
+                ptr(sh2) if two else None, ptr(sums2), ptr(dz1b), ptr(dz2b), None, nvox, C, 1)
+        assert torch.equal(dz1b.cpu(), dz1.cpu())
+        if two:
+            assert torch.equal(dz2b.cpu(), dz2.cpu())

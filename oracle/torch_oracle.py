@@ -647,3 +647,165 @@ def igev_init_disparity(cost, maxdisp):
     disparity_regression(prob, max_disp // 4) at 1/4 resolution, keepdim (IGEVStereo/submodule.py:221-225)."""
     prob = F.softmax(cost.squeeze(1), dim=1)
     return disparity_regression(prob, maxdisp // 4, keepdim=True)
+
+
+# ----------------------------------------------------------------------------- CFNet (SURVEY 8f rank 1)
+def _cf_conv_bn_mish(cx, x, p):
+    """CFNet/submodule.py:70-93 `conv2DBatchNormRelu` (1x1 conv, BN, Mish): keys p.cbr_unit.{0,1}."""
+    return mish(cx.bn(F.conv2d(x, cx.sd[p + ".cbr_unit.0.weight"]), p + ".cbr_unit.1"))
+
+
+def _cf_pyramid_pooling(cx, x, p):
+    """CFNet/submodule.py:11-68 in the configuration cfnet.py:31 uses (pool_sizes=None, fusion 'sum', 'icnet')."""
+    import numpy as np
+    h, w = x.shape[2:]
+    sizes = [(int(h / s), int(w / s)) for s in np.linspace(2, min(h, w), 4, dtype=int)][::-1]
+    acc = x
+    for i, k in enumerate(sizes):
+        out = _cf_conv_bn_mish(cx, F.avg_pool2d(x, k, stride=k, padding=0), f"{p}.path_module_list.{i}")
+        acc = acc + 0.25 * F.interpolate(out, size=(h, w), mode="bilinear", align_corners=False)
+    return mish(acc / 2.0)
+
+
+def features_cf(cx, x, p="feature_extraction"):
+    """CFNet/cfnet.py:12-176 with concat_feature=True."""
+    def up(t, q):            # nn.Upsample(scale_factor=2) (nearest) + convbn + Mish
+        return mish(convbn_2d(cx, F.interpolate(t, scale_factor=2), q + ".1", 1, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".firstconv.0", 2, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".firstconv.2", 1, 1, 1))
+    x = mish(convbn_2d(cx, x, p + ".firstconv.4", 1, 1, 1))
+    l2 = _pcw_layer(cx, x, p + ".layer2", 1, 1, 1, 1, True)
+    l3 = _pcw_layer(cx, l2, p + ".layer3", 1, 2, 1, 1, True)
+    l4 = _pcw_layer(cx, l3, p + ".layer4", 1, 2, 1, 1, True)
+    l5 = _pcw_layer(cx, l4, p + ".layer5", 1, 2, 1, 1, True)
+    l6 = _cf_pyramid_pooling(cx, _pcw_layer(cx, l5, p + ".layer6", 1, 2, 1, 1, True), p + ".pyramid_pooling")
+    d5 = mish(convbn_2d(cx, torch.cat((l5, up(l6, p + ".upconv6")), 1), p + ".iconv5.0", 1, 1, 1))
+    d4 = mish(convbn_2d(cx, torch.cat((l4, up(d5, p + ".upconv5")), 1), p + ".iconv4.0", 1, 1, 1))
+    d3 = mish(convbn_2d(cx, torch.cat((l3, up(d4, p + ".upconv4")), 1), p + ".iconv3.0", 1, 1, 1))
+    d2 = mish(convbn_2d(cx, torch.cat((l2, up(d3, p + ".upconv3")), 1), p + ".iconv2.0", 1, 1, 1))
+    feats = {"2": d2, "3": d3, "4": d4, "5": d5, "6": l6}
+    out = {}
+    for k, t in feats.items():
+        out["gw" + k] = _pcw_head2d(cx, t, p + ".gw" + k)
+        out["concat_feature" + k] = _pcw_head2d(cx, t, p + ".concat" + k)
+    return out
+
+
+def hourglassup_cf(cx, x, f4, f5, p):
+    """CFNet/cfnet.py:178-228."""
+    sd = cx.sd
+    c1 = F.conv3d(x, sd[p + ".conv1.weight"], None, 2, 1)
+    c1 = mish(convbn_3d(cx, torch.cat((c1, f4), 1), p + ".combine1.0", 1, 1))
+    c2 = mish(convbn_3d(cx, c1, p + ".conv2.0", 1, 1))
+    c3 = F.conv3d(c2, sd[p + ".conv3.weight"], None, 2, 1)
+    c3 = mish(convbn_3d(cx, torch.cat((c3, f5), 1), p + ".combine2.0", 1, 1))
+    c4 = mish(convbn_3d(cx, c3, p + ".conv4.0", 1, 1))
+    c8 = mish(deconvbn_3d(cx, c4, p + ".conv8") + convbn_3d(cx, c2, p + ".redir2", 1, 0))
+    return mish(deconvbn_3d(cx, c8, p + ".conv9") + convbn_3d(cx, x, p + ".redir1", 1, 0))
+
+
+def _cf_dres(cx, x, p0, p1):
+    c = mish(convbn_3d(cx, mish(convbn_3d(cx, x, p0 + ".0")), p0 + ".2"))
+    return convbn_3d(cx, mish(convbn_3d(cx, c, p1 + ".0")), p1 + ".2") + c
+
+
+def _cf_classif(cx, x, p):
+    return F.conv3d(mish(convbn_3d(cx, x, p + ".0")), cx.sd[p + ".2.weight"], None, 1, 1).squeeze(1)
+
+
+def cf_sampled_volume(left, right, samples, num_groups):
+    """CFNet/submodule.py:306-350 (`SpatialTransformer`) + cfnet.py:479-497 (`cost_volume_generator`): right features
+    gathered at column w - sample (clamped index; zero where the un-clamped column leaves the image), then either
+    the concat of (left, warped right) (num_groups=None) or their group-wise correlation.  samples: float [B,S,H,W]."""
+    B, C, H, W = left.shape
+    S = samples.shape[1]
+    pos = torch.arange(0.0, W).view(1, 1, 1, W) - samples
+    idx = pos.clamp(0, W - 1).long().unsqueeze(1).expand(B, C, S, H, W)
+    warped = torch.gather(right.unsqueeze(2).expand(B, C, S, H, W), 4, idx)
+    warped = (1 - ((pos < 0) | (pos > W - 1)).float().unsqueeze(1)) * warped
+    lmap = left.unsqueeze(2).expand(B, C, S, H, W)
+    if num_groups is None:
+        return torch.cat((lmap, warped), 1)
+    return (lmap * warped).view(B, num_groups, C // num_groups, S, H, W).mean(2)
+
+
+def cfnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False, forced_samples=None):
+    """CFNet/cfnet.py:499-666 (CFNet = cfnet(use_concat_volume=True)).  train: the 9 predictions of cfnet.py:653.
+    forced_samples = (samples_s3, samples_s2) [B,S,H,W] replaces the integer disparity samples of the two cascade
+    stages (tests: the samples the reference drew; see tests/golden/make_golden_cfnet.py)."""
+    cx = Ctx(sd, training)
+    fl, fr = features_cf(cx, left), features_cf(cx, right)
+    H, W = left.shape[2], left.shape[3]
+    vols = {}
+    for k, div in (("4", 8), ("5", 16), ("6", 32)):
+        g = build_gwc_volume(fl["gw" + k], fr["gw" + k], maxdisp // div, 40)
+        c = build_concat_volume(fl["concat_feature" + k], fr["concat_feature" + k], maxdisp // div)
+        vols[k] = torch.cat((g, c), 1)
+    cost0_4 = _cf_dres(cx, vols["4"], "dres0", "dres1")
+    cost0_5 = _cf_dres(cx, vols["5"], "dres0_5", "dres1_5")
+    cost0_6 = _cf_dres(cx, vols["6"], "dres0_6", "dres1_6")
+    out1_4 = hourglassup_cf(cx, cost0_4, cost0_5, cost0_6, "combine1")
+    out2_4 = hourglass_pcw(cx, out1_4, "dres3")
+    poss4 = F.softmax(_cf_classif(cx, out2_4, "classif2"), dim=1)
+    pred2_s4 = disparity_regression(poss4, maxdisp // 8).unsqueeze(1)
+    cur = pred2_s4.detach()
+    dv = torch.arange(0, maxdisp // 8, dtype=left.dtype).view(1, -1, 1, 1)
+    var = torch.sum(poss4 * (dv - cur) ** 2, 1, keepdim=True).sqrt()
+
+    def up(x, scale, h, w):
+        return F.interpolate(x * scale, [h, w], mode="bilinear", align_corners=True)
+
+    def search_range(count, lo, hi, scale):
+        top = maxdisp // (2 ** scale) - 1
+        slack = torch.clamp(count - hi + lo, min=0) / 2.0
+        return torch.clamp(lo - slack, min=0, max=top), torch.clamp(hi + slack, min=0, max=top)
+
+    def samples_of(lo, hi, count):
+        k = torch.arange(1.0, count + 1, 1).view(count, 1, 1)
+        mid = lo + (hi - lo) / (count + 1) * k
+        return torch.cat((torch.floor(lo), mid, torch.ceil(hi)), 1).long().float()
+
+    def stage(k, lo, hi, count, scale, groups, tag):
+        lo1, hi1 = search_range(count + 1, lo, hi, scale)
+        smp = samples_of(lo1, hi1, count)
+        if forced_samples is not None:
+            smp = forced_samples[0 if tag == "s3" else 1].to(smp.dtype)
+        v_cat = cf_sampled_volume(fl["concat_feature" + k], fr["concat_feature" + k], smp, None)
+        v_gwc = cf_sampled_volume(fl["gw" + k], fr["gw" + k], smp, groups)
+        vol = torch.cat((v_gwc, v_cat, smp.unsqueeze(1)), 1)
+        c0 = _cf_dres(cx, vol, f"confidence0_{tag}", f"confidence1_{tag}")
+        o1 = hourglass_pcw(cx, c0, f"confidence2_{tag}")
+        o2 = hourglass_pcw(cx, o1, f"confidence3_{tag}")
+        poss = F.softmax(_cf_classif(cx, o2, f"confidence_classif1_{tag}"), dim=1)
+        return c0, o1, poss, smp
+
+    g3, b3, g2, b2 = sd["gamma_s3"], sd["beta_s3"], sd["gamma_s2"], sd["beta_s2"]
+    lo = up(cur - (g3 + 1) * var - b3, 2, H // 4, W // 4)
+    hi = up(cur + (g3 + 1) * var + b3, 2, H // 4, W // 4)
+    c0_s3, o1_s3, poss3, smp3 = stage("3", lo, hi, 14, 2, 40, "s3")
+    pred1_s3 = torch.sum(poss3 * smp3, 1, keepdim=True)
+    cur = pred1_s3.detach()
+    var = torch.sum(poss3 * (cur - smp3) ** 2, 1, keepdim=True).sqrt()
+    lo = up(cur - (g2 + 1) * var - b2, 2, H // 2, W // 2)
+    hi = up(cur + (g2 + 1) * var + b2, 2, H // 2, W // 2)
+    c0_s2, o1_s2, poss2, smp2 = stage("2", lo, hi, 10, 1, 20, "s2")
+    pred1_s2 = torch.sum(poss2 * smp2, 1, keepdim=True)
+    if not training:
+        out = up(pred1_s2, 2, H, W).squeeze(1)
+        return (out, cx) if return_ctx else out
+
+    def head(x, p):
+        c = F.conv3d(mish(convbn_3d(cx, x, p + ".0")), sd[p + ".2.weight"], None, 1, 1)
+        return regression_head(c, maxdisp, H, W, align_corners=True)
+
+    def sampled(x, p, smp, scale):
+        pr = F.softmax(_cf_classif(cx, x, p), dim=1)
+        return up(torch.sum(pr * smp, 1, keepdim=True), scale, H, W).squeeze(1)
+
+    # evaluation order of the reference (cfnet.py:609-651): classif0, classif1, then the stage-3 and stage-2 side heads
+    p0, p1 = head(cost0_4, "classif0"), head(out1_4, "classif1")
+    out = [p0, p1, up(pred2_s4, 8, H, W).squeeze(1), sampled(c0_s3, "confidence_classif0_s3", smp3, 4),
+           sampled(o1_s3, "confidence_classifmid_s3", smp3, 4), up(pred1_s3, 4, H, W).squeeze(1),
+           sampled(c0_s2, "confidence_classif0_s2", smp2, 2), sampled(o1_s2, "confidence_classifmid_s2", smp2, 2),
+           up(pred1_s2, 2, H, W).squeeze(1)]
+    return (out, cx) if return_ctx else out

@@ -5,6 +5,7 @@ from .GwcNet import GwcNet, GwcNet_G, GwcNet_GC  # noqa: F401
 from .PSMNet import PSMNet  # noqa: F401
 from .ACVNet import ACVNet  # noqa: F401
 from .PCWNet import PCWNet_G, PCWNet_GC  # noqa: F401
+from .CFNet import CFNet  # noqa: F401
 from . import IGEVStereo  # noqa: F401  (initial-volume entry points only)
 
 

@@ -154,6 +154,18 @@ def _pad_channels(t, C):
     return out
 
 
+def pad_input_channels(x, w):
+    """Zero-pad the channel axis of an NDHWC activation and dim 1 of a conv weight [Cout, Cin, k, k, k] to the next
+    multiple of 8 (the implicit-GEMM kernels take K in steps of 8)."""
+    Cin = x.shape[-1]
+    Cp = (Cin + 7) // 8 * 8
+    if Cp == Cin:
+        return x, w
+    wp = w.new_zeros(w.shape[0], Cp, *w.shape[2:])
+    wp[:, :Cin] = w
+    return _pad_channels(x, Cp), wp
+
+
 # --------------------------------------------------------------------------------------- raw convs
 def conv_out_dims(D, H, W, ks, stride):
     pad = ks // 2
@@ -257,6 +269,11 @@ class ConvRawFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, ks, stride, transposed, want_stats):
         _chk(x, "x", 5)
+        ctx.cin_true = None
+        if not transposed and x.shape[-1] % 8 != 0:
+            # GEMM-K (input channels) in steps of 8: zero-pad odd widths (CFNet's 65- and 33-channel cascade volumes)
+            ctx.cin_true = x.shape[-1]
+            x, w = pad_input_channels(x, w)
         if _is_c1(w, ks, stride, transposed) and not want_stats:
             z, stats = conv3d_c1_forward(x, w.contiguous()), None
         elif transposed:
@@ -317,6 +334,11 @@ class ConvRawFn(torch.autograd.Function):
                     gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
                     x_w = x if Ci % 32 == 0 else _pad_channels(x, (Ci + 31) // 32 * 32)
                     gw = conv3d_wgrad(x_w, gz_w, ks, stride)[:Co, :Ci].reshape(w.shape)
+        if ctx.cin_true is not None:
+            if gx is not None:
+                gx = gx[..., :ctx.cin_true].contiguous()
+            if gw is not None:
+                gw = gw[:, :ctx.cin_true].contiguous()
         return gx, gw, None, None, None, None
 
 

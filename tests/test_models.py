@@ -573,3 +573,83 @@ def test_pcwnet_gc_train_step_gpu():
         assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
     n, _ = _check_grads(m, ref_sd, sd64)
     assert n > 400
+
+
+# ------------------------------------------------------------------------------ CFNet
+def test_cfnet_state_dict_keys_match_reference():
+    import json
+    import os
+    from stereo_toolbox_amd.models import CFNet
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "state_dict_keys_cfnet.json")))["CFNet"]
+    mine = [[k, list(v.shape)] for k, v in CFNet(64).state_dict().items()]
+    assert mine == ref
+
+
+def _cfnet_filled(D):
+    from stereo_toolbox_amd.models import CFNet
+    m, sd = _filled(CFNet, D)
+    with torch.no_grad():                       # the range parameters start at 0 in the reference; exercise them
+        m.gamma_s3.fill_(0.25); m.beta_s3.fill_(0.5); m.gamma_s2.fill_(0.15); m.beta_s2.fill_(0.3)
+    for k, v in (("gamma_s3", 0.25), ("beta_s3", 0.5), ("gamma_s2", 0.15), ("beta_s2", 0.3)):
+        sd[k].fill_(v)
+    return m, sd
+
+
+def test_cfnet_eval_parity(env, parity_log):
+    """Whole-model eval forward vs the oracle (pinned exactly to the reference at this shape).  The cascade draws INTEGER
+    disparity samples: a sample may legitimately flip at an isolated pixel when the previous stage differs in the last
+    fp32 bits, which moves the output there by up to a sample step -- a handful of such pixels is tolerated, the rest
+    must meet the 1e-3 bar."""
+    D = 64
+    m, sd = _cfnet_filled(D)
+    m = m.to(env.device).eval()
+    left, right = synthetic_tensor((1, 3, 64, 128), 1), synthetic_tensor((1, 3, 64, 128), 2)
+    with env.ctx(), torch.no_grad():
+        got = m(left.to(env.device), right.to(env.device)).cpu()
+    ref = O.cfnet_forward(sd, left, right, D)
+    assert got.shape == ref.shape == (1, 64, 128)
+    err = (got - ref).abs()
+    bad = (err > 1e-3).sum().item()
+    parity_log(f"cfnet_eval[{env.name}]", max_abs=err.max().item(), median_abs=err.median().item(), pixels_over_1e_3=bad)
+    assert bad <= 0.01 * err.numel(), (bad, err.max().item())
+    assert err.median().item() < 1e-4
+
+
+def test_cfnet_train_parity(env):
+    """The 9 train-mode predictions, the loss and every parameter gradient vs the fp64-calibrated oracle, with the integer
+    disparity samples of both cascade stages taken from the oracle run (forced on the product: see cfnet.forced_samples)."""
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    if env.name == "emu":
+        pytest.skip("CFNet train step: covered on the GPU (the emulator runs the eval forward and the oracle pins the train path)")
+    D, w = 64, (0.5, 0.5, 0.7, 0.5, 0.7, 1.0, 0.5, 0.7, 1.0)
+    m, sd = _cfnet_filled(D)
+    m = m.to(env.device).train()
+    B = 2
+    left, right = synthetic_tensor((B, 3, 64, 128), 1), synthetic_tensor((B, 3, 64, 128), 2)
+    gt = synthetic_tensor((B, 64, 128), 3, lo=0.0, hi=float(D - 2))
+    # oracle first: its samples are forced on the fp64 run and on the product
+    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    drawn = []
+    orig = O.cf_sampled_volume
+    O.cf_sampled_volume = lambda l, r, s, g: (drawn.append(s) or orig(l, r, s, g))
+    try:
+        rp = O.cfnet_forward(ref_sd, left, right, D, training=True)
+    finally:
+        O.cf_sampled_volume = orig
+    forced = (drawn[0], drawn[2])                                   # (concat, gwc) calls per stage share the samples
+    O.smooth_l1_multi(rp, gt, D, w).backward()
+    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    rp64 = O.cfnet_forward(sd64, left.double(), right.double(), D, training=True, forced_samples=forced)
+    O.smooth_l1_multi(rp64, gt.double(), D, w).backward()
+    m.forced_samples = tuple(s.to(env.device) for s in forced)
+    with env.ctx():
+        preds = m(left.to(env.device), right.to(env.device))
+        loss = masked_smooth_l1_multi(preds, gt.to(env.device), D, w)
+        loss.backward()
+    assert len(preds) == 9
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
+        assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
+    n, _ = _check_grads(m, ref_sd, sd64)
+    assert n > 500

@@ -208,3 +208,41 @@ def test_gwc_gc_train_step():
         if k.startswith("grad:"):
             close(sd[k[5:]].grad, v, 1e-4)
     close(cx.new_stats["dres2.conv4.0.1.running_mean"], g["rm:dres2.conv4.0.1"])
+
+
+def test_cfnet():
+    """CFNet: whole-model eval + the 9 train outputs, loss, named gradient slices and running statistics
+    against the reference (tests/golden/make_golden_cfnet.py)."""
+    import torch.nn.functional as F_
+    g = load("cfnet.npz")
+    D, loss_w = 64, (0.5, 0.5, 0.7, 0.5, 0.7, 1.0, 0.5, 0.7, 1.0)
+    from stereo_toolbox_amd.models.CFNet import CFNet
+    sd = CFNet(D).state_dict()
+    fill_state_dict(sd)
+    sd["gamma_s3"].fill_(0.25); sd["beta_s3"].fill_(0.5); sd["gamma_s2"].fill_(0.15); sd["beta_s2"].fill_(0.3)
+    assert state_dict_digest(sd) == int(g["digest"])
+    left, right = synthetic_tensor((1, 3, 64, 128), 1), synthetic_tensor((1, 3, 64, 128), 2)
+    gt = synthetic_tensor((1, 64, 128), 3, lo=0.0, hi=60.0)
+    with torch.no_grad():
+        close(O.cfnet_forward({k: v.clone() for k, v in sd.items()}, left, right, D), g["eval"], 1e-5)
+    tsd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    # train mode with the integer disparity samples the reference drew (a single flipped sample moves every cascade
+    # prediction by O(1) px under batch-stat BN; the sampling itself is pinned by the exact eval-mode match above)
+    forced = (g["samples_s3"].float(), g["samples_s2"].float())
+    preds, cx = O.cfnet_forward(tsd, left, right, D, training=True, return_ctx=True, forced_samples=forced)
+    assert len(preds) == 9
+    mask = ((gt > 0) & (gt < D - 1)).float()
+    loss = sum(w * (F_.smooth_l1_loss(p, gt, reduction="none") * mask).sum() / mask.sum() for p, w in zip(preds, loss_w))
+    loss.backward()
+    for i, p in enumerate(preds):
+        close(p.detach(), g[f"pred{i}"], 1e-4)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    for key in g.keys():
+        if key.startswith("grad_"):
+            k = key[5:]
+            gr = tsd[k].grad
+            close(gr[:2] if gr.dim() > 1 else gr, g[key], 2e-3)
+        elif key.startswith("nograd_"):
+            assert tsd[key[7:]].grad is None
+    close(cx.new_stats["dres3.conv1.0.1.running_mean"], g["rm_dres3_conv1"], 1e-5)
+    close(cx.new_stats["confidence2_s2.conv6.1.running_var"], g["rv_conf2_s2_conv6"], 1e-5)

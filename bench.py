@@ -82,7 +82,7 @@ class KernelTimer:
         return wrapper
 
     def install_conv(self):
-        """3x3x3 stride-1 Conv3d with Cin = 32, Cout <= 32: the launches served by conv3d_march_kernel<1,*,2>."""
+        """3x3x3 stride-1 Conv3d with Cin = 32, Cout <= 32: the launches served by conv3d_marchw_kernel (one launch each)."""
         from stereo_toolbox_amd import ops
 
         def units(x, wp, Cout, ks, stride, *a, **k):
@@ -377,8 +377,8 @@ def main(argv=None):
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
         elif ks:
             ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e12
-            src = first_existing("r02_pmc_conv3d_march.txt", "r01_pmc_conv3d_march.txt")
-            roof = {"bound": "mfma", "kernel": "conv3d_march_kernel<1,*,2> (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA)",
+            src = first_existing("r02_pmc_conv3d_marchw.txt", "r01_pmc_conv3d_march.txt")
+            roof = {"bound": "mfma", "kernel": "conv3d_marchw_kernel (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA, weights resident in LDS)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": committed_pmc_traffic(src),
                     "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "

@@ -1468,6 +1468,7 @@ static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
 extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks,
                                                        int stride) {
     const int npairs = (CF / 32) * (CC / 32);
+    if (npairs < 1 || B < 1 || Dc < 1 || Hc < 1 || Wc < 1) return 0;   // stx_conv3d_wgrad rejects these shapes
     const int rows = (ks == 1) ? 8 : 27;
     // sized for the largest chunk count any tile/pipeline choice can produce (they are tuning switches)
     int cmax = 1;
@@ -1484,7 +1485,9 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
                                 int Wf, int CF, int Dc, int Hc, int Wc, int CC, int ks, int stride, void* stream) {
     stx_begin();
     STX_REQUIRE(f && c && dw && workspace && B > 0, "conv3d_wgrad: null operand");
-    STX_REQUIRE(CF % 32 == 0 && CC % 32 == 0, "conv3d_wgrad: channel counts (%d, %d) must be multiples of 32", CF, CC);
+    STX_REQUIRE(CF >= 32 && CC >= 32 && CF % 32 == 0 && CC % 32 == 0,
+                "conv3d_wgrad: channel counts (%d, %d) must be positive multiples of 32", CF, CC);
+    STX_REQUIRE(Dc > 0 && Hc > 0 && Wc > 0, "conv3d_wgrad: empty volume");
     STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1), "conv3d_wgrad: ks/stride");
     WgradArgs a;
     a.f = f; a.c = c; a.slab = workspace;

@@ -5,9 +5,12 @@
 // mode of the per-pixel distribution, re-normalised.
 //
 // The reference builds ~15 full-volume temporaries (repeat, diff, flip, int masks, products: ~6 GB of traffic
-// at 576x960, D=192); here one thread owns one pixel and walks its D probabilities in place (lanes run along W,
-// so every access of a wave is a contiguous row segment).  Roofline: HBM, algorithmic bytes = the volume once
-// (the later passes of a pixel hit L2).
+// at 576x960, D=192); here one thread owns one pixel (lanes run along W, so every access of a wave is a contiguous
+// row segment).  The walks over a pixel's D probabilities are data dependent (arg-max, then outwards to the edges of
+// the mode, then over the support) and touch every entry 3-10 times, so a wave first copies its 64 columns into LDS
+// ([d][lane]: a lane only ever reads its own column -- no barrier, no bank conflict) with 32 loads in flight per lane,
+// and walks them there: HBM sees the volume exactly once.  Roofline: HBM, algorithmic bytes = the volume once.
+// Columns longer than ES_LDS_MAX_D entries (160 KiB / 256 B) are walked in place instead (the round-1 path).
 //
 // Mode support around the arg-max of a sequence s[0..D) (extended by s[-1] = s[D] = 1):
 //   hi = (first j > index with s[j] > s[j-1]) - 1     (-1 when there is none, i.e. s[D-1] >= 1)
@@ -19,6 +22,22 @@
 namespace {
 
 constexpr int ES_THREADS = 256;
+constexpr int ES_WAVE = 64;            // LDS-staged kernels: one wave per workgroup, D * 256 B of LDS
+constexpr int ES_LDS_MAX_D = 600;      // 150 KiB
+constexpr int ES_STAGE = 32;           // loads in flight per lane while staging
+
+// copy column `p` (stride HW) into the lane's LDS column (stride ES_WAVE)
+__device__ __forceinline__ void es_stage_column(const float* __restrict__ p, size_t HW, int D, float* col) {
+    int d0 = 0;
+    for (; d0 + ES_STAGE <= D; d0 += ES_STAGE) {
+        float r[ES_STAGE];
+#pragma unroll
+        for (int k = 0; k < ES_STAGE; ++k) r[k] = p[(size_t)(d0 + k) * HW];
+#pragma unroll
+        for (int k = 0; k < ES_STAGE; ++k) col[(d0 + k) * ES_WAVE] = r[k];
+    }
+    for (; d0 < D; ++d0) col[d0 * ES_WAVE] = p[(size_t)d0 * HW];
+}
 
 struct ModeRange { int index, lo, hi; };
 
@@ -75,22 +94,36 @@ __device__ __forceinline__ void es_write_aux(float* aux, size_t b, int HW, int i
     a[4 * (size_t)HW] = S;
 }
 
-__global__ __launch_bounds__(ES_THREADS) void unimodal_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                             float* __restrict__ aux, int D, int HW) {
-    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
-    if (i >= HW) return;
-    const float* p = x + (size_t)b * D * HW + i;
+// p: the pixel's column with stride hw (global memory in place, or its LDS copy)
+__device__ __forceinline__ void unimodal_pixel(const float* p, size_t hw, float* __restrict__ out, float* __restrict__ aux,
+                                               int D, int HW, int b, int i) {
     float best = p[0];
     int bi = 0;
     for (int d = 1; d < D; ++d) {
-        const float v = p[(size_t)d * HW];
+        const float v = p[(size_t)d * hw];
         if (v > best) { best = v; bi = d; }
     }
-    const size_t hw = (size_t)HW;
     auto f = [&](int d) { return p[(size_t)d * hw]; };
     const ModeRange m = es_mode_bounds(f, D, bi, best);
     out[(size_t)b * HW + i] = es_expect(p, hw, m.lo, m.hi, 1, 0);
     es_write_aux(aux, b, HW, i, m.lo, m.hi, 1, 0, p, hw);
+}
+
+__global__ __launch_bounds__(ES_THREADS) void unimodal_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                             float* __restrict__ aux, int D, int HW) {
+    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    unimodal_pixel(x + (size_t)b * D * HW + i, (size_t)HW, out, aux, D, HW, b, i);
+}
+
+__global__ __launch_bounds__(ES_WAVE) void unimodal_lds_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                              float* __restrict__ aux, int D, int HW) {
+    STX_DYN_SMEM(smem);
+    float* col = reinterpret_cast<float*>(smem) + threadIdx.x;
+    const int i = blockIdx.x * ES_WAVE + threadIdx.x, b = blockIdx.y;
+    const int ic = i < HW ? i : HW - 1;                      // lanes past the row end stage a valid column and drop it
+    es_stage_column(x + (size_t)b * D * HW + ic, (size_t)HW, D, col);
+    if (i < HW) unimodal_pixel(col, (size_t)ES_WAVE, out, aux, D, HW, b, i);
 }
 
 // 5-tap box blur along D with zero padding (conv1d, padding='same', weight 1/5), entries of [zlo, zhi] forced to 0
@@ -146,13 +179,8 @@ __device__ __forceinline__ void es_modal_range(const BlurSeq& s, int* lo, int* h
     if (*hi > s.D - 1) *hi = s.D - 1;
 }
 
-__global__ __launch_bounds__(ES_THREADS) void dominant_modal_kernel(const float* __restrict__ x,
-                                                                   float* __restrict__ out, float* __restrict__ aux,
-                                                                   int D, int HW) {
-    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
-    if (i >= HW) return;
-    const float* p = x + (size_t)b * D * HW + i;
-    const size_t hw = (size_t)HW;
+__device__ __forceinline__ void dominant_modal_pixel(const float* p, size_t hw, float* __restrict__ out,
+                                                     float* __restrict__ aux, int D, int HW, int b, int i) {
     BlurSeq s{p, hw, D, 1, 0};
     int a1, b1, a2, b2;
     es_modal_range(s, &a1, &b1);                // main mode of the blurred volume
@@ -166,6 +194,25 @@ __global__ __launch_bounds__(ES_THREADS) void dominant_modal_kernel(const float*
     out[(size_t)b * HW + i] = (sy >= sz) ? es_expect(p, hw, a1, b1, 1, 0) : es_expect(p, hw, a2, b2, a1, b1);
     if (sy >= sz) es_write_aux(aux, b, HW, i, a1, b1, 1, 0, p, hw);
     else es_write_aux(aux, b, HW, i, a2, b2, a1, b1, p, hw);
+}
+
+__global__ __launch_bounds__(ES_THREADS) void dominant_modal_kernel(const float* __restrict__ x,
+                                                                   float* __restrict__ out, float* __restrict__ aux,
+                                                                   int D, int HW) {
+    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    dominant_modal_pixel(x + (size_t)b * D * HW + i, (size_t)HW, out, aux, D, HW, b, i);
+}
+
+__global__ __launch_bounds__(ES_WAVE) void dominant_modal_lds_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ out, float* __restrict__ aux,
+                                                                    int D, int HW) {
+    STX_DYN_SMEM(smem);
+    float* col = reinterpret_cast<float*>(smem) + threadIdx.x;
+    const int i = blockIdx.x * ES_WAVE + threadIdx.x, b = blockIdx.y;
+    const int ic = i < HW ? i : HW - 1;
+    es_stage_column(x + (size_t)b * D * HW + ic, (size_t)HW, D, col);
+    if (i < HW) dominant_modal_pixel(col, (size_t)ES_WAVE, out, aux, D, HW, b, i);
 }
 
 // Backward of both estimators.  The support mask is a constant of the graph (`x * mask.data`,
@@ -190,30 +237,48 @@ __global__ __launch_bounds__(ES_THREADS) void modal_bwd_kernel(const float* __re
 
 }  // namespace
 
+static int modal_launch(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream,
+                        const char* what) {
+    static const int in_place = getenv("STX_MODAL_INPLACE") ? atoi(getenv("STX_MODAL_INPLACE")) : 0;   // A/B switch
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= ES_LDS_MAX_D && !in_place) {
+        const dim3 grid(stx_cdiv(HW, ES_WAVE), B);
+        const size_t lds = (size_t)D * ES_WAVE * sizeof(float);
+        if (kind == 0) {
+            if (lds > 64 * 1024)
+                hipFuncSetAttribute((const void*)unimodal_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(unimodal_lds_kernel, grid, dim3(ES_WAVE), lds, st, x, out, aux, D, HW);
+        } else {
+            if (lds > 64 * 1024)
+                hipFuncSetAttribute((const void*)dominant_modal_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds);
+            hipLaunchKernelGGL(dominant_modal_lds_kernel, grid, dim3(ES_WAVE), lds, st, x, out, aux, D, HW);
+        }
+    } else {
+        const dim3 grid(stx_cdiv(HW, ES_THREADS), B);
+        if (kind == 0) hipLaunchKernelGGL(unimodal_kernel, grid, dim3(ES_THREADS), 0, st, x, out, aux, D, HW);
+        else hipLaunchKernelGGL(dominant_modal_kernel, grid, dim3(ES_THREADS), 0, st, x, out, aux, D, HW);
+    }
+    return stx_check_launch(what);
+}
+
 extern "C" int stx_unimodal_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "unimodal_fwd: bad shape");
-    hipLaunchKernelGGL(unimodal_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0, (hipStream_t)stream, x,
-                       out, (float*)nullptr, D, HW);
-    return stx_check_launch("unimodal_fwd");
+    return modal_launch(x, out, nullptr, B, D, HW, 0, stream, "unimodal_fwd");
 }
 
 extern "C" int stx_dominant_modal_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "dominant_modal_fwd: bad shape");
-    hipLaunchKernelGGL(dominant_modal_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0,
-                       (hipStream_t)stream, x, out, (float*)nullptr, D, HW);
-    return stx_check_launch("dominant_modal_fwd");
+    return modal_launch(x, out, nullptr, B, D, HW, 1, stream, "dominant_modal_fwd");
 }
 
 // kind 0: unimodal, 1: dominant-modal; aux [B][5][HW] is what stx_modal_bwd needs (may be null: plain forward)
 extern "C" int stx_modal_fwd(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream) {
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0 && (kind == 0 || kind == 1), "modal_fwd: bad arguments");
-    const dim3 grid(stx_cdiv(HW, ES_THREADS), B);
-    if (kind == 0) hipLaunchKernelGGL(unimodal_kernel, grid, dim3(ES_THREADS), 0, (hipStream_t)stream, x, out, aux, D, HW);
-    else hipLaunchKernelGGL(dominant_modal_kernel, grid, dim3(ES_THREADS), 0, (hipStream_t)stream, x, out, aux, D, HW);
-    return stx_check_launch("modal_fwd");
+    return modal_launch(x, out, aux, B, D, HW, kind, stream, "modal_fwd");
 }
 
 extern "C" int stx_modal_bwd(const float* g, const float* out, const float* aux, float* gx, int B, int D, int HW,

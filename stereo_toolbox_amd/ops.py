@@ -300,8 +300,10 @@ class ConvRawFn(torch.autograd.Function):
             Ci, Co = w.shape[0], w.shape[1]
             if ctx.needs_input_grad[0]:   # stride-2 conv of gz with the deconv weight read as [Cout'][Cin']
                 gx, _ = conv3d_forward(gz, pack_weight(w, 0), Ci, 3, 2)
-            if ctx.needs_input_grad[1]:
-                gw = conv3d_wgrad(gz, x, 3, 2).view_as(w)
+            if ctx.needs_input_grad[1]:   # the wgrad kernel works on 32-channel pairs: pad CFNet's 16-wide deconvs
+                gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
+                x_w = x if Ci % 32 == 0 else _pad_channels(x, (Ci + 31) // 32 * 32)
+                gw = conv3d_wgrad(gz_w, x_w, 3, 2)[:Ci, :Co].reshape(w.shape)
         else:
             Co, Ci = w.shape[0], w.shape[1]
             c1 = _is_c1(w, ks, stride, transposed)

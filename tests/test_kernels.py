@@ -182,7 +182,8 @@ def test_estimators(be):
     _close(y, torch.softmax(z, 1), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22), (1, 192, 6, 40, 31), (2, 16, 6, 10, 0)])
+@pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22), (1, 192, 6, 40, 31), (2, 16, 6, 10, 0),
+                                  (1, 608, 2, 5, 3)])   # D > 600: columns walked in place instead of in LDS
 def test_modal_estimators(be, case):
     """unimodal / dominant-modal estimators vs the oracle (which is pinned bitwise to the reference, tests/golden).
     The mode choice is discrete: a pixel may legitimately flip when the blurred volume (different fp32 summation order

@@ -619,8 +619,10 @@ def test_cfnet_train_parity(env):
     """The 9 train-mode predictions, the loss and every parameter gradient vs the fp64-calibrated oracle, with the integer
     disparity samples of both cascade stages taken from the oracle run (forced on the product: see cfnet.forced_samples)."""
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi
-    if env.name == "emu":
-        pytest.skip("CFNet train step: covered on the GPU (the emulator runs the eval forward and the oracle pins the train path)")
+    import os
+    if env.name == "emu" and not os.environ.get("STX_TEST_SLOW"):
+        pytest.skip("CFNet train step on the emulator takes tens of minutes (STX_TEST_SLOW=1 runs it); covered on the GPU, "
+                    "its layer shapes by test_conv_block_autograd_layer_shapes")
     D, w = 64, (0.5, 0.5, 0.7, 0.5, 0.7, 1.0, 0.5, 0.7, 1.0)
     m, sd = _cfnet_filled(D)
     m = m.to(env.device).train()
@@ -653,3 +655,61 @@ def test_cfnet_train_parity(env):
         assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
     n, _ = _check_grads(m, ref_sd, sd64)
     assert n > 500
+
+
+# ------------------------------------------------------------------------------ every layer shape, forward + backward
+# (Cin, Cout, ks, stride, transposed): the Conv3d / ConvTranspose3d shapes of all model families incl. CFNet's 16-wide
+# 1/2-resolution stage and its zero-padded 65- / 33-channel cascade volumes.  The train-step tests of the wide models run
+# on the GPU only; this one drives the same autograd wiring (padding, slicing, weight re-packing) on the emulator too.
+LAYER_SHAPES = [
+    (32, 32, 3, 1, False), (64, 32, 3, 1, False), (40, 32, 3, 1, False), (32, 64, 3, 2, False), (64, 64, 1, 1, False),
+    (64, 32, 3, 2, True), (128, 64, 3, 2, True),
+    (16, 16, 3, 1, False), (16, 32, 3, 2, False), (32, 16, 3, 2, True), (16, 16, 1, 1, False), (33, 16, 3, 1, False),
+    (65, 32, 3, 1, False), (96, 64, 3, 1, False), (32, 1, 3, 1, False), (16, 1, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES, ids=lambda s: "x".join(str(int(v)) for v in s))
+def test_conv_block_autograd_layer_shapes(env, shape):
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stereo_toolbox_amd.aggregation import conv_block
+    Cin, Cout, ks, stride, transposed = shape
+    torch.manual_seed(Cin * 131 + Cout)
+    B, D, H, W = 2, (2 if transposed else 4), 3, (9 if transposed else 18)
+    if transposed:
+        conv = nn.ConvTranspose3d(Cin, Cout, 3, padding=1, output_padding=1, stride=2, bias=False)
+    else:
+        conv = nn.Conv3d(Cin, Cout, ks, stride, ks // 2, bias=False)
+    bn = nn.BatchNorm3d(Cout) if Cout > 1 else None
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+        if bn is not None:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(B, Cin, D, H, W)
+    # reference: stock torch autograd in fp64
+    xr = x.double().requires_grad_()
+    wr = conv.weight.detach().double().requires_grad_()
+    zr = (F.conv_transpose3d(xr, wr, None, 2, 1, 1) if transposed else F.conv3d(xr, wr, None, stride, ks // 2))
+    if bn is not None:
+        gr, br = bn.weight.detach().double().requires_grad_(), bn.bias.detach().double().requires_grad_()
+        zr = F.relu(F.batch_norm(zr, None, None, gr, br, True, 0.1, bn.eps))
+    gy = torch.randn(zr.shape)
+    zr.backward(gy.double())
+    # product
+    conv, bn = conv.to(env.device).train(), (bn.to(env.device).train() if bn is not None else None)
+    xp = x.permute(0, 2, 3, 4, 1).contiguous().to(env.device).requires_grad_()
+    with env.ctx():
+        y = conv_block(xp, conv, bn, relu=bn is not None)
+        y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().to(env.device))
+
+    def close(got, ref, what):
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (what, err, ref.abs().max().item())
+    close(y.permute(0, 4, 1, 2, 3), zr.detach(), "out")
+    close(xp.grad.permute(0, 4, 1, 2, 3), xr.grad, "dx")
+    close(conv.weight.grad, wr.grad, "dw")
+    if bn is not None:
+        close(bn.weight.grad, gr.grad, "dgamma")
+        close(bn.bias.grad, br.grad, "dbeta")

@@ -65,7 +65,7 @@ def pack(w, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--only", default="", help="substring filter on kernel names")
+    ap.add_argument("--only", default="", help="substring filter(s) on kernel names, comma separated")
     ap.add_argument("--skip-wgrad", action="store_true")
     ap.add_argument("--H", type=int, default=576)
     ap.add_argument("--W", type=int, default=960)
@@ -75,8 +75,10 @@ def main():
     L = {0: (D4, H4, W4), 1: (D4 // 2, H4 // 2, W4 // 2), 2: (D4 // 4, H4 // 4, W4 // 4)}
     it = a.iters
 
+    only = [t for t in a.only.split(",") if t]
+
     def want(n):
-        return a.only in n
+        return not only or any(t in n for t in only)
 
     if want("cost_volume"):
         Lg, Rg = torch.randn(B, 320, H4, W4, device=dev), torch.randn(B, 320, H4, W4, device=dev)

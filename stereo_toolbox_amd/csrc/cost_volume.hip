@@ -951,6 +951,10 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
         STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16, "cost_volume_bwd: channels per group %d not in {4,8,12,16}", cpg);
     }
     if (Cc) STX_REQUIRE(gLc && gRc, "cost_volume_bwd: concat outputs missing");
+    if (G) {      // second generation: matrix-core kernel with loader waves (cost_volume_bwd_mfma.hip); -1 = not served
+        const int rc = stx_cv_bwd_mfma(gvol, Lg, Rg, Cg, G, Cc, gLg, gRg, gLc, gRc, B, H, W, D, mask_left, stream);
+        if (rc >= 0) return rc;
+    }
     static const int no_g8 = getenv("STX_CVB_GENERIC") ? 1 : 0;
     if (G && Cg == 8 * G && G <= 40 && G + 2 * Cc <= 64 && Cc * CV_WT <= CVG_THREADS && !no_g8) {
         const size_t lds8 = ((size_t)CVG_DC * CV_WT * CVG_GS + (size_t)CVG_RING * CVG_FS) * 4;

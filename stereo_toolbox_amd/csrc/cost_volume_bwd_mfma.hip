@@ -1,0 +1,392 @@
+// Cost-volume backward, second generation: the group-wise correlation gradients on the matrix cores, the volume
+// gradient streamed through LDS exactly once per side by loader waves that do nothing else.
+//
+// Backward of the same reference functions as cost_volume.hip (build_gwc_volume GwcNet/submodule.py:53-63,
+// build_concat_volume GwcNet/submodule.py:30-41 / ACVNet/submodule.py:180-191, torch.cat gwcnet.py:180 -- autograd of
+// those in the reference) for 4, 8, 12 or 16 channels per group and D' <= 48:
+//   LEFT  side:  dL[c][w] = 1/cpg * sum_d gv[g(c)][d][w]     * R[c][w - d]      dLc[c][w] = sum_d gv[G + c][d][w] (masked w >= d)
+//   RIGHT side:  dR[c][x] = 1/cpg * sum_d gv[g(c)][d][x + d] * L[c][x + d]      dRc[c][x] = sum_d gv[G + Cc + c][d][x + d]
+// gv = gradient of the volume, NDHWC [B][D'][H][W][G + 2 Cc].
+//
+// Why.  The first-generation kernel (cost_volume_bwd_g8_kernel) is instruction- and latency-bound: 443 VALU instructions
+// per wave and 8-disparity slice for 128 useful FMAs, 2 barriers per slice, ~4 waves per SIMD: 0.31 ms = 24 % of the HBM
+// roofline at 576x960 although HBM sees the volume only once (PMC: FETCH 514 MB).
+//
+// Formulation.  A MACRO-UNIT is (b, h, side, 16 output columns), all D'; it is walked in CHUNKS of 8 disparities.  In
+// "tile coordinates" j = 0..15 both sides look alike: the chunk image is img[dd][j][g] = gv[g][d0 + dd][col(j, dd)] with
+// col = w0 + j (LEFT) or x0 + j + d0 + dd (RIGHT: the sheared set), and the partner feature column of (j, dd) is
+// f = w0 + j - d0 - dd (LEFT, features R) or x0 + j + d0 + dd (RIGHT, features L).  For one feature column f the update
+//   out[c][j] += feat[c][f] * img[dd(j, f)][j][g(c)]          (dd = j + 7 - fi  |  fi - j,  fi = f - first column of the chunk)
+// is an outer product per group, i.e. one v_mfma_f32_4x4x1_16B_f32: 16 blocks = 4 groups x 4 column quads, block rows =
+// 4 channels of the group, block columns = the 4 columns of the quad, K = 1 = the feature column.  A chunk needs 23 feature
+// columns; per column and group quad one ds_read_b32 gathers the B operand (the image diagonal; entries outside the chunk
+// read a zero word) and one ds_read_b32 per channel quad the A operand (broadcast over the column quads).
+// LDS layouts make both gathers conflict-free for both sides: image voxel stride G, d-row pitch 16 G + pad with
+// (pitch + G) mod 32 = 4  (LEFT walks +pitch+G per column, RIGHT -pitch+G: both odd multiples of 4 banks, the 4 groups of a
+// block row fill the gaps); feature ring [64 columns][channel quad][G][4].
+//
+// Roles inside a workgroup (one per CU):
+//   * LOADER waves: lane = (column j, float4 q of the voxel), one disparity row per load, two chunks in flight in registers
+//     (16 x 16 B per lane); gwc quads -> ds_write_b128 into the image (double buffered), concat quads are summed in the
+//     loader's registers (a lane keeps its (j, q) for the whole macro-unit: the RIGHT side's shear makes x = x0 + j constant
+//     as well) and written at the end of the macro-unit.  The feature ring slides with the tiles of an image row: 16 new
+//     columns per macro-unit (every feature element is read once per row and side), a full refill at row starts.
+//   * COMPUTE waves (4, i.e. 8 waves = 2 per SIMD with the loaders: 256 VGPRs each): up to three group quads each; per chunk 23 x (1 + cpg/4) LDS reads and 23 x cpg/4 MFMAs per group quad;
+//     accumulators (4 VGPRs per group quad and channel quad) live for the whole macro-unit and are written as 64-byte
+//     row segments of the NCHW gradients.
+//   One barrier per chunk; LEFT macro-units walk d downwards and RIGHT ones upwards so that the ring slots the next tile
+//   overwrites are dead by the time of the last chunk.
+// Macro-units are dealt in equal contiguous runs to gridDim.x workgroups; consecutive runs (the two sides of an image
+// row) sit on the same XCD, so HBM still sees the volume once.
+//
+// Roofline: HBM; algorithmic bytes = volume once + features once + feature gradients once.
+#include "cost_volume.h"
+#include "stx_common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int CVB2_T = 16;        // columns per macro-unit
+constexpr int CVB2_DC = 8;        // disparities per chunk
+constexpr int CVB2_NF = CVB2_T + CVB2_DC - 1;   // feature columns per chunk (23)
+constexpr int CVB2_RING = 64;     // feature ring columns (window D' + 15 <= 63, + slack for the 16 incoming ones)
+constexpr int CVB2_NLW = 4;       // loader waves
+constexpr int CVB2_NLTHR = CVB2_NLW * 64;
+
+struct CvbArgs {
+    const float *gv, *Lg, *Rg;
+    float *gLg, *gRg, *gLc, *gRc;
+    int B, H, W, D, G, Cc, mask_left;
+    int nt, nch, macros;           // tiles per row, chunks per macro-unit, B * H * 2 * nt
+    int S, PD, FS;                 // image voxel stride, d-row pitch, ring column stride (dwords)
+};
+
+struct CvbCursor {                 // a chunk of the workgroup's run: macro-unit m (decoded) and step i of its d walk
+    int m, i, b, h, t, side;
+};
+
+__device__ __forceinline__ int cvb_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
+    return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+__device__ __forceinline__ void cvb_decode(const CvbArgs& a, int m, CvbCursor& c) {
+    c.m = m;
+    c.t = m % a.nt;
+    const int r = m / a.nt;
+    c.side = r & 1;
+    const int bh = r >> 1;
+    c.h = bh % a.H;
+    c.b = bh / a.H;
+}
+__device__ __forceinline__ void cvb_advance(const CvbArgs& a, CvbCursor& c) {
+    if (++c.i == a.nch) {
+        c.i = 0;
+        cvb_decode(a, c.m + 1, c);
+    }
+}
+// first disparity of the chunk: LEFT walks d downwards, RIGHT upwards
+__device__ __forceinline__ int cvb_d0(const CvbArgs& a, const CvbCursor& c) {
+    return CVB2_DC * (c.side ? c.i : a.nch - 1 - c.i);
+}
+
+__device__ __forceinline__ f32x4 cvb_zero4() {
+    f32x4 z;
+    z[0] = 0.f; z[1] = 0.f; z[2] = 0.f; z[3] = 0.f;
+    return z;
+}
+
+// CPG channels per group; NCW compute waves with QPW group quads each (NCW * QPW >= G / 4)
+template <int CPG, int NCW, int QPW>
+__global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_kernel(CvbArgs a) {
+    constexpr int NQ = CPG / 4;                                    // channel quads per group
+    constexpr int NFR = 5 * CPG / 2;                               // new-column feature loads per loader lane: Cg <= 40 * CPG
+    STX_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, D = a.D, G = a.G, Cc = a.Cc, nch = a.nch;
+    const int HW = H * W, Cg = G * CPG, CT = G + 2 * Cc;
+    const int GQ = G >> 2, CQ = Cc >> 2, Q = CT >> 2;
+    const int S = a.S, PD = a.PD, FS = a.FS;
+    const int IMG = CVB2_DC * PD;                                  // dwords per image
+    const int IMGZ = IMG + G;                                      // image + G zero words (B operand of entries outside the chunk)
+    float* lds = reinterpret_cast<float*>(smem);                   // [2][IMGZ] (double buffer over chunks)
+    float* ring = lds + 2 * IMGZ;                                  // [CVB2_RING][FS]
+    const size_t dstride = (size_t)HW * CT;
+
+    const long long wg = cvb_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * wg / gridDim.x));
+    const int m1 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * (wg + 1) / gridDim.x));
+    if (m0 >= m1) return;
+    const int N = (m1 - m0) * nch;                                 // chunks of this run
+    CvbCursor cc;                                                  // the chunk the compute waves work on
+    cvb_decode(a, m0, cc);
+    cc.i = 0;
+    // the next macro-unit continues the image row of `c` (ring slides by 16 columns) / starts a new row or side (refill)
+    auto next_slides = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 < a.nt; };
+    auto next_refills = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 == a.nt; };
+
+    if (wave >= NCW) {
+        // ======================================================================= loader waves
+        const int lt = tid - NCW * 64;
+        const int q = lt & 15, j = (lt >> 4) & 15;
+        const bool gq_lane = q < GQ;
+        for (int i = lt; i < 2 * G; i += CVB2_NLTHR) lds[(i >= G ? IMGZ + IMG - G : IMG) + i] = 0.f;
+        // ---- volume gradient: two chunks in registers
+        float4 gvr[2][CVB2_DC];
+        unsigned gvok[2] = {0u, 0u};
+        float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (always executes its 8 loads -- `live` = false reads a valid dummy address: with a fixed number of loads on every
+        //  path hipcc waits for the chunk being committed with a counted vmcnt and leaves the newer chunk in flight)
+        auto issue = [&](float4 (&dst)[CVB2_DC], unsigned& okbits, const CvbCursor& c, bool live) {
+            const int d0 = cvb_d0(a, c);
+            const int col0 = c.t * CVB2_T + j + (c.side ? d0 : 0);
+            const bool want = live && (gq_lane || (c.side ? (q >= GQ + CQ && q < Q) : (q >= GQ && q < GQ + CQ)));
+            const float* row = a.gv + (((size_t)c.b * D + d0) * H + c.h) * (size_t)W * CT + 4 * q;
+            unsigned ok = 0;
+#pragma unroll
+            for (int k = 0; k < CVB2_DC; ++k) {
+                const int col = c.side ? col0 + k : col0;
+                const bool v = want && d0 + k < D && col < W;
+                dst[k] = stx_ld4(v ? row + (size_t)k * dstride + (size_t)col * CT : a.gv);
+                ok |= (v ? 1u : 0u) << k;
+            }
+            okbits = ok;
+        };
+        auto commit = [&](const float4 (&src)[CVB2_DC], unsigned okbits, const CvbCursor& c, float* img) {
+            const int d0 = cvb_d0(a, c);
+            const int w = c.t * CVB2_T + j;                          // LEFT: the voxel column (mask w >= d)
+#pragma unroll
+            for (int k = 0; k < CVB2_DC; ++k) {
+                const bool v = (okbits >> k) & 1u;
+                float4 x = src[k];
+                if (!v) x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gq_lane) stx_st4(img + k * PD + j * S + 4 * q, x);
+                else if (c.side || !a.mask_left || w >= d0 + k) { cacc.x += x.x; cacc.y += x.y; cacc.z += x.z; cacc.w += x.w; }
+            }
+            if (c.i == nch - 1) {                                    // last chunk of the macro-unit: concat sums are complete
+                const int col = c.t * CVB2_T + j;
+                const int qc = c.side ? q - GQ - CQ : q - GQ;
+                if (!gq_lane && qc >= 0 && qc < CQ && col < W) {
+                    float* o = (c.side ? a.gRc : a.gLc) + ((size_t)(c.b * Cc + 4 * qc) * H + c.h) * W + col;
+                    o[0] = cacc.x; o[(size_t)HW] = cacc.y; o[2 * (size_t)HW] = cacc.z; o[3 * (size_t)HW] = cacc.w;
+                }
+                cacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        // ---- feature ring: lane = (column lt & 15, channel (lt >> 4) + 16 i); 16 columns per batch
+        const int fcol = lt & 15, fc0 = lt >> 4;
+        auto ring_off = [&](int col, int c) {                        // [slot][channel quad][group][4]
+            const int g = c / CPG, ci = c - g * CPG;
+            return (col & (CVB2_RING - 1)) * FS + (ci >> 2) * 4 * G + g * 4 + (ci & 3);
+        };
+        float fr[NFR];
+        auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0) {   // columns col0 .. col0 + 15 of the row of c
+            const float* F = (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W;
+            const int col = col0 + fcol;
+            const bool okc = col >= 0 && col < W;
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {
+                const int ch = fc0 + 16 * i;
+                dst[i] = F[(size_t)(ch < Cg ? ch : 0) * HW + (okc ? col : 0)];
+            }
+        };
+        auto feat_commit = [&](const float (&src)[NFR], int col0) {
+            const int col = col0 + fcol;
+            const bool okc = col >= 0 && col < W;
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {
+                const int ch = fc0 + 16 * i;
+                if (ch < Cg) ring[ring_off(col, ch)] = okc ? src[i] : 0.f;
+            }
+        };
+        // first column of the window of macro-unit c: LEFT [w0 - 8 nch + 1, w0 + 15], RIGHT [x0, x0 + 8 nch + 14]
+        auto window0 = [&](const CvbCursor& c) { return c.side ? c.t * CVB2_T : c.t * CVB2_T - CVB2_DC * nch + 1; };
+        auto ring_refill = [&](const CvbCursor& c) {                 // compute waves are parked at a barrier
+            const int f0 = window0(c);
+            if constexpr (NFR <= 20) {
+                float fr2[NFR];                                      // two 16-column batches in flight
+                for (int bt = 0; bt < CVB2_RING / 16; bt += 2) {
+                    feat_issue(fr, c, f0 + 16 * bt);
+                    feat_issue(fr2, c, f0 + 16 * bt + 16);
+                    feat_commit(fr, f0 + 16 * bt);
+                    feat_commit(fr2, f0 + 16 * bt + 16);
+                }
+            } else {                                                 // 12 / 16 channels per group: one batch (registers)
+                for (int bt = 0; bt < CVB2_RING / 16; ++bt) {
+                    feat_issue(fr, c, f0 + 16 * bt);
+                    feat_commit(fr, f0 + 16 * bt);
+                }
+            }
+        };
+        // the 16 columns the NEXT macro-unit of the row adds to the window of c
+        auto incoming0 = [&](const CvbCursor& c) {
+            return c.side ? c.t * CVB2_T + CVB2_DC * nch + CVB2_T - 1 : c.t * CVB2_T + CVB2_T;
+        };
+
+        // ---- prologue
+        CvbCursor wc = cc, pc = cc;                                  // write cursor (chunk ci + 1), prefetch cursor (ci + 2)
+        issue(gvr[0], gvok[0], cc, true);
+        if (N > 1) cvb_advance(a, wc);
+        issue(gvr[1], gvok[1], wc, N > 1);
+        ring_refill(cc);
+        commit(gvr[0], gvok[0], cc, lds);
+        pc = wc;
+        __syncthreads();
+        auto step = [&](auto par, int ci) {
+            constexpr int P = decltype(par)::value;                  // ci & 1: set P holds chunk ci (already in the image)
+            // order matters for the memory counter (loads retire in order): the ring columns fetched nch - 1 steps ago are
+            // committed before anything new is issued; the chunk ci + 1 is committed with the 8 loads of chunk ci + 2 (and
+            // nothing else) behind it; the next ring columns are requested last.
+            if (cc.i == nch - 1 && next_slides(cc)) feat_commit(fr, incoming0(cc));
+            if (ci + 2 < N) cvb_advance(a, pc);
+            issue(gvr[P], gvok[P], pc, ci + 2 < N);
+            if (ci + 1 < N) commit(gvr[P ^ 1], gvok[P ^ 1], wc, lds + (P ^ 1) * IMGZ);
+            if (cc.i == 0 && next_slides(cc)) feat_issue(fr, cc, incoming0(cc));
+            __syncthreads();
+            if (cc.i == nch - 1 && next_refills(cc)) {
+                CvbCursor nx = cc;
+                cvb_advance(a, nx);
+                ring_refill(nx);
+                __syncthreads();
+            }
+            if (ci + 1 < N) cvb_advance(a, wc);
+            cvb_advance(a, cc);
+        };
+        for (int ci = 0; ci < N; ci += 2) {
+            step(std::integral_constant<int, 0>{}, ci);
+            if (ci + 1 < N) step(std::integral_constant<int, 1>{}, ci + 1);
+        }
+        return;
+    }
+
+    // =========================================================================== compute waves
+    const int n = lane & 3, gl = (lane >> 2) & 3, jq = lane >> 4;
+    const int j = 4 * jq + n;
+    const int joff = j * S + gl + 4 * wave;                          // B operand: img[dd][j][4 gq + gl], gq = wave + u NCW
+    const float* abase = ring + (lane & 15) + 16 * wave;             // A operand: ring[slot][cq][4 gq + gl][n]
+    const float inv = 1.0f / (float)CPG;
+    f32x4 acc[QPW][NQ];
+#pragma unroll
+    for (int u = 0; u < QPW; ++u)
+#pragma unroll
+        for (int cq = 0; cq < NQ; ++cq) acc[u][cq] = cvb_zero4();
+    // image offset of the B operand per feature column of a chunk; depends on the side only: the entry (j, dd) pairs with
+    // column fi = j + 7 - dd (LEFT) / j + dd (RIGHT); entries outside the chunk read the zero words behind the image
+    int bo[CVB2_NF];
+    int bo_side = -1;
+    __syncthreads();                                                 // prologue: ring + image 0
+    for (int ci = 0; ci < N; ++ci) {
+        if (cc.side != bo_side) {
+            bo_side = cc.side;
+#pragma unroll
+            for (int fi = 0; fi < CVB2_NF; ++fi) {
+                const int dd = cc.side ? fi - j : j + (CVB2_DC - 1) - fi;
+                bo[fi] = ((unsigned)dd < (unsigned)CVB2_DC) ? dd * PD + joff : IMG + gl + 4 * wave;
+            }
+        }
+        const float* img = lds + (ci & 1) * IMGZ;
+        const int d0 = cvb_d0(a, cc);
+        const int tile0 = cc.t * CVB2_T;
+        const int fbase = cc.side ? tile0 + d0 : tile0 - d0 - (CVB2_DC - 1);
+#pragma unroll
+        for (int u = 0; u < QPW; ++u) {
+            const int gq = wave + u * NCW;
+            if (gq < GQ) {                                           // wave-uniform
+                // all operands of the chunk first (the reads of a wave do not wait on each other), then the MFMAs
+                float bv[CVB2_NF], av[CVB2_NF][NQ];
+#pragma unroll
+                for (int fi = 0; fi < CVB2_NF; ++fi) {
+                    bv[fi] = img[bo[fi] + 4 * NCW * u];
+                    const float* rp = abase + ((fbase + fi) & (CVB2_RING - 1)) * FS + 16 * NCW * u;
+#pragma unroll
+                    for (int cq = 0; cq < NQ; ++cq) av[fi][cq] = rp[cq * 4 * G];
+                }
+                STX_SCHED_BARRIER();
+#pragma unroll
+                for (int fi = 0; fi < CVB2_NF; ++fi)
+#pragma unroll
+                    for (int cq = 0; cq < NQ; ++cq)
+                        acc[u][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[fi][cq], bv[fi], acc[u][cq], 0, 0, 0);
+            }
+        }
+        if (cc.i == nch - 1) {
+            // macro-unit complete: lane holds out[channel 4 cq + r of group 4 gq + gl][column j] in acc[u][cq][r]
+            float* gout = (cc.side ? a.gRg : a.gLg) + ((size_t)cc.b * Cg * H + cc.h) * W + tile0 + j;
+            const bool okc = tile0 + j < W;
+#pragma unroll
+            for (int u = 0; u < QPW; ++u) {
+                const int gq = wave + u * NCW;
+                if (gq < GQ) {
+#pragma unroll
+                    for (int cq = 0; cq < NQ; ++cq) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = (4 * gq + gl) * CPG + 4 * cq + r;
+                            if (okc) gout[(size_t)c * HW] = acc[u][cq][r] * inv;
+                        }
+                        acc[u][cq] = cvb_zero4();
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (cc.i == nch - 1 && next_refills(cc)) __syncthreads();   // loader waves refill the ring for the next image row / side
+        cvb_advance(a, cc);
+    }
+}
+
+template <int CPG, int NCW, int QPW>
+int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
+    auto kern = cost_volume_bwd_mfma_kernel<CPG, NCW, QPW>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int grid = 256;
+    if (const char* e = getenv("STX_CVB_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force short / long runs
+    if (grid > a.macros) grid = a.macros;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + CVB2_NLW) * 64), lds, st, a);
+    return stx_check_launch("cost_volume_bwd(mfma)");
+}
+
+}  // namespace
+
+// Returns -1 when the configuration is not served by this kernel (caller falls back to cost_volume.hip).
+int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc, float* gLg, float* gRg,
+                    float* gLc, float* gRc, int B, int H, int W, int D, int mask_left, void* stream) {
+    const int off = getenv("STX_CVB_OLD") ? 1 : 0;          // (read per call: tests switch generations)
+    if (off || !G) return -1;
+    const int cpg = Cg / G;
+    if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || (G & 3) || (Cc & 3) || G > 40) return -1;
+    const int CT = G + 2 * Cc, Q = CT / 4;
+    if (Q > 16) return -1;                                 // loader lane = (column, one of 16 float4 of the voxel)
+    const int nch = stx_cdiv(D, CVB2_DC);
+    if (CVB2_DC * nch + CVB2_T - 1 > CVB2_RING - 1) return -1;   // feature window D' + 15 must leave one ring column free
+    CvbArgs a;
+    a.gv = gvol; a.Lg = Lg; a.Rg = Rg; a.gLg = gLg; a.gRg = gRg; a.gLc = gLc; a.gRc = gRc;
+    a.B = B; a.H = H; a.W = W; a.D = D; a.G = G; a.Cc = Cc; a.mask_left = mask_left;
+    a.nt = stx_cdiv(W, CVB2_T); a.nch = nch;
+    const long long macros = 2ll * B * H * a.nt;
+    if (macros >= (1ll << 30) || (long long)B * Cg * H * W >= (1ll << 31)) return -1;
+    a.macros = (int)macros;
+    a.S = G;
+    int pad = (4 - 17 * G) % 32;                           // (pitch + S) mod 32 == 4, pitch = 16 S + pad
+    if (pad < 0) pad += 32;
+    a.PD = CVB2_T * G + pad;
+    a.FS = Cg + 4;
+    const size_t lds = ((size_t)2 * (CVB2_DC * a.PD + G) + (size_t)CVB2_RING * a.FS) * 4;
+    if (lds > 160 * 1024) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int GQ = G / 4;
+    if (getenv("STX_CVB_TRACE"))
+        fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu\n", cpg, G, Cc, D, nch,
+                a.macros, lds);
+#define CVB_CASE(CPG_)                                                           \
+    if (cpg == CPG_) {                                                           \
+        if (GQ <= 4) return cvb_launch<CPG_, 4, 1>(a, lds, st);                  \
+        if (GQ <= 8) return cvb_launch<CPG_, 4, 2>(a, lds, st);                  \
+        return cvb_launch<CPG_, 4, 3>(a, lds, st);                               \
+    }
+    CVB_CASE(4) CVB_CASE(8) CVB_CASE(12) CVB_CASE(16)
+#undef CVB_CASE
+    return -1;
+}

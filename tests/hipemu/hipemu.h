@@ -196,6 +196,20 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     return c;
 }
 
+// 16 blocks of D(4x4) += A(4x1) * B(1x4): lane = 4 * block + (row of A | column of B), D[i][j] in register i of lane
+// 4 * block + j.
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    using namespace hipemu;
+    State& s = S();
+    unsigned w = wave_(), l = lane_();
+    s.slot[w][l][0] = a;
+    wave_sync_();
+    const unsigned blk = l >> 2;
+    for (int i = 0; i < 4; ++i) c[i] = fmaf(s.slot[w][4 * blk + i][0], b, c[i]);
+    wave_sync_();
+    return c;
+}
+
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -68,8 +68,28 @@ def test_cost_volume_fwd_launch_variants(be, variant, monkeypatch):
         _close(ncdhw(vol), ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "first_generation"])
+def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
+    """Backward launch variants (environment switches read per call).  Small test volumes otherwise give the matrix-core
+    kernel one macro-unit per workgroup; `one_workgroup` / `three_workgroups` force runs over many macro-units: the
+    feature ring sliding along an image row, ring refills at row and side changes, the register double buffer of the
+    volume gradient crossing macro-unit boundaries.  `first_generation` keeps the VALU kernels covered."""
+    if variant == "first_generation":
+        monkeypatch.setenv("STX_CVB_OLD", "1")
+    else:
+        monkeypatch.setenv("STX_CVB_GRID", "1" if variant == "one_workgroup" else "3")
+    for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
+        if case[2] == 0:
+            continue
+        _cv_fwd_bwd(be, case, fwd=False)
+
+
 @pytest.mark.parametrize("case", CV_CASES)
 def test_cost_volume_fwd_bwd(be, case):
+    _cv_fwd_bwd(be, case)
+
+
+def _cv_fwd_bwd(be, case, fwd=True):
     B, Cg, G, Cc, H, W, D, ml = case
     torch.manual_seed(1)
     Lg = torch.randn(B, Cg, H, W) if G else None
@@ -85,9 +105,10 @@ def test_cost_volume_fwd_bwd(be, case):
         parts.append(O.build_concat_volume(leaves[2], leaves[3], D, mask_left=bool(ml)))
     ref = torch.cat(parts, 1)
     dLg, dRg, dLc, dRc = (be.dev(t) for t in (Lg, Rg, Lc, Rc))
-    vol = be.empty(B, D, H, W, CT)
-    be.call("stx_cost_volume_fwd", ptr(dLg), ptr(dRg), Cg, G, ptr(dLc), ptr(dRc), Cc, None, ptr(vol), B, H, W, D, ml)
-    _close(ncdhw(vol), ref.detach(), rtol=1e-6, atol=1e-6)
+    if fwd:
+        vol = be.empty(B, D, H, W, CT)
+        be.call("stx_cost_volume_fwd", ptr(dLg), ptr(dRg), Cg, G, ptr(dLc), ptr(dRc), Cc, None, ptr(vol), B, H, W, D, ml)
+        _close(ncdhw(vol), ref.detach(), rtol=1e-6, atol=1e-6)
 
     gv = torch.randn(B, D, H, W, CT)
     ref.backward(ncdhw(gv))

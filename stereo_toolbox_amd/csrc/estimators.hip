@@ -8,7 +8,7 @@
 // at 576x960, D=192); here one thread owns one pixel (lanes run along W, so every access of a wave is a contiguous
 // row segment).  The walks over a pixel's D probabilities are data dependent (arg-max, then outwards to the edges of
 // the mode, then over the support) and touch every entry 3-10 times, so a wave first copies its 64 columns into LDS
-// ([d][lane]: a lane only ever reads its own column -- no barrier, no bank conflict) with 32 loads in flight per lane,
+// ([d][lane]: a lane only ever reads its own column -- no barrier, no bank conflict) with 64 loads in flight per lane,
 // and walks them there: HBM sees the volume exactly once.  Roofline: HBM, algorithmic bytes = the volume once.
 // Columns longer than ES_LDS_MAX_D entries (160 KiB / 256 B) are walked in place instead (the round-1 path).
 //
@@ -24,7 +24,7 @@ namespace {
 constexpr int ES_THREADS = 256;
 constexpr int ES_WAVE = 64;            // LDS-staged kernels: one wave per workgroup, D * 256 B of LDS
 constexpr int ES_LDS_MAX_D = 600;      // 150 KiB
-constexpr int ES_STAGE = 32;           // loads in flight per lane while staging
+constexpr int ES_STAGE = 64;           // loads in flight per lane while staging (3 waves per CU: 48 KiB in flight)
 
 // copy column `p` (stride HW) into the lane's LDS column (stride ES_WAVE)
 __device__ __forceinline__ void es_stage_column(const float* __restrict__ p, size_t HW, int D, float* col) {

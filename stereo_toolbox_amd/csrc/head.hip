@@ -200,6 +200,34 @@ __global__ __launch_bounds__(HD_THREADS) void softargmax_kernel(const float* __r
     out[(size_t)b * HW + i] = a;
 }
 
+// Same, four pixels per lane (HW % 4 == 0) and eight disparity planes in flight: 128 bytes of loads per lane instead of
+// one dword per trip of a dependent fma chain (the scalar kernel reaches 0.31 of the HBM roofline at 576x960, D = 192).  The per-pixel fma order is unchanged.
+constexpr int HD_SA_UNROLL = 8;
+__global__ __launch_bounds__(HD_THREADS) void softargmax4_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                  int D, int HW) {
+    const int i = (blockIdx.x * HD_THREADS + threadIdx.x) * 4, b = blockIdx.y;
+    if (i >= HW) return;
+    const float* p = x + (size_t)b * D * HW + i;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int d = 0;
+    for (; d + HD_SA_UNROLL <= D; d += HD_SA_UNROLL) {
+        float4 v[HD_SA_UNROLL];
+#pragma unroll
+        for (int k = 0; k < HD_SA_UNROLL; ++k) v[k] = stx_ld4(p + (size_t)(d + k) * HW);
+#pragma unroll
+        for (int k = 0; k < HD_SA_UNROLL; ++k) {
+            const float f = (float)(d + k);
+            a.x = fmaf(f, v[k].x, a.x); a.y = fmaf(f, v[k].y, a.y); a.z = fmaf(f, v[k].z, a.z); a.w = fmaf(f, v[k].w, a.w);
+        }
+    }
+    for (; d < D; ++d) {
+        const float4 v = stx_ld4(p + (size_t)d * HW);
+        const float f = (float)d;
+        a.x = fmaf(f, v.x, a.x); a.y = fmaf(f, v.y, a.y); a.z = fmaf(f, v.z, a.z); a.w = fmaf(f, v.w, a.w);
+    }
+    stx_st4(out + (size_t)b * HW + i, a);
+}
+
 __global__ __launch_bounds__(HD_THREADS) void argmax_kernel(const float* __restrict__ x, long long* __restrict__ out,
                                                              int D, int HW) {
     const int i = blockIdx.x * HD_THREADS + threadIdx.x, b = blockIdx.y;
@@ -299,8 +327,12 @@ extern "C" int stx_head_bwd2(const float* gout, const float* cost, const float* 
 extern "C" int stx_softargmax_fwd(const float* x, float* out, int B, int D, int HW, void* stream) {
     stx_begin();
     STX_REQUIRE(x && out && B > 0 && D > 0 && HW > 0, "softargmax_fwd: bad shape");
-    hipLaunchKernelGGL(softargmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0,
-                       (hipStream_t)stream, x, out, D, HW);
+    if (HW % 4 == 0 && ((size_t)x & 15) == 0 && ((size_t)out & 15) == 0)
+        hipLaunchKernelGGL(softargmax4_kernel, dim3(stx_cdiv(HW / 4, HD_THREADS), B), dim3(HD_THREADS), 0,
+                           (hipStream_t)stream, x, out, D, HW);
+    else
+        hipLaunchKernelGGL(softargmax_kernel, dim3(stx_cdiv(HW, HD_THREADS), B), dim3(HD_THREADS), 0,
+                           (hipStream_t)stream, x, out, D, HW);
     return stx_check_launch("softargmax_fwd");
 }
 

@@ -68,7 +68,8 @@ def test_cost_volume_fwd_launch_variants(be, variant, monkeypatch):
         _close(ncdhw(vol), ref, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "first_generation"])
+@pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "two_chunks_in_flight", "three_chunks_in_flight",
+                                     "first_generation"])
 def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
     """Backward launch variants (environment switches read per call).  Small test volumes otherwise give the matrix-core
     kernel one macro-unit per workgroup; `one_workgroup` / `three_workgroups` force runs over many macro-units: the
@@ -76,6 +77,9 @@ def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
     volume gradient crossing macro-unit boundaries.  `first_generation` keeps the VALU kernels covered."""
     if variant == "first_generation":
         monkeypatch.setenv("STX_CVB_OLD", "1")
+    elif variant.endswith("in_flight"):      # register sets of the loader waves (default 4 for the 40-group volumes)
+        monkeypatch.setenv("STX_CVB_NSET", "2" if variant.startswith("two") else "3")
+        monkeypatch.setenv("STX_CVB_GRID", "2")
     else:
         monkeypatch.setenv("STX_CVB_GRID", "1" if variant == "one_workgroup" else "3")
     for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
@@ -189,6 +193,11 @@ def test_estimators(be):
     torch.manual_seed(4)
     x = torch.softmax(torch.randn(2, 16, 6, 10) * 3, 1)
     flat = torch.full((2, 16, 6, 10), 1.0 / 16)
+    # (HW % 4 == 0: four pixels per lane, eight planes per trip; D = 21 leaves a tail; HW = 35 takes the scalar kernel)
+    for t in (torch.softmax(torch.randn(1, 21, 4, 7) * 3, 1), torch.softmax(torch.randn(1, 21, 5, 7) * 3, 1)):
+        o = be.empty(*t.shape[:1], *t.shape[2:])
+        be.call("stx_softargmax_fwd", ptr(be.dev(t)), ptr(o), 1, 21, t.shape[2] * t.shape[3])
+        _close(o, O.disparity_regression(t, 21), rtol=1e-6, atol=1e-6)
     for t in (x, flat):
         d = be.dev(t)
         o = be.empty(2, 6, 10)
@@ -280,6 +289,7 @@ CONV_CASES = [
     (1, 40, 32, 2, 2, 20, 3, 1),     # ACVNet dres1_att_ (Cin=40 -> 8-channel K chunks)
     (1, 32, 1, 2, 4, 35, 3, 1),      # classifier tail Conv3d(32->1)
     (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
+    (1, 64, 64, 3, 5, 37, 3, 1),     # hourglass conv2 (STX_MARCH_6464=1: 2 x 2 channel slices on the march kernel)
     (1, 64, 128, 4, 4, 24, 3, 2),
     (2, 32, 64, 7, 6, 40, 3, 1),     # march kernel, 2 column blocks (NT=2), ragged H/W, several D segments
     (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 5 16-wide tiles (8 x 16 columns)

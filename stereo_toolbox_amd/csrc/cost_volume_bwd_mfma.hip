@@ -36,8 +36,16 @@
 //     row segments of the NCHW gradients.
 //   One barrier per chunk; LEFT macro-units walk d downwards and RIGHT ones upwards so that the ring slots the next tile
 //   overwrites are dead by the time of the last chunk.
-// Macro-units are dealt in equal contiguous runs to gridDim.x workgroups; consecutive runs (the two sides of an image
-// row) sit on the same XCD, so HBM still sees the volume once.
+// Schedules.  RUN schedule (general): macro-units are dealt in equal contiguous runs to gridDim.x workgroups; the ring
+// slides along the row, but the two sides of a row touch the same part of the volume many microseconds apart: L2 (4 MB
+// per XCD) has lost it by then and the volume crosses the fabric twice (PMC: FETCH 1.03 GB, 0.30 ms whatever the prefetch
+// depth).  TEAM schedule (chosen when 16 < 2 x tiles per row <= 32 and 40 < D' <= 48, i.e. the 576x960 benchmark shape):
+// the 32 workgroups of an XCD form a team that owns an image row at a time, member = (tile, side); every member walks
+// d upwards, so at any moment the whole team reads the same 8 disparity planes of the row (~0.5 MB) -- whoever comes
+// first pays the miss, the others hit L2 and catch up.  A member keeps its tile while the rows change, so its feature
+// ring cannot slide; the 16-column batches of a macro-unit's window are fetched progressively instead (the first two
+// during the last chunks of the previous macro-unit: with 6 chunks those slots are dead by then), 4 x more feature
+// traffic, all of it L2 hits within the team.
 //
 // Roofline: HBM; algorithmic bytes = volume once + features once + feature gradients once.
 #include "cost_volume.h"
@@ -61,6 +69,7 @@ struct CvbArgs {
     int B, H, W, D, G, Cc, mask_left;
     int nt, nch, macros;           // tiles per row, chunks per macro-unit, B * H * 2 * nt
     int S, PD, FS;                 // image voxel stride, d-row pitch, ring column stride (dwords)
+    int team, nteams;              // row-team schedule (see the kernel) and the number of teams (= XCDs)
 };
 
 struct CvbCursor {                 // a chunk of the workgroup's run: macro-unit m (decoded) and step i of its d walk
@@ -85,15 +94,19 @@ __device__ __forceinline__ void cvb_advance(const CvbArgs& a, CvbCursor& c) {   
     if (++c.i == a.nch) {
         c.i = 0;
         ++c.m;
-        if (++c.t == a.nt) {
+        if (a.team) {                                  // same tile and side of the team's next image row
+            c.h += a.nteams;
+            while (c.h >= a.H) { c.h -= a.H; ++c.b; }
+        } else if (++c.t == a.nt) {
             c.t = 0;
             if ((c.side ^= 1) == 0 && ++c.h == a.H) { c.h = 0; ++c.b; }
         }
     }
 }
-// first disparity of the chunk: LEFT walks d downwards, RIGHT upwards
+// first disparity of the chunk.  Run schedule: LEFT walks d downwards, RIGHT upwards (ring reuse along the row); team
+// schedule: both upwards (the two sides and all tiles of a row read the same 8 disparity planes at the same time)
 __device__ __forceinline__ int cvb_d0(const CvbArgs& a, const CvbCursor& c) {
-    return CVB2_DC * (c.side ? c.i : a.nch - 1 - c.i);
+    return CVB2_DC * ((c.side || a.team) ? c.i : a.nch - 1 - c.i);
 }
 
 __device__ __forceinline__ f32x4 cvb_zero4() {
@@ -121,16 +134,30 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     const size_t dstride = (size_t)HW * CT;
 
     const long long wg = cvb_xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * wg / gridDim.x));
-    const int m1 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * (wg + 1) / gridDim.x));
-    if (m0 >= m1) return;
-    const int N = (m1 - m0) * nch;                                 // chunks of this run
+    int m0, m1;
     CvbCursor cc;                                                  // the chunk the compute waves work on
-    cvb_decode(a, m0, cc);
+    if (a.team) {
+        // logical workgroups 32 x .. 32 x + 31 share XCD x (gridDim.x == 256): team x, member = (tile, side), rows x, x + 8, ..
+        const int team = (int)(wg >> 5), member = (int)(wg & 31), rows = a.B * H;
+        if (member >= 2 * a.nt || team >= rows) return;
+        m0 = 0;
+        m1 = __builtin_amdgcn_readfirstlane((rows - team + a.nteams - 1) / a.nteams);
+        cc.m = 0; cc.t = member >> 1; cc.side = member & 1;
+        cc.h = team % H; cc.b = team / H;
+    } else {
+        m0 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * wg / gridDim.x));
+        m1 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * (wg + 1) / gridDim.x));
+        if (m0 >= m1) return;
+        cvb_decode(a, m0, cc);
+    }
     cc.i = 0;
-    // the next macro-unit continues the image row of `c` (ring slides by 16 columns) / starts a new row or side (refill)
-    auto next_slides = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 < a.nt; };
-    auto next_refills = [&](const CvbCursor& c) { return c.m + 1 < m1 && c.t + 1 == a.nt; };
+    const int N = (m1 - m0) * nch;                                 // chunks of this run
+    // run schedule: the next macro-unit continues the image row of `c` (ring slides by 16 columns) / starts a new row or
+    // side (refill)
+    auto next_slides = [&](const CvbCursor& c) { return !a.team && c.m + 1 < m1 && c.t + 1 < a.nt; };
+    auto next_refills = [&](const CvbCursor& c) { return !a.team && c.m + 1 < m1 && c.t + 1 == a.nt; };
+    // team schedule: first column of 16-column batch j of the window of macro-unit c (j = 0: the tile's own columns)
+    auto batch0 = [&](const CvbCursor& c, int jb) { return c.t * CVB2_T + (c.side ? 16 * jb : -16 * jb); };
 
     // ---- feature ring helpers (both roles: a refill is shared): lane = (column lt & 15, channel (lt >> 4) + 16 i), 16
     // columns per batch; ring layout [slot][channel quad][group][4]
@@ -253,15 +280,31 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
             // committed before anything new is issued; chunk ci + 1 is committed with the loads of chunks ci + 2 .. ci + NS
             // (8 each, on every path) behind it; the next ring columns are requested last.
             if (cc.i == nch - 1 && next_slides(cc)) feat_commit(fr, incoming0(cc));
+            CvbCursor nx = cc;                                       // team schedule: my next macro-unit
+            const bool more = a.team && cc.m + 1 < m1;
+            if (a.team) {
+                nx.i = nch - 1;
+                cvb_advance(a, nx);
+                if (cc.i == 1) feat_commit(fr, batch0(cc, 2));
+                if (cc.i == 3) feat_commit(fr, batch0(cc, 3));
+                if (cc.i == nch - 2 && more) feat_commit(fr, batch0(nx, 0));
+                if (cc.i == nch - 1 && more) feat_commit(fr, batch0(nx, 1));
+            }
             if (ci + NS < N) cvb_advance(a, pc);
             issue(gvr[P], gvok[P], pc, ci + NS < N);
             if (ci + 1 < N) commit(gvr[(P + 1) % NS], gvok[(P + 1) % NS], wc, lds + ((ci + 1) & 1) * IMGZ);
             if (cc.i == 0 && next_slides(cc)) feat_issue(fr, cc, incoming0(cc));
+            if (a.team) {                                            // (each request follows the commit of the previous one)
+                if (cc.i == 0) feat_issue(fr, cc, batch0(cc, 2));
+                if (cc.i == 2) feat_issue(fr, cc, batch0(cc, 3));
+                if (cc.i == nch - 3 && more) feat_issue(fr, nx, batch0(nx, 0));
+                if (cc.i == nch - 2 && more) feat_issue(fr, nx, batch0(nx, 1));
+            }
             __syncthreads();
             if (cc.i == nch - 1 && next_refills(cc)) {
-                CvbCursor nx = cc;
-                cvb_advance(a, nx);
-                ring_refill_loader(nx);
+                CvbCursor rf = cc;
+                cvb_advance(a, rf);
+                ring_refill_loader(rf);
                 __syncthreads();
             }
             if (ci + 1 < N) cvb_advance(a, wc);
@@ -369,6 +412,7 @@ int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
     int grid = 256;
     if (const char* e = getenv("STX_CVB_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force short / long runs
     if (grid > a.macros) grid = a.macros;
+    if (a.team) grid = 256;                                 // 8 XCDs x 32 members
     hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + CVB2_NLW) * 64), lds, st, a);
     return stx_check_launch("cost_volume_bwd(mfma)");
 }
@@ -394,6 +438,10 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     if (macros >= (1ll << 30) || (long long)B * Cg * H * W >= (1ll << 31)) return -1;
     if ((long long)(CVB2_DC + 1) * H * W * CT >= (1ll << 31) || (long long)Cg * H * W >= (1ll << 31)) return -1;   // 32-bit lane offsets
     a.macros = (int)macros;
+    // team schedule (see the kernel): one row team per XCD
+    const int team_env = getenv("STX_CVB_TEAM") ? atoi(getenv("STX_CVB_TEAM")) : 1;
+    a.nteams = 8;
+    a.team = (team_env && 2 * a.nt > 16 && 2 * a.nt <= 32 && nch == 6 && B * H >= a.nteams && !getenv("STX_CVB_GRID")) ? 1 : 0;
     a.S = G;
     int pad = (4 - 17 * G) % 32;                           // (pitch + S) mod 32 == 4, pitch = 16 S + pad
     if (pad < 0) pad += 32;
@@ -404,8 +452,8 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     hipStream_t st = (hipStream_t)stream;
     const int GQ = G / 4;
     if (getenv("STX_CVB_TRACE"))
-        fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu\n", cpg, G, Cc, D, nch,
-                a.macros, lds);
+        fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu team %d\n", cpg, G, Cc,
+                D, nch, a.macros, lds, a.team);
     // chunks in flight per loader lane: 4 (64 x 16 B per lane, ~100 KB per CU) where the registers allow; STX_CVB_NSET=2 for A/B
     const int nset = getenv("STX_CVB_NSET") ? atoi(getenv("STX_CVB_NSET")) : 4;
 #define CVB_CASE(CPG_)                                                           \

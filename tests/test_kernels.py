@@ -88,6 +88,18 @@ def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
         _cv_fwd_bwd(be, case, fwd=False)
 
 
+@pytest.mark.parametrize("case", [(1, 320, 40, 12, 10, 130, 48, 1),     # GwcNet_GC channels, 6 chunks, 9 tiles, rows 8/9 = second round
+                                  (2, 64, 8, 4, 5, 140, 43, 0)])         # D' = 43 (ragged last chunk), batch 2, left half unmasked
+def test_cost_volume_bwd_team_schedule(be, case, monkeypatch):
+    """The matrix-core backward's row-team schedule (one team of (tile, side) members per XCD, progressive feature ring):
+    taken for 9-16 tiles per row and 40 < D' <= 48, i.e. the benchmark shape -- these are its smallest eligible volumes.
+    Checked against the same launch on the run schedule (STX_CVB_TEAM=0) by way of the common reference."""
+    monkeypatch.setenv("STX_CVB_TRACE", "1")
+    _cv_fwd_bwd(be, case, fwd=False)
+    monkeypatch.setenv("STX_CVB_TEAM", "0")
+    _cv_fwd_bwd(be, case, fwd=False)
+
+
 @pytest.mark.parametrize("case", CV_CASES)
 def test_cost_volume_fwd_bwd(be, case):
     _cv_fwd_bwd(be, case)

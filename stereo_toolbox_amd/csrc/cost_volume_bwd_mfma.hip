@@ -167,15 +167,17 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
         const int g = c / CPG, ci = c - g * CPG;
         return (col & (CVB2_RING - 1)) * FS + (ci >> 2) * 4 * G + g * 4 + (ci & 3);
     };
-    auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0) {   // columns col0 .. col0 + 15 of the row of c
-        const float* F = (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W;   // wave-uniform base + 32-bit lane offsets
+    // columns col0 .. col0 + 15 of the row of c.  Always executes its NFR loads (`live` = false: of one dummy address), so
+    // that the number of loads in flight is the same on every path and the waits stay counted (see the loader's step).
+    auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0, bool live = true) {
+        const float* F = live ? (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W : a.Lg;   // wave-uniform base
         const int col = col0 + fcol;
-        const bool okc = col >= 0 && col < W;
-        const unsigned off0 = (unsigned)fc0 * (unsigned)HW + (unsigned)(okc ? col : 0);
+        const bool okc = live && col >= 0 && col < W;
+        const unsigned off0 = okc ? (unsigned)fc0 * (unsigned)HW + (unsigned)col : 0u;   // + 32-bit lane offsets
 #pragma unroll
         for (int i = 0; i < NFR; ++i) {
             const int ch = fc0 + 16 * i;
-            dst[i] = F[ch < Cg ? off0 + (unsigned)(16 * i) * (unsigned)HW : 0u];
+            dst[i] = F[(okc && ch < Cg) ? off0 + (unsigned)(16 * i) * (unsigned)HW : 0u];
         }
     };
     auto feat_commit = [&](const float (&src)[NFR], int col0) {
@@ -276,30 +278,36 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
         __syncthreads();
         auto step = [&](auto par, int ci) {
             constexpr int P = decltype(par)::value;                  // ci % NS: set P holds chunk ci (already in the image)
-            // order matters for the memory counter (loads retire in order): the ring columns fetched nch - 1 steps ago are
-            // committed before anything new is issued; chunk ci + 1 is committed with the loads of chunks ci + 2 .. ci + NS
-            // (8 each, on every path) behind it; the next ring columns are requested last.
-            if (cc.i == nch - 1 && next_slides(cc)) feat_commit(fr, incoming0(cc));
-            CvbCursor nx = cc;                                       // team schedule: my next macro-unit
-            const bool more = a.team && cc.m + 1 < m1;
+            // Loads retire in order and hipcc counts them only along straight-line code, so every step executes the same
+            // loads in the same order: [NFR feature loads][8 loads of chunk ci + NS].  What differs is only their addresses
+            // (a batch of ring columns is needed in some steps: the others read a dummy word) and which results are
+            // committed: the ring batch requested in the previous step first (8 younger loads behind it), then chunk ci + 1
+            // (the loads of chunks ci + 2 .. ci + NS and of the feature batches between them behind it).
+            CvbCursor nx = cc;                                       // my next macro-unit
+            nx.i = nch - 1;
+            cvb_advance(a, nx);
+            const bool more = cc.m + 1 < m1;
+            // ring batch to commit now / to request now: {cursor of its row, first column}; -1 = none
+            int ccol = 0, icol = 0;
+            bool cdo = false, ido = false, inext = false;
             if (a.team) {
-                nx.i = nch - 1;
-                cvb_advance(a, nx);
-                if (cc.i == 1) feat_commit(fr, batch0(cc, 2));
-                if (cc.i == 3) feat_commit(fr, batch0(cc, 3));
-                if (cc.i == nch - 2 && more) feat_commit(fr, batch0(nx, 0));
-                if (cc.i == nch - 1 && more) feat_commit(fr, batch0(nx, 1));
+                if (cc.i == 1) { cdo = true; ccol = batch0(cc, 2); }
+                else if (cc.i == 3) { cdo = true; ccol = batch0(cc, 3); }
+                else if (cc.i == nch - 2 && more) { cdo = true; ccol = batch0(nx, 0); }
+                else if (cc.i == nch - 1 && more) { cdo = true; ccol = batch0(nx, 1); }
+                if (cc.i == 0) { ido = true; icol = batch0(cc, 2); }
+                else if (cc.i == 2) { ido = true; icol = batch0(cc, 3); }
+                else if (cc.i == nch - 3 && more) { ido = inext = true; icol = batch0(nx, 0); }
+                else if (cc.i == nch - 2 && more) { ido = inext = true; icol = batch0(nx, 1); }
+            } else {
+                if (cc.i == nch - 1 && next_slides(cc)) { cdo = true; ccol = incoming0(cc); }
+                if (cc.i == nch - 2 && next_slides(cc)) { ido = true; icol = incoming0(cc); }
             }
+            if (cdo) feat_commit(fr, ccol);
+            feat_issue(fr, inext ? nx : cc, icol, ido);
             if (ci + NS < N) cvb_advance(a, pc);
             issue(gvr[P], gvok[P], pc, ci + NS < N);
             if (ci + 1 < N) commit(gvr[(P + 1) % NS], gvok[(P + 1) % NS], wc, lds + ((ci + 1) & 1) * IMGZ);
-            if (cc.i == 0 && next_slides(cc)) feat_issue(fr, cc, incoming0(cc));
-            if (a.team) {                                            // (each request follows the commit of the previous one)
-                if (cc.i == 0) feat_issue(fr, cc, batch0(cc, 2));
-                if (cc.i == 2) feat_issue(fr, cc, batch0(cc, 3));
-                if (cc.i == nch - 3 && more) feat_issue(fr, nx, batch0(nx, 0));
-                if (cc.i == nch - 2 && more) feat_issue(fr, nx, batch0(nx, 1));
-            }
             __syncthreads();
             if (cc.i == nch - 1 && next_refills(cc)) {
                 CvbCursor rf = cc;
@@ -430,6 +438,7 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     if (Q > 16) return -1;                                 // loader lane = (column, one of 16 float4 of the voxel)
     const int nch = stx_cdiv(D, CVB2_DC);
     if (CVB2_DC * nch + CVB2_T - 1 > CVB2_RING - 1) return -1;   // feature window D' + 15 must leave one ring column free
+    if (nch < 2) return -1;                                // the ring batch of the next tile is requested one step before it is committed
     CvbArgs a;
     a.gv = gvol; a.Lg = Lg; a.Rg = Rg; a.gLg = gLg; a.gRg = gRg; a.gLc = gLc; a.gRc = gRc;
     a.B = B; a.H = H; a.W = W; a.D = D; a.G = G; a.Cc = Cc; a.mask_left = mask_left;

@@ -26,10 +26,13 @@
 // block row fill the gaps); feature ring [64 columns][channel quad][G][4].
 //
 // Roles inside a workgroup (one per CU):
-//   * LOADER waves: lane = (column j, float4 q of the voxel), one disparity row per load, two chunks in flight in registers
-//     (16 x 16 B per lane); gwc quads -> ds_write_b128 into the image (double buffered), concat quads are summed in the
+//   * LOADER waves: lane = (column j, float4 q of the voxel), one disparity row per load, NS chunks in flight in registers
+//     (8 x 16 B per lane each); gwc quads -> ds_write_b128 into the image (double buffered), concat quads are summed in the
 //     loader's registers (a lane keeps its (j, q) for the whole macro-unit: the RIGHT side's shear makes x = x0 + j constant
-//     as well) and written at the end of the macro-unit.  The feature ring slides with the tiles of an image row: 16 new
+//     as well) and written at the end of the macro-unit.  All loads are buffer loads: rows past D', columns past W, the
+//     masked part of the left concat half and the quads a side does not need get an out-of-range offset and read zeros
+//     (no clamps, no selects, no divergent code: the first version of this loader spent 1 300 instructions per chunk,
+//     mostly exec-mask and spill traffic, and that -- not memory -- set the kernel's time).  The feature ring slides with the tiles of an image row: 16 new
 //     columns per macro-unit (every feature element is read once per row and side), a full refill at row starts.
 //   * COMPUTE waves (4, i.e. 8 waves = 2 per SIMD with the loaders: 256 VGPRs each): up to three group quads each; per chunk 23 x (1 + cpg/4) LDS reads and 23 x cpg/4 MFMAs per group quad;
 //     accumulators (4 VGPRs per group quad and channel quad) live for the whole macro-unit and are written as 64-byte
@@ -60,6 +63,7 @@ constexpr int CVB2_T = 16;        // columns per macro-unit
 constexpr int CVB2_DC = 8;        // disparities per chunk
 constexpr int CVB2_NF = CVB2_T + CVB2_DC - 1;   // feature columns per chunk (23)
 constexpr int CVB2_RING = 64;     // feature ring columns (window D' + 15 <= 63, + slack for the 16 incoming ones)
+constexpr int CVB2_NCW = 4;       // compute waves
 constexpr int CVB2_NLW = 4;       // loader waves
 constexpr int CVB2_NLTHR = CVB2_NLW * 64;
 
@@ -68,13 +72,15 @@ struct CvbArgs {
     float *gLg, *gRg, *gLc, *gRc;
     int B, H, W, D, G, Cc, mask_left;
     int nt, nch, macros;           // tiles per row, chunks per macro-unit, B * H * 2 * nt
-    int S, PD, FS;                 // image voxel stride, d-row pitch, ring column stride (dwords)
-    int team, nteams;              // row-team schedule (see the kernel) and the number of teams (= XCDs)
+    int team, nteams;              // row-team schedule (see above) and the number of teams (= XCDs)
 };
 
 struct CvbCursor {                 // a chunk of the workgroup's run: macro-unit m (decoded) and step i of its d walk
     int m, i, b, h, t, side;
 };
+
+// image geometry for G groups: voxel stride G, d-row pitch 16 G + pad with (pitch + G) mod 32 == 4; ring column stride
+__host__ __device__ constexpr int cvb_pitch(int G) { return CVB2_T * G + (((4 - 17 * G) % 32) + 32) % 32; }
 
 __device__ __forceinline__ int cvb_xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
@@ -115,23 +121,25 @@ __device__ __forceinline__ f32x4 cvb_zero4() {
     return z;
 }
 
-// CPG channels per group; NCW compute waves with QPW group quads each (NCW * QPW >= G / 4); NS chunks of the volume
-// gradient in flight in the loader waves' registers
-template <int CPG, int NCW, int QPW, int NS>
-__global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_kernel(CvbArgs a) {
+// CPG channels per group; QPW group quads per compute wave (4 QPW >= G / 4); NS chunks of the volume gradient in flight in
+// the loader waves' registers; GT / CCT: G and Cc as compile-time constants (0 / -1: taken from the arguments) -- with them
+// every LDS offset of the inner loops is an instruction immediate.
+template <int CPG, int QPW, int NS, int GT, int CCT>
+__global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_kernel(CvbArgs a) {
+    constexpr int NCW = CVB2_NCW;
     constexpr int NQ = CPG / 4;                                    // channel quads per group
-    constexpr int NFR = 5 * CPG / 2;                               // new-column feature loads per loader lane: Cg <= 40 * CPG
+    constexpr int NFR = 5 * CPG / 2;                               // feature loads per loader lane and 16-column batch: Cg <= 40 CPG
     STX_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = a.H, W = a.W, D = a.D, G = a.G, Cc = a.Cc, nch = a.nch;
+    const int H = a.H, W = a.W, D = a.D, nch = a.nch;
+    const int G = GT ? GT : a.G, Cc = CCT >= 0 ? CCT : a.Cc;
     const int HW = H * W, Cg = G * CPG, CT = G + 2 * Cc;
     const int GQ = G >> 2, CQ = Cc >> 2, Q = CT >> 2;
-    const int S = a.S, PD = a.PD, FS = a.FS;
+    const int S = G, PD = cvb_pitch(G), FS = Cg + 4;
     const int IMG = CVB2_DC * PD;                                  // dwords per image
     const int IMGZ = IMG + G;                                      // image + G zero words (B operand of entries outside the chunk)
     float* lds = reinterpret_cast<float*>(smem);                   // [2][IMGZ] (double buffer over chunks)
     float* ring = lds + 2 * IMGZ;                                  // [CVB2_RING][FS]
-    const size_t dstride = (size_t)HW * CT;
 
     const long long wg = cvb_xcd_remap(blockIdx.x, gridDim.x);
     int m0, m1;
@@ -159,34 +167,35 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     // team schedule: first column of 16-column batch j of the window of macro-unit c (j = 0: the tile's own columns)
     auto batch0 = [&](const CvbCursor& c, int jb) { return c.t * CVB2_T + (c.side ? 16 * jb : -16 * jb); };
 
-    // ---- feature ring helpers (both roles: a refill is shared): lane = (column lt & 15, channel (lt >> 4) + 16 i), 16
-    // columns per batch; ring layout [slot][channel quad][group][4]
-    const int ft = tid & (CVB2_NLTHR - 1);                          // (NCW == CVB2_NLW == 4: 256 lanes per role)
+    // ---- feature ring helpers (both roles: a refill is shared): lane = (column ft & 15, channel (ft >> 4) + 16 i), 16
+    // columns per batch; ring layout [slot][channel quad][group][4].  The loads always execute (`live` = false: every lane
+    // out of range), so the number of loads in flight is the same on every path and hipcc's waits stay counted.
+    const int ft = tid & (CVB2_NLTHR - 1);                          // (256 lanes per role)
     const int fcol = ft & 15, fc0 = ft >> 4;
-    auto ring_off = [&](int col, int c) {
-        const int g = c / CPG, ci = c - g * CPG;
-        return (col & (CVB2_RING - 1)) * FS + (ci >> 2) * 4 * G + g * 4 + (ci & 3);
+    auto ring_chan = [&](int ch) {                                  // offset of channel ch inside a ring column
+        const int g = ch / CPG, ci = ch - g * CPG;
+        return (ci >> 2) * 4 * G + g * 4 + (ci & 3);
     };
-    // columns col0 .. col0 + 15 of the row of c.  Always executes its NFR loads (`live` = false: of one dummy address), so
-    // that the number of loads in flight is the same on every path and the waits stay counted (see the loader's step).
-    auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0, bool live = true) {
-        const float* F = live ? (c.side ? a.Lg : a.Rg) + ((size_t)c.b * Cg * H + c.h) * W : a.Lg;   // wave-uniform base
+    const int rchan0 = ring_chan(fc0);
+    auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0, bool live) {
+        const stx_bufrsrc rs = stx_make_rsrc((c.side ? a.Lg : a.Rg) + (size_t)c.b * Cg * HW, (unsigned)Cg * (unsigned)HW * 4u);
         const int col = col0 + fcol;
-        const bool okc = live && col >= 0 && col < W;
-        const unsigned off0 = okc ? (unsigned)fc0 * (unsigned)HW + (unsigned)col : 0u;   // + 32-bit lane offsets
+        const unsigned voff = (live && col >= 0 && col < W) ? (unsigned)(fc0 * HW + col) * 4u : STX_BUF_OOB;
+        const unsigned srow = (unsigned)(c.h * W) * 4u, sstep = 16u * (unsigned)HW * 4u;
 #pragma unroll
-        for (int i = 0; i < NFR; ++i) {
-            const int ch = fc0 + 16 * i;
-            dst[i] = F[(okc && ch < Cg) ? off0 + (unsigned)(16 * i) * (unsigned)HW : 0u];
-        }
+        for (int i = 0; i < NFR; ++i) dst[i] = stx_buf_ld1(rs, voff, srow + (unsigned)i * sstep);   // channels >= Cg: out of range
     };
-    auto feat_commit = [&](const float (&src)[NFR], int col0) {
-        const int col = col0 + fcol;
-        const bool okc = col >= 0 && col < W;
+    auto feat_commit = [&](const float (&src)[NFR], int col0) {     // (columns outside the image were read as zeros)
+        float* rp = ring + ((col0 + fcol) & (CVB2_RING - 1)) * FS;
+        if constexpr (16 % CPG == 0) {                              // channel + 16 = group + 16 / CPG: constant stride
+            rp += rchan0;
 #pragma unroll
-        for (int i = 0; i < NFR; ++i) {
-            const int ch = fc0 + 16 * i;
-            if (ch < Cg) ring[ring_off(col, ch)] = okc ? src[i] : 0.f;
+            for (int i = 0; i < NFR; ++i)
+                if (fc0 + 16 * i < Cg) rp[i * (64 / CPG)] = src[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NFR; ++i)
+                if (fc0 + 16 * i < Cg) rp[ring_chan(fc0 + 16 * i)] = src[i];
         }
     };
     // first column of the window of macro-unit c: LEFT [w0 - 8 nch + 1, w0 + 15], RIGHT [x0, x0 + 8 nch + 14]
@@ -196,15 +205,15 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     // one round trip to memory instead of four.
     auto ring_refill_loader = [&](const CvbCursor& c) {
         float t0[NFR];
-        feat_issue(t0, c, window0(c) + 48);
+        feat_issue(t0, c, window0(c) + 48, true);
         feat_commit(t0, window0(c) + 48);
     };
     auto ring_refill_compute = [&](const CvbCursor& c) {
         float t0[NFR], t1[NFR], t2[NFR];
         const int f0 = window0(c);
-        feat_issue(t0, c, f0);
-        feat_issue(t1, c, f0 + 16);
-        feat_issue(t2, c, f0 + 32);
+        feat_issue(t0, c, f0, true);
+        feat_issue(t1, c, f0 + 16, true);
+        feat_issue(t2, c, f0 + 32, true);
         feat_commit(t0, f0);
         feat_commit(t1, f0 + 16);
         feat_commit(t2, f0 + 32);
@@ -215,39 +224,43 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
         const int lt = tid - NCW * 64;
         const int q = lt & 15, j = (lt >> 4) & 15;
         const bool gq_lane = q < GQ;
+        const bool lc_lane = q >= GQ && q < GQ + CQ, rc_lane = q >= GQ + CQ && q < Q;
+        const int wimg = j * S + 4 * q;                              // my voxel quad inside an image row
         for (int i = lt; i < 2 * G; i += CVB2_NLTHR) lds[(i >= G ? IMGZ + IMG - G : IMG) + i] = 0.f;
-        // ---- volume gradient: NS chunks in registers
+        // ---- volume gradient: NS chunks in registers.  Lane (j, q) reads rows d0 .. d0 + 7 of one column (LEFT) or of the
+        // sheared diagonal (RIGHT: + one voxel per row, the instruction's immediate offset when CT is a constant).
         float4 gvr[NS][CVB2_DC];
-        unsigned gvok[NS];
         float4 cacc = make_float4(0.f, 0.f, 0.f, 0.f);
-        // (always executes its 8 loads -- `live` = false reads a valid dummy address: with a fixed number of loads on every
-        //  path hipcc waits for the chunk being committed with a counted vmcnt and leaves the newer chunk in flight)
-        auto issue = [&](float4 (&dst)[CVB2_DC], unsigned& okbits, const CvbCursor& c, bool live) {
+        const unsigned gvbytes = (unsigned)D * (unsigned)HW * (unsigned)CT * 4u;     // one batch item (checked < 2 GiB)
+        const unsigned dstep = (unsigned)HW * (unsigned)CT * 4u;
+        auto issue = [&](float4 (&dst)[CVB2_DC], const CvbCursor& c, bool live) {
+            const stx_bufrsrc rs = stx_make_rsrc(a.gv + (size_t)c.b * D * HW * CT, gvbytes);
             const int d0 = cvb_d0(a, c);
             const int col0 = c.t * CVB2_T + j + (c.side ? d0 : 0);
-            const bool want = live && (gq_lane || (c.side ? (q >= GQ + CQ && q < Q) : (q >= GQ && q < GQ + CQ)));
-            const float* row = a.gv + (((size_t)c.b * D + d0) * H + c.h) * (size_t)W * CT;   // wave-uniform; 32-bit lane offsets
-            const unsigned ds32 = (unsigned)dstride;
-            unsigned ok = 0;
-#pragma unroll
-            for (int k = 0; k < CVB2_DC; ++k) {
-                const int col = c.side ? col0 + k : col0;
-                const bool v = want && d0 + k < D && col < W;
-                dst[k] = stx_ld4(row + (v ? (unsigned)k * ds32 + (unsigned)col * (unsigned)CT + 4u * (unsigned)q : 0u));
-                ok |= (v ? 1u : 0u) << k;
+            // rows this lane wants: k < klim.  LEFT: the column must exist; the left concat half stops at d = w when masked.
+            // RIGHT: row k sits at column col0 + k.
+            int klim;
+            if (c.side) {
+                klim = (D - d0 < W - col0) ? D - d0 : W - col0;
+                if (!(gq_lane || rc_lane)) klim = 0;
+            } else {
+                const int dlim = (lc_lane && a.mask_left && col0 + 1 < D) ? col0 + 1 : D;
+                klim = (col0 < W && (gq_lane || lc_lane)) ? dlim - d0 : 0;
             }
-            okbits = ok;
-        };
-        auto commit = [&](const float4 (&src)[CVB2_DC], unsigned okbits, const CvbCursor& c, float* img) {
-            const int d0 = cvb_d0(a, c);
-            const int w = c.t * CVB2_T + j;                          // LEFT: the voxel column (mask w >= d)
+            if (!live) klim = 0;
+            const unsigned voff0 = (unsigned)(col0 * CT + 4 * q) * 4u, kstep = c.side ? (unsigned)CT * 4u : 0u;
+            const unsigned srow = (unsigned)((d0 * H + c.h) * W) * (unsigned)CT * 4u;
 #pragma unroll
-            for (int k = 0; k < CVB2_DC; ++k) {
-                const bool v = (okbits >> k) & 1u;
-                float4 x = src[k];
-                if (!v) x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gq_lane) stx_st4(img + k * PD + j * S + 4 * q, x);
-                else if (c.side || !a.mask_left || w >= d0 + k) { cacc.x += x.x; cacc.y += x.y; cacc.z += x.z; cacc.w += x.w; }
+            for (int k = 0; k < CVB2_DC; ++k)
+                dst[k] = stx_buf_ld4(rs, k < klim ? voff0 + (unsigned)k * kstep : STX_BUF_OOB, srow + (unsigned)k * dstep);
+        };
+        auto commit = [&](const float4 (&src)[CVB2_DC], const CvbCursor& c, float* img) {
+            if (gq_lane) {
+#pragma unroll
+                for (int k = 0; k < CVB2_DC; ++k) stx_st4(img + k * PD + wimg, src[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < CVB2_DC; ++k) { cacc.x += src[k].x; cacc.y += src[k].y; cacc.z += src[k].z; cacc.w += src[k].w; }
             }
             if (c.i == nch - 1) {                                    // last chunk of the macro-unit: concat sums are complete
                 const int col = c.t * CVB2_T + j;
@@ -260,7 +273,7 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
             }
         };
         float fr[NFR];
-        // the 16 columns the NEXT macro-unit of the row adds to the window of c
+        // the 16 columns the NEXT macro-unit of the row adds to the window of c (run schedule)
         auto incoming0 = [&](const CvbCursor& c) {
             return c.side ? c.t * CVB2_T + CVB2_DC * nch + CVB2_T - 1 : c.t * CVB2_T + CVB2_T;
         };
@@ -270,25 +283,24 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if (k > 0 && k < N) cvb_advance(a, pc);
-            issue(gvr[k], gvok[k], pc, k < N);
+            issue(gvr[k], pc, k < N);
         }
         if (N > 1) cvb_advance(a, wc);
         ring_refill_loader(cc);
-        commit(gvr[0], gvok[0], cc, lds);
+        commit(gvr[0], cc, lds);
         __syncthreads();
         auto step = [&](auto par, int ci) {
             constexpr int P = decltype(par)::value;                  // ci % NS: set P holds chunk ci (already in the image)
             // Loads retire in order and hipcc counts them only along straight-line code, so every step executes the same
-            // loads in the same order: [NFR feature loads][8 loads of chunk ci + NS].  What differs is only their addresses
-            // (a batch of ring columns is needed in some steps: the others read a dummy word) and which results are
-            // committed: the ring batch requested in the previous step first (8 younger loads behind it), then chunk ci + 1
-            // (the loads of chunks ci + 2 .. ci + NS and of the feature batches between them behind it).
+            // loads in the same order: [NFR feature loads][8 loads of chunk ci + NS].  What differs is only their offsets
+            // (a batch of ring columns is needed in some steps: in the others every lane is out of range) and which results
+            // are committed: the ring batch requested in the previous step first (8 younger loads behind it), then chunk
+            // ci + 1 (the loads of chunks ci + 2 .. ci + NS and of the feature batches between them behind it).
             CvbCursor nx = cc;                                       // my next macro-unit
             nx.i = nch - 1;
             cvb_advance(a, nx);
             const bool more = cc.m + 1 < m1;
-            // ring batch to commit now / to request now: {cursor of its row, first column}; -1 = none
-            int ccol = 0, icol = 0;
+            int ccol = 0, icol = 0;                                  // ring batch to commit now / to request now
             bool cdo = false, ido = false, inext = false;
             if (a.team) {
                 if (cc.i == 1) { cdo = true; ccol = batch0(cc, 2); }
@@ -306,8 +318,8 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
             if (cdo) feat_commit(fr, ccol);
             feat_issue(fr, inext ? nx : cc, icol, ido);
             if (ci + NS < N) cvb_advance(a, pc);
-            issue(gvr[P], gvok[P], pc, ci + NS < N);
-            if (ci + 1 < N) commit(gvr[(P + 1) % NS], gvok[(P + 1) % NS], wc, lds + ((ci + 1) & 1) * IMGZ);
+            issue(gvr[P], pc, ci + NS < N);
+            if (ci + 1 < N) commit(gvr[(P + 1) % NS], wc, lds + ((ci + 1) & 1) * IMGZ);
             __syncthreads();
             if (cc.i == nch - 1 && next_refills(cc)) {
                 CvbCursor rf = cc;
@@ -413,15 +425,15 @@ __global__ __launch_bounds__((NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_ke
     }
 }
 
-template <int CPG, int NCW, int QPW, int NS>
+template <int CPG, int QPW, int NS, int GT, int CCT>
 int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_bwd_mfma_kernel<CPG, NCW, QPW, NS>;
+    auto kern = cost_volume_bwd_mfma_kernel<CPG, QPW, NS, GT, CCT>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256;
     if (const char* e = getenv("STX_CVB_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force short / long runs
     if (grid > a.macros) grid = a.macros;
     if (a.team) grid = 256;                                 // 8 XCDs x 32 members
-    hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + CVB2_NLW) * 64), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3((CVB2_NCW + CVB2_NLW) * 64), lds, st, a);
     return stx_check_launch("cost_volume_bwd(mfma)");
 }
 
@@ -445,33 +457,37 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     a.nt = stx_cdiv(W, CVB2_T); a.nch = nch;
     const long long macros = 2ll * B * H * a.nt;
     if (macros >= (1ll << 30) || (long long)B * Cg * H * W >= (1ll << 31)) return -1;
-    if ((long long)(CVB2_DC + 1) * H * W * CT >= (1ll << 31) || (long long)Cg * H * W >= (1ll << 31)) return -1;   // 32-bit lane offsets
+    // buffer resources of one batch item: < 2 GiB each (32-bit offsets, STX_BUF_OOB beyond every valid one)
+    if ((long long)D * H * W * CT * 4 >= (1ll << 31) || (long long)Cg * H * W * 4 >= (1ll << 31)) return -1;
     a.macros = (int)macros;
-    // team schedule (see the kernel): one row team per XCD
+    // team schedule (see above): one row team per XCD
     const int team_env = getenv("STX_CVB_TEAM") ? atoi(getenv("STX_CVB_TEAM")) : 1;
     a.nteams = 8;
     a.team = (team_env && 2 * a.nt > 16 && 2 * a.nt <= 32 && nch == 6 && B * H >= a.nteams && !getenv("STX_CVB_GRID")) ? 1 : 0;
-    a.S = G;
-    int pad = (4 - 17 * G) % 32;                           // (pitch + S) mod 32 == 4, pitch = 16 S + pad
-    if (pad < 0) pad += 32;
-    a.PD = CVB2_T * G + pad;
-    a.FS = Cg + 4;
-    const size_t lds = ((size_t)2 * (CVB2_DC * a.PD + G) + (size_t)CVB2_RING * a.FS) * 4;
+    const size_t lds = ((size_t)2 * (CVB2_DC * cvb_pitch(G) + G) + (size_t)CVB2_RING * (Cg + 4)) * 4;
     if (lds > 160 * 1024) return -1;
     hipStream_t st = (hipStream_t)stream;
     const int GQ = G / 4;
     if (getenv("STX_CVB_TRACE"))
         fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu team %d\n", cpg, G, Cc,
                 D, nch, a.macros, lds, a.team);
-    // chunks in flight per loader lane: 4 (64 x 16 B per lane, ~100 KB per CU) where the registers allow; STX_CVB_NSET=2 for A/B
-    const int nset = getenv("STX_CVB_NSET") ? atoi(getenv("STX_CVB_NSET")) : 4;
+    // GwcNet / ACVNet volumes (320 channels in 40 groups, 12 or 0 concat channels): constants folded, STX_CVB_NSET chunks
+    // in flight per loader lane (A/B switch)
+    const int nset = getenv("STX_CVB_NSET") ? atoi(getenv("STX_CVB_NSET")) : 3;
+    if (cpg == 8 && G == 40 && (Cc == 12 || Cc == 0) && !getenv("STX_CVB_GENERIC_G")) {
+        if (Cc == 12) {
+            if (nset == 2) return cvb_launch<8, 3, 2, 40, 12>(a, lds, st);
+            if (nset == 4) return cvb_launch<8, 3, 4, 40, 12>(a, lds, st);
+            return cvb_launch<8, 3, 3, 40, 12>(a, lds, st);
+        }
+        if (nset == 2) return cvb_launch<8, 3, 2, 40, 0>(a, lds, st);
+        return cvb_launch<8, 3, 3, 40, 0>(a, lds, st);
+    }
 #define CVB_CASE(CPG_)                                                           \
     if (cpg == CPG_) {                                                           \
-        if (GQ <= 4) return cvb_launch<CPG_, 4, 1, 2>(a, lds, st);               \
-        if (GQ <= 8) return cvb_launch<CPG_, 4, 2, 2>(a, lds, st);               \
-        if (CPG_ == 8 && nset == 4) return cvb_launch<8, 4, 3, 4>(a, lds, st);   \
-        if (CPG_ == 8 && nset == 3) return cvb_launch<8, 4, 3, 3>(a, lds, st);   \
-        return cvb_launch<CPG_, 4, 3, 2>(a, lds, st);                            \
+        if (GQ <= 4) return cvb_launch<CPG_, 1, 2, 0, -1>(a, lds, st);           \
+        if (GQ <= 8) return cvb_launch<CPG_, 2, 2, 0, -1>(a, lds, st);           \
+        return cvb_launch<CPG_, 3, 2, 0, -1>(a, lds, st);                        \
     }
     CVB_CASE(4) CVB_CASE(8) CVB_CASE(12) CVB_CASE(16)
 #undef CVB_CASE

@@ -23,6 +23,37 @@
 // would otherwise be precomputed into dozens of live registers; guide 5.7 item 3).
 #define STX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
 #endif
+// Buffer loads through a resource descriptor (wave-uniform base + 32-bit lane offset + wave-uniform offset): lanes whose
+// offset lies outside [0, bytes) read zeros without touching memory -- the bounds check replaces address clamps and
+// selects (guide T8).  STX_BUF_OOB is the offset to pass for such lanes (bytes <= 2 GiB).
+#define STX_BUF_OOB 0x80000000u
+#ifdef STX_HIPEMU
+struct stx_bufrsrc { const char* base; unsigned bytes; };
+static inline stx_bufrsrc stx_make_rsrc(const void* p, unsigned bytes) { return stx_bufrsrc{(const char*)p, bytes}; }
+static inline float4 stx_buf_ld4(stx_bufrsrc r, unsigned voff, unsigned soff) {
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (voff >= STX_BUF_OOB || off + 16 > r.bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(r.base + off);
+}
+static inline float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsigned soff) {
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (voff >= STX_BUF_OOB || off + 4 > r.bytes) return 0.f;
+    return *reinterpret_cast<const float*>(r.base + off);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t stx_bufrsrc;
+typedef unsigned int stx_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ stx_bufrsrc stx_make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 stx_buf_ld4(stx_bufrsrc r, unsigned voff, unsigned soff) {
+    const stx_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+__device__ __forceinline__ float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+#endif
 // A pointer the program knows to be wave-uniform, forced into SGPRs (two v_readfirstlane): loads through it become
 // `global_load v, v_offset, s[base:base+1]` and it cannot be spilled to scratch as a VGPR pair.
 template <typename T>

@@ -373,26 +373,46 @@ __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mf
         const int d0 = cvb_d0(a, cc);
         const int tile0 = cc.t * CVB2_T;
         const int fbase = cc.side ? tile0 + d0 : tile0 - d0 - (CVB2_DC - 1);
+        // operand addresses of the chunk's 23 feature columns, shared by all my group quads (constant offsets between them)
+        const float *bp[CVB2_NF], *ap[CVB2_NF];
 #pragma unroll
-        for (int u = 0; u < QPW; ++u) {
-            const int gq = wave + u * NCW;
-            if (gq < GQ) {                                           // wave-uniform
-                // all operands of the chunk first (the reads of a wave do not wait on each other), then the MFMAs
-                float bv[CVB2_NF], av[CVB2_NF][NQ];
+        for (int fi = 0; fi < CVB2_NF; ++fi) {
+            bp[fi] = img + bo[fi];
+            ap[fi] = abase + ((fbase + fi) & (CVB2_RING - 1)) * FS;
+        }
+        // Software pipeline over groups of 6 feature columns (12 LDS reads: the LDS counter tracks at most 15): the reads of
+        // group gp are issued before the MFMAs of group gp - 1, so the matrix pipe works while the next operands arrive.
+        constexpr int GS = 6, NGU = (CVB2_NF + GS - 1) / GS;         // 4 groups per group quad
+        float bv[2][GS], av[2][GS][NQ];
 #pragma unroll
-                for (int fi = 0; fi < CVB2_NF; ++fi) {
-                    bv[fi] = img[bo[fi] + 4 * NCW * u];
-                    const float* rp = abase + ((fbase + fi) & (CVB2_RING - 1)) * FS + 16 * NCW * u;
+        for (int gp = 0; gp <= NGU * QPW; ++gp) {
+            if (gp < NGU * QPW) {
+                const int u = gp / NGU, f0 = (gp % NGU) * GS;
+                if (wave + u * NCW < GQ) {                           // wave-uniform
 #pragma unroll
-                    for (int cq = 0; cq < NQ; ++cq) av[fi][cq] = rp[cq * 4 * G];
+                    for (int t = 0; t < GS; ++t)
+                        if (f0 + t < CVB2_NF) {
+                            bv[gp & 1][t] = bp[f0 + t][4 * NCW * u];
+#pragma unroll
+                            for (int cq = 0; cq < NQ; ++cq) av[gp & 1][t][cq] = ap[f0 + t][16 * NCW * u + cq * 4 * G];
+                        }
                 }
-                STX_SCHED_BARRIER();
-#pragma unroll
-                for (int fi = 0; fi < CVB2_NF; ++fi)
-#pragma unroll
-                    for (int cq = 0; cq < NQ; ++cq)
-                        acc[u][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[fi][cq], bv[fi], acc[u][cq], 0, 0, 0);
             }
+            STX_SCHED_BARRIER();
+            if (gp > 0) {
+                const int u = (gp - 1) / NGU, f0 = ((gp - 1) % NGU) * GS;
+                if (wave + u * NCW < GQ) {
+#pragma unroll
+                    for (int t = 0; t < GS; ++t)
+                        if (f0 + t < CVB2_NF) {
+#pragma unroll
+                            for (int cq = 0; cq < NQ; ++cq)
+                                acc[u][cq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[(gp - 1) & 1][t][cq], bv[(gp - 1) & 1][t],
+                                                                                 acc[u][cq], 0, 0, 0);
+                        }
+                }
+            }
+            STX_SCHED_BARRIER();
         }
         if (cc.i == nch - 1) {
             // macro-unit complete: lane holds out[channel 4 cq + r of group 4 gq + gl][column j] in acc[u][cq][r]

@@ -23,7 +23,7 @@
 // read a zero word) and one ds_read_b32 per channel quad the A operand (broadcast over the column quads).
 // LDS layouts make both gathers conflict-free for both sides: image voxel stride G, d-row pitch 16 G + pad with
 // (pitch + G) mod 32 = 4  (LEFT walks +pitch+G per column, RIGHT -pitch+G: both odd multiples of 4 banks, the 4 groups of a
-// block row fill the gaps); feature ring [64 columns][channel quad][G][4].
+// block row fill the gaps); feature ring [64 columns][G][4][channel quad] (one 8-byte read = both A operands of a lane).
 //
 // Roles inside a workgroup (one per CU):
 //   * LOADER waves: lane = (column j, float4 q of the voxel), one disparity row per load, NS chunks in flight in registers
@@ -168,13 +168,13 @@ __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mf
     auto batch0 = [&](const CvbCursor& c, int jb) { return c.t * CVB2_T + (c.side ? 16 * jb : -16 * jb); };
 
     // ---- feature ring helpers (both roles: a refill is shared): lane = (column ft & 15, channel (ft >> 4) + 16 i), 16
-    // columns per batch; ring layout [slot][channel quad][group][4].  The loads always execute (`live` = false: every lane
+    // columns per batch; ring layout [slot][group][4][channel quad] (a lane's A operands of all quads: one 8- or 16-byte read).  The loads always execute (`live` = false: every lane
     // out of range), so the number of loads in flight is the same on every path and hipcc's waits stay counted.
     const int ft = tid & (CVB2_NLTHR - 1);                          // (256 lanes per role)
     const int fcol = ft & 15, fc0 = ft >> 4;
-    auto ring_chan = [&](int ch) {                                  // offset of channel ch inside a ring column
+    auto ring_chan = [&](int ch) {                                  // offset of channel ch inside a ring column: [group][4][quad]
         const int g = ch / CPG, ci = ch - g * CPG;
-        return (ci >> 2) * 4 * G + g * 4 + (ci & 3);
+        return (g * 4 + (ci & 3)) * NQ + (ci >> 2);
     };
     const int rchan0 = ring_chan(fc0);
     auto feat_issue = [&](float (&dst)[NFR], const CvbCursor& c, int col0, bool live) {
@@ -187,11 +187,11 @@ __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mf
     };
     auto feat_commit = [&](const float (&src)[NFR], int col0) {     // (columns outside the image were read as zeros)
         float* rp = ring + ((col0 + fcol) & (CVB2_RING - 1)) * FS;
-        if constexpr (16 % CPG == 0) {                              // channel + 16 = group + 16 / CPG: constant stride
+        if constexpr (16 % CPG == 0) {                              // channel + 16 = group + 16 / CPG = 16 dwords further
             rp += rchan0;
 #pragma unroll
             for (int i = 0; i < NFR; ++i)
-                if (fc0 + 16 * i < Cg) rp[i * (64 / CPG)] = src[i];
+                if (fc0 + 16 * i < Cg) rp[i * 16] = src[i];
         } else {
 #pragma unroll
             for (int i = 0; i < NFR; ++i)
@@ -347,7 +347,7 @@ __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mf
     const int n = lane & 3, gl = (lane >> 2) & 3, jq = lane >> 4;
     const int j = 4 * jq + n;
     const int joff = j * S + gl + 4 * wave;                          // B operand: img[dd][j][4 gq + gl], gq = wave + u NCW
-    const float* abase = ring + (lane & 15) + 16 * wave;             // A operand: ring[slot][cq][4 gq + gl][n]
+    const float* abase = ring + ((lane & 15) + 16 * wave) * NQ;      // A operand: ring[slot][4 gq + gl][n][cq]
     const float inv = 1.0f / (float)CPG;
     f32x4 acc[QPW][NQ];
 #pragma unroll
@@ -393,8 +393,17 @@ __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mf
                     for (int t = 0; t < GS; ++t)
                         if (f0 + t < CVB2_NF) {
                             bv[gp & 1][t] = bp[f0 + t][4 * NCW * u];
+                            const float* rp = ap[f0 + t] + 16 * NCW * NQ * u;
+                            if constexpr (NQ == 2) {
+                                const float2 v2 = *reinterpret_cast<const float2*>(rp);
+                                av[gp & 1][t][0] = v2.x; av[gp & 1][t][1] = v2.y;
+                            } else if constexpr (NQ == 4) {
+                                const float4 v4 = stx_ld4(rp);
+                                av[gp & 1][t][0] = v4.x; av[gp & 1][t][1] = v4.y; av[gp & 1][t][2] = v4.z; av[gp & 1][t][3] = v4.w;
+                            } else {
 #pragma unroll
-                            for (int cq = 0; cq < NQ; ++cq) av[gp & 1][t][cq] = ap[f0 + t][16 * NCW * u + cq * 4 * G];
+                                for (int cq = 0; cq < NQ; ++cq) av[gp & 1][t][cq] = rp[cq];
+                            }
                         }
                 }
             }

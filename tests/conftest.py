@@ -23,14 +23,24 @@ def emu():
 # ---------------------------------------------------------------------------------------------------------------
 # Parity report: tests that measure an error against the oracle / the reference fixtures record it here; the numbers
 # are printed in the terminal summary (also under -q, where captured stdout of passing tests is not shown) and
-# appended to gpurun_out/parity_report.jsonl when that directory exists (GPU box runs).
+# appended to gpurun_out/parity_report.jsonl when that directory exists (GPU box runs; xdist-safe).
 _PARITY = []
 
 
 @pytest.fixture
 def parity_log():
     def add(name, **fields):
-        _PARITY.append({"test": name, **fields})
+        rec = {"test": name, **fields}
+        _PARITY.append(rec)
+        # written at once (one O_APPEND line): under pytest-xdist the workers' records never reach the controller's summary
+        out = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out):
+            try:
+                import json
+                with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
+                    f.write(json.dumps(rec) + "\n")
+            except OSError:
+                pass
     return add
 
 
@@ -41,11 +51,3 @@ def pytest_terminal_summary(terminalreporter):
     terminalreporter.section("parity report (achieved errors)")
     for rec in _PARITY:
         terminalreporter.write_line(json.dumps(rec))
-    out = os.path.join(ROOT, "gpurun_out")
-    if os.path.isdir(out):
-        try:
-            with open(os.path.join(out, "parity_report.jsonl"), "a") as f:
-                for rec in _PARITY:
-                    f.write(json.dumps(rec) + "\n")
-        except OSError:
-            pass

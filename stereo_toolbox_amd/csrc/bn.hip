@@ -13,6 +13,7 @@
 //             stx_bn_bwd_apply : dz_k = gamma_k*invstd_k*(g - mean(g) - xhat_k*mean(g*xhat_k))
 // All kernels are HBM-bound streaming passes (16-B accesses, one float4 channel quad per lane).
 #include "stx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,6 +48,65 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
     s1 = bn_block_sum(s1, red, tid);
     s2 = bn_block_sum(s2, red, tid);
     if (tid == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = bt - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        invstd_out[c] = invstd;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        if (running_var) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// Same result for C % 4 == 0 and many partial rows (the L0 layers emit ~13 000 of them): one workgroup per channel QUAD,
+// 512 threads, every thread two 16-byte loads per row (the first version read one dword per load with a 2C-float
+// stride and a dependent add: 18-30 us per BN layer, ~0.6 ms of a GwcNet_GC train step).  fp64 throughout; the
+// cross-lane sums go through the wave (bit moves of the two double halves), then one LDS round.  Fixed summation
+// order -> run-to-run deterministic.
+constexpr int BN_FIN_THREADS = 512;
+
+__device__ __forceinline__ double bn_shfl_down_f64(double v, int delta) {
+    union { double d; float f[2]; } a, b;
+    a.d = v;
+    b.f[0] = __shfl_down(a.f[0], delta);
+    b.f[1] = __shfl_down(a.f[1], delta);
+    return b.d;
+}
+
+__global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize4_kernel(
+    const float* __restrict__ partials, int nrows, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+    float* __restrict__ invstd_out) {
+    __shared__ double red[BN_FIN_THREADS / 64][8];
+    const int c0 = blockIdx.x * 4, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const float* p = partials + c0;
+#pragma unroll 4
+    for (int r = tid; r < nrows; r += BN_FIN_THREADS) {
+        const float4 a = stx_ld4(p + (size_t)r * 2 * C), b = stx_ld4(p + (size_t)r * 2 * C + C);
+        acc[0] += (double)a.x; acc[1] += (double)a.y; acc[2] += (double)a.z; acc[3] += (double)a.w;
+        acc[4] += (double)b.x; acc[5] += (double)b.y; acc[6] += (double)b.z; acc[7] += (double)b.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc[k] += bn_shfl_down_f64(acc[k], d);
+        if (lane == 0) red[wave][k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < BN_FIN_THREADS / 64; ++w) { s1 += red[w][tid]; s2 += red[w][4 + tid]; }
+        const int c = c0 + tid;
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -243,8 +303,13 @@ extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double c
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
     stx_begin();
     STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    static const int v1 = getenv("STX_BN_FINALIZE_V1") ? 1 : 0;                      // A/B switch: first-generation kernel
+    if (C % 4 == 0 && nrows >= 256 && !v1)
+        hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(BN_FIN_THREADS), 0, (hipStream_t)stream, partials, nrows, C,
+                           count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
+                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     return stx_check_launch("bn_finalize");
 }
 

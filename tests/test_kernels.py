@@ -534,6 +534,34 @@ def test_ac_volume_backward(be):
 
 
 # ------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("case", [(1500, 32), (300, 64), (100, 32), (257, 20)])
+def test_bn_finalize_many_rows(be, case):
+    """stx_bn_finalize with as many partial rows as the L0 convolutions emit (the channel-quad kernel serves
+    C % 4 == 0 and >= 256 rows, the first-generation kernel the rest): both against an fp64 evaluation."""
+    nrows, C = case
+    torch.manual_seed(5)
+    part = torch.randn(nrows, 2, C)
+    part[:, 1] = part[:, 1].abs() * 40 + 50          # sum z^2 comfortably above (sum z)^2 / n
+    count = float(nrows * 64)
+    g, b = torch.rand(C) + 0.5, torch.randn(C)
+    rm, rv = torch.randn(C), torch.rand(C) + 0.5
+    s1, s2 = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    mean = s1 / count
+    var = (s2 / count - mean * mean).clamp(min=0)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    drm, drv = be.dev(rm.clone()), be.dev(rv.clone())      # (the emulator backend works on the host tensor itself)
+    outs = [be.empty(C) for _ in range(4)]
+    be.call("stx_bn_finalize", ptr(be.dev(part)), nrows, C, count, ptr(be.dev(g)), ptr(be.dev(b)), ptr(drm), ptr(drv),
+            0.1, 1e-5, *[ptr(o) for o in outs])
+    sc, sh, m, i = outs
+    _close(m, mean.float(), rtol=1e-6, atol=1e-7)
+    _close(i, invstd.float(), rtol=1e-6, atol=1e-7)
+    _close(sc, (g.double() * invstd).float(), rtol=1e-6, atol=1e-7)
+    _close(sh, (b.double() - mean * g.double() * invstd).float(), rtol=1e-5, atol=1e-6)
+    _close(drm, (0.9 * rm.double() + 0.1 * mean).float(), rtol=1e-6, atol=1e-7)
+    _close(drv, (0.9 * rv.double() + 0.1 * var * count / (count - 1)).float(), rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("case", [(1000, 32, False, True, False), (777, 64, True, True, False),
                                   (500, 32, False, False, True), (640, 128, False, True, True)])
 def test_bn_train_fwd_bwd(be, case):

@@ -164,6 +164,12 @@ def main():
         sc, sh = torch.rand(C, device=dev), torch.rand(C, device=dev)
         ms = timeit(lambda: lib.call("stx_bn_apply", P(z), P(sc), P(sh), None, None, None, P(y), nvox, C, 1, stream()), it)
         report("bn_apply_L0", ms, nbytes=z.numel() * 8)
+        nrows = lib.raw("stx_conv3d_fwd_blocks")(D, Hh, Ww) * B
+        fpart = torch.randn(nrows, 2, C, device=dev)
+        fo = [torch.empty(C, device=dev) for _ in range(6)]
+        ms = timeit(lambda: lib.call("stx_bn_finalize", P(fpart), nrows, C, float(nvox), P(sc), P(sh), P(fo[4]), P(fo[5]),
+                                     0.1, 1e-5, P(fo[0]), P(fo[1]), P(fo[2]), P(fo[3]), stream()), it)
+        report("bn_finalize_L0", ms, nbytes=fpart.numel() * 4)
         NB = lib.raw("stx_bn_reduce_blocks")()
         part, sums = torch.empty(NB, 3, C, device=dev), torch.empty(3, C, device=dev)
         ms = timeit(lambda: lib.call("stx_bn_bwd_reduce", P(z), P(y), P(z), P(sc), P(sh), None, None, None, P(part),

@@ -19,6 +19,7 @@
 // One thread owns one output pixel: it walks the 192 output disparities once, advancing a
 // two-entry window of H/W-interpolated cost samples, with an online (running-max) softmax.
 #include "stx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,6 +145,196 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_kernel(
     for (int dc = cur + 2; dc < Dc; ++dc) gp[dc * pstride] = 0.f;
 }
 
+// ---- second generation of the two per-pixel kernels (same results up to the softmax shift; chosen when the LDS fits).
+// The first versions spend ~30 VALU instructions per (pixel, disparity): the D-axis lerp coordinates -- identical for every
+// lane -- are recomputed per lane and step, the softmax is the online (rescaling) form with a divergent branch, and the
+// H/W-interpolated cost samples arrive through four dependent gathers every fourth step (head_fwd 0.092 ms at 576x960 where
+// 192 x 553k exp + lerp need ~0.03 ms of VALU time).  Here a workgroup of 256 pixels of one image row
+//   1. builds a per-launch table in LDS: {1-t, t, i0} of every output disparity (+ a sentinel),
+//   2. gathers every lane's Dc H/W-interpolated samples once into LDS (cs[k][lane]: conflict-free), eight planes in
+//      flight, keeping their maximum M (an upper bound of every interpolated logit: lerp weights are in [0, 1]),
+//   3. walks the output disparities ONCE with everything it needs one step ahead in registers: the next table entry, and
+//      c0 / c1 / the prefetched c(k+2) of the current coarse interval (i0 is non-decreasing and wave-uniform, so the
+//      interval change is a scalar branch) -- no LDS latency on the dependent chain, one exp per step, softmax shift M.
+// M can exceed the true maximum by the lerp gap of the steepest interval; should that ever underflow the whole sum of a
+// lane (cost steps of several hundred between neighbouring planes), the workgroup redoes the walk with the exact maximum.
+struct HdStep { float w0, w1; int k, pad; };   // 1 - t, t, i0
+
+template <bool AC>
+__device__ __forceinline__ void hd_build_table(HdStep* tw, int Dc, int D, float rd, int tid) {
+    for (int d = tid; d <= D; d += HD_THREADS) {
+        const Lerp ld = hd_src<AC>(d < D ? d : D - 1, rd, Dc);
+        HdStep t;
+        t.w0 = 1.f - ld.t; t.w1 = ld.t; t.k = ld.i0; t.pad = 0;
+        tw[d] = t;
+    }
+}
+
+constexpr int HD_STAGE_UNROLL = 8;
+
+// cs[k][tid] = H/W-interpolated sample of coarse plane k for this lane's pixel; returns their maximum
+__device__ __forceinline__ float hd_stage_samples(float* cs, const float* __restrict__ cb, int plane, int Dc, int Wc,
+                                                  Lerp lh, Lerp lw, int tid) {
+    const int o00 = lh.i0 * Wc + lw.i0, o01 = lh.i0 * Wc + lw.i1, o10 = lh.i1 * Wc + lw.i0, o11 = lh.i1 * Wc + lw.i1;
+    const float wh0 = 1.f - lh.t, ww0 = 1.f - lw.t;
+    float mx = -3.0e38f;
+    int k = 0;
+    for (; k + HD_STAGE_UNROLL <= Dc; k += HD_STAGE_UNROLL) {
+        float a[HD_STAGE_UNROLL], b[HD_STAGE_UNROLL], c[HD_STAGE_UNROLL], d[HD_STAGE_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HD_STAGE_UNROLL; ++u) {
+            const float* pl = cb + (size_t)(k + u) * plane;
+            a[u] = pl[o00]; b[u] = pl[o01]; c[u] = pl[o10]; d[u] = pl[o11];
+        }
+#pragma unroll
+        for (int u = 0; u < HD_STAGE_UNROLL; ++u) {
+            const float v = wh0 * (ww0 * a[u] + lw.t * b[u]) + lh.t * (ww0 * c[u] + lw.t * d[u]);
+            cs[(k + u) * HD_THREADS + tid] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    for (; k < Dc; ++k) {
+        const float* pl = cb + (size_t)k * plane;
+        const float v = wh0 * (ww0 * pl[o00] + lw.t * pl[o01]) + lh.t * (ww0 * pl[o10] + lw.t * pl[o11]);
+        cs[k * HD_THREADS + tid] = v;
+        mx = fmaxf(mx, v);
+    }
+    return mx;
+}
+
+static size_t hd_lds_bytes(int Dc, int D) {
+    return (size_t)Dc * HD_THREADS * 4 + (size_t)(D + 1) * sizeof(HdStep);
+}
+
+// The pipelined walk over d = 0 .. D-1.  step(d as float, w0, w1, c0, c1) runs once per output disparity;
+// leave(k, kn) runs when the coarse interval changes from k to kn > k (wave-uniform) and once at the end (kn = -1);
+// tie(nk) pins the step's results and the prefetched interval index to one program point (STX_TIE3), so that the wait
+// for the table entry sits behind the step's arithmetic instead of in front of it (hipcc hoists the branch otherwise).
+template <typename Step, typename Leave, typename Tie>
+__device__ __forceinline__ void hd_walk(const float* cs, const HdStep* tw, int Dc, int D, int tid, Step&& step, Leave&& leave,
+                                        Tie&& tie) {
+    HdStep cur = tw[0];
+    int k = __builtin_amdgcn_readfirstlane(cur.k);
+    auto at = [&](int kk) { return cs[(kk < Dc ? kk : Dc - 1) * HD_THREADS + tid]; };
+    float c0 = at(k), c1 = at(k + 1), cn = at(k + 2);
+    float fd = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const HdStep nxt = tw[d + 1];                       // (in flight during this step's arithmetic)
+        STX_SCHED_BARRIER();
+        step(fd, cur.w0, cur.w1, c0, c1);
+        fd += 1.f;
+        int nk = nxt.k;
+        tie(nk);
+        const int kn = __builtin_amdgcn_readfirstlane(nk);
+        if (kn != k) {
+            leave(k, kn);
+            if (kn == k + 1) { c0 = c1; c1 = cn; }
+            else { c0 = at(kn); c1 = at(kn + 1); }
+            k = kn;
+            cn = at(k + 2);
+        }
+        cur = nxt;
+    }
+    leave(k, -1);
+}
+
+template <bool AC>
+__global__ __launch_bounds__(HD_THREADS) void head_fwd_lds_kernel(
+    const float* __restrict__ cost, float* __restrict__ disp, float* __restrict__ stats,
+    int Dc, int Hc, int Wc, int D, int H, int W) {
+    STX_DYN_SMEM(smem);
+    __shared__ int redo;
+    float* cs = reinterpret_cast<float*>(smem);                           // [Dc][256]
+    HdStep* tw = reinterpret_cast<HdStep*>(cs + (size_t)Dc * HD_THREADS);   // [D + 1]
+    const int tid = threadIdx.x;
+    const int w_raw = blockIdx.x * HD_THREADS + tid;
+    const int w = w_raw < W ? w_raw : W - 1;                             // (every lane reaches the barriers)
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float rd = hd_scale<AC>(Dc, D), rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
+    const Lerp lh = hd_src<AC>(h, rh, Hc), lw = hd_src<AC>(w, rw, Wc);
+    const int plane = Hc * Wc;
+    if (tid == 0) redo = 0;
+    hd_build_table<AC>(tw, Dc, D, rd, tid);
+    float m = hd_stage_samples(cs, cost + (size_t)b * Dc * plane, plane, Dc, Wc, lh, lw, tid);
+    __syncthreads();
+    float s = 0.f, acc = 0.f;
+    hd_walk(cs, tw, Dc, D, tid,
+            [&](float fd, float w0, float w1, float c0, float c1) {
+                const float e = stx_exp(w0 * c0 + w1 * c1 - m);
+                s += e;
+                acc = fmaf(fd, e, acc);
+            },
+            [](int, int) {}, [&](int& nk) { STX_TIE3(s, acc, nk); });
+    if (!(s > 1e-30f)) redo = 1;                                         // (also catches NaN logits: the exact walk reproduces them)
+    __syncthreads();
+    if (redo) {
+        m = -3.0e38f;
+        hd_walk(cs, tw, Dc, D, tid, [&](float, float w0, float w1, float c0, float c1) { m = fmaxf(m, w0 * c0 + w1 * c1); },
+                [](int, int) {}, [](int&) {});
+        s = 0.f; acc = 0.f;
+        hd_walk(cs, tw, Dc, D, tid,
+                [&](float fd, float w0, float w1, float c0, float c1) {
+                    const float e = stx_exp(w0 * c0 + w1 * c1 - m);
+                    s += e;
+                    acc = fmaf(fd, e, acc);
+                },
+                [](int, int) {}, [](int&) {});
+    }
+    if (w_raw < W) {
+        const size_t o = ((size_t)b * H + h) * W + w;
+        disp[o] = acc / s;
+        if (stats) { stats[2 * o] = m; stats[2 * o + 1] = s; }
+    }
+}
+
+template <bool AC>
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_lds_kernel(
+    const float* __restrict__ gout, const float* __restrict__ cost, const float* __restrict__ disp,
+    const float* __restrict__ stats, float* __restrict__ gpix, int Dc, int Hc, int Wc, int D, int H, int W) {
+    STX_DYN_SMEM(smem);
+    float* cs = reinterpret_cast<float*>(smem);
+    HdStep* tw = reinterpret_cast<HdStep*>(cs + (size_t)Dc * HD_THREADS);
+    const int tid = threadIdx.x;
+    const int w_raw = blockIdx.x * HD_THREADS + tid;
+    const int w = w_raw < W ? w_raw : W - 1;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const float rd = hd_scale<AC>(Dc, D), rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
+    const Lerp lh = hd_src<AC>(h, rh, Hc), lw = hd_src<AC>(w, rw, Wc);
+    const int plane = Hc * Wc;
+    hd_build_table<AC>(tw, Dc, D, rd, tid);
+    (void)hd_stage_samples(cs, cost + (size_t)b * Dc * plane, plane, Dc, Wc, lh, lw, tid);
+    __syncthreads();
+    const size_t o = ((size_t)b * H + h) * W + w;
+    const float dv = disp[o], m = stats[2 * o], gs = gout[o] / stats[2 * o + 1];      // g / sum
+    float* gp = gpix + ((size_t)b * Dc * H + h) * W + w;                              // + k * H * W
+    const size_t pstride = (size_t)H * W;
+    const bool live = w_raw < W;
+    float a0 = 0.f, a1 = 0.f;                                                         // gradients of samples k and k + 1
+    for (int k = 0, k0 = __builtin_amdgcn_readfirstlane(tw[0].k); k < k0; ++k)        // (planes below the first interval: none in practice)
+        if (live) gp[k * pstride] = 0.f;
+    hd_walk(cs, tw, Dc, D, tid,
+            [&](float fd, float w0, float w1, float c0, float c1) {
+                const float e = stx_exp(w0 * c0 + w1 * c1 - m);
+                const float gl = gs * e * (fd - dv);                                  // g * p_d * (d - disp)
+                a0 = fmaf(w0, gl, a0);
+                a1 = fmaf(w1, gl, a1);
+            },
+            [&](int k, int kn) {
+                if (k + 1 >= Dc) { a0 += a1; a1 = 0.f; }                              // the clamped upper neighbour is plane k itself
+                if (live) gp[k * pstride] = a0;
+                const int stop = kn < 0 ? Dc : kn;                                    // planes k+1 .. stop-1 are left for good
+                if (k + 1 < stop) {
+                    if (live) gp[(k + 1) * pstride] = a1;
+                    for (int z = k + 2; z < stop; ++z)
+                        if (live) gp[z * pstride] = 0.f;
+                    a1 = 0.f;
+                }
+                a0 = a1;
+                a1 = 0.f;
+            },
+            [&](int& nk) { STX_TIE3(a0, a1, nk); });
+}
+
 // weight with which output index `dst` reads source cell `cell` under the lerp
 template <bool AC>
 __device__ __forceinline__ float hd_weight(int dst, float scale, int n, int cell) {
@@ -259,13 +450,27 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 
 }  // namespace
 
+// LDS-staged per-pixel kernels when their tables fit comfortably (two workgroups per CU); STX_HEAD_V1 = first generation
+static bool hd_use_lds(size_t lds) {
+    const int v1 = getenv("STX_HEAD_V1") ? 1 : 0;                  // (read per call: tests switch generations)
+    return !v1 && lds <= 80 * 1024;
+}
+
 template <bool AC>
 static int head_fwd_launch(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H,
                            int W, void* stream) {
     STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
     dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
-    hipLaunchKernelGGL(head_fwd_kernel<AC>, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
-                       Wc, D, H, W);
+    const size_t lds = hd_lds_bytes(Dc, D);
+    if (hd_use_lds(lds)) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void*)head_fwd_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(head_fwd_lds_kernel<AC>, grid, dim3(HD_THREADS), lds, (hipStream_t)stream, cost, disp, stats,
+                           Dc, Hc, Wc, D, H, W);
+    } else {
+        hipLaunchKernelGGL(head_fwd_kernel<AC>, grid, dim3(HD_THREADS), 0, (hipStream_t)stream, cost, disp, stats, Dc, Hc,
+                           Wc, D, H, W);
+    }
     return stx_check_launch("head_fwd");
 }
 
@@ -290,8 +495,17 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
                            float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
     STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_bwd_pix_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
-                       disp, stats, workspace, Dc, Hc, Wc, D, H, W);
+    const size_t lds = hd_lds_bytes(Dc, D);
+    if (hd_use_lds(lds)) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void*)head_bwd_pix_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        hipLaunchKernelGGL(head_bwd_pix_lds_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), lds, st, gout,
+                           cost, disp, stats, workspace, Dc, Hc, Wc, D, H, W);
+    } else {
+        hipLaunchKernelGGL(head_bwd_pix_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
+                           disp, stats, workspace, Dc, Hc, Wc, D, H, W);
+    }
     int rc = stx_check_launch("head_bwd(pixels)");
     if (rc) return rc;
     // footprint of a cost cell in output pixels: 2/scale (+ slack for the border clamps)

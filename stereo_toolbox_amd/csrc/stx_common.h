@@ -13,6 +13,7 @@
 #define stx_exp(x) expf(x)
 #define STX_SCHED_BARRIER() ((void)0)
 #define STX_OPAQUE_VGPR(x) ((void)0)
+#define STX_TIE3(a, b, c) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -22,6 +23,9 @@
 // Makes a VGPR value opaque to the optimiser at this point (blocks hoisting of address math that
 // would otherwise be precomputed into dozens of live registers; guide 5.7 item 3).
 #define STX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))
+// Orders three VGPR values at this point of the program: everything that produces a, b, c is issued before anything that
+// consumes them afterwards (keeps a prefetched value's s_waitcnt BEHIND the arithmetic it is meant to overlap with).
+#define STX_TIE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 #endif
 // Buffer loads through a resource descriptor (wave-uniform base + 32-bit lane offset + wave-uniform offset): lanes whose
 // offset lies outside [0, bytes) read zeros without touching memory -- the bounds check replaces address clamps and

@@ -180,11 +180,20 @@ def test_head_fwd_bwd(be, case):
     _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("gen", ["lds", "v1"])
 @pytest.mark.parametrize("ac", [0, 1])
 @pytest.mark.parametrize("case", [(1, 4, 5, 7, 16, 20, 28, 5.0), (2, 12, 6, 9, 48, 24, 36, 3.0), (1, 5, 4, 6, 17, 13, 22, 4.0),
-                                  (1, 1, 3, 1, 4, 9, 5, 2.0)])
-def test_head2_fwd_bwd(be, case, ac):
-    """Entry points with an explicit interpolation rule: align_corners=True is the PCWNet / CFNet head."""
+                                  (1, 1, 3, 1, 4, 9, 5, 2.0), (1, 3, 2, 75, 12, 3, 300, 40.0), (1, 9, 3, 4, 5, 4, 6, 3.0),
+                                  (1, 6, 3, 5, 24, 12, 20, 3000.0)])
+def test_head2_fwd_bwd(be, case, ac, gen, monkeypatch):
+    """Entry points with an explicit interpolation rule: align_corners=True is the PCWNet / CFNet head.  Both kernel
+    generations (LDS-staged tables / first version); W = 300 spans two workgroups with a ragged tail, D < Dc leaves
+    coarse planes without an output disparity, gain 3000 has cost steps far beyond the exp range (the LDS kernel's
+    bound-shifted sum underflows and it must redo the walk with the exact maximum)."""
+    if gen == "v1":
+        monkeypatch.setenv("STX_HEAD_V1", "1")
+    else:
+        monkeypatch.delenv("STX_HEAD_V1", raising=False)
     B, Dc, Hc, Wc, D, H, W, gain = case
     torch.manual_seed(3)
     cost = (torch.randn(B, 1, Dc, Hc, Wc) * gain).requires_grad_()

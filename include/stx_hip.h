@@ -178,6 +178,24 @@ int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z1, const fl
 int stx_pad_normalize_u8(const unsigned char* img, float* out, int B, int H, int W, int Hp, int Wp, int top,
                          const float* mean3, const float* std3, void* stream);
 
+/* ---- Sampled (cascade) cost volume of the CFNet family ---------------------------------------------------
+ * One call replaces, per cascade stage (models/CFNet/cfnet.py:553-566 / 584-597),
+ *   SpatialTransformer (models/CFNet/submodule.py:306-350) x 2, groupwise_correlation_4D (submodule.py:163-169),
+ *   cost_volume_generator (cfnet.py:470-497) x 2 and torch.cat((gwc_volume, concat_volume, disparity_samples), dim=1):
+ *   vol[b][s][h][w][:] = ( mean_c Lg[g*cpg+c][h][w] * Rg[g*cpg+c][h][x]   g < G
+ *                        | Lc[c][h][w] | Rc[c][h][x]                        c < Cc
+ *                        | samples[b][s][h][w] | zero pad up to CTp ),     x = w - samples[b][s][h][w]
+ * with the reference's boundary rule: the gather index is clamped into the row and every right-feature term is
+ * zeroed where the un-clamped x leaves [0, W-1].  Features NCHW fp32, samples [B][S][H][W] (integer-valued floats),
+ * vol NDHWC [B][S][H][W][CTp], CTp >= G + 2*Cc + 1 and a multiple of 4 (the consuming convolution wants 8).
+ * _bwd: gradients w.r.t. the four feature maps (the hypotheses carry none); gRg / gRc are zeroed and then accumulated
+ * with float atomics, like the reference's gather backward. */
+int stx_sampled_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc, const float* Rc, int Cc,
+                           const float* samples, float* vol, int B, int H, int W, int S, int CTp, void* stream);
+int stx_sampled_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc,
+                           const float* samples, float* gLg, float* gRg, float* gLc, float* gRc, int B, int H, int W,
+                           int S, int CTp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,8 @@ SIGNATURES = {
     "stx_scale_channels": [_P, _P, _P, _L, _I, _P],
     # preprocess.hip
     "stx_pad_normalize_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "stx_sampled_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "stx_sampled_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # bn.hip
     "stx_bn_reduce_blocks": [],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],

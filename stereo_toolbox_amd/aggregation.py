@@ -74,6 +74,11 @@ def _infer_conv(x, conv, scale, bias, residual, relu):
         return ops.deconv3d_forward(x, wp, conv.weight.shape[1], scale=scale, bias=bias, residual=residual, relu=relu)[0]
     if ops._is_c1(conv.weight, ks, stride, False) and scale is None and bias is None and not relu:
         return ops.conv3d_c1_forward(x, conv.weight.detach().contiguous(), residual)
+    if x.shape[-1] != conv.weight.shape[1]:     # a volume that already carries its zero pad channels (ops.sampled_volume)
+        if x.shape[-1] != (conv.weight.shape[1] + 7) // 8 * 8:
+            raise ops.StxError(f"conv: input has {x.shape[-1]} channels, weight expects {conv.weight.shape[1]}")
+        wpad = ops.pad_weight_channels(conv.weight.detach(), x.shape[-1])
+        return ops.conv3d_forward(x, ops.pack_weight(wpad, 0), conv.weight.shape[0], ks, stride, scale, bias, residual, relu)[0]
     if x.shape[-1] % 8 != 0:       # odd input widths (CFNet cascade volumes): zero-padded GEMM-K, packed copy not cached
         xp, wpad = ops.pad_input_channels(x, conv.weight.detach())
         return ops.conv3d_forward(xp, ops.pack_weight(wpad, 0), conv.weight.shape[0], ks, stride, scale, bias, residual, relu)[0]

@@ -1,0 +1,234 @@
+// Sampled (cascade) cost volume of the CFNet family for gfx950: the per-pixel disparity hypotheses of a cascade stage
+// turned into the stage's NDHWC input volume in one pass, and its backward.
+//
+// Replaces (reference, /root/reference/stereo_toolbox/models/CFNet):
+//   SpatialTransformer.forward                submodule.py:306-350  (right features gathered at column w - sample with a
+//                                                                   clamped index, zeroed where the un-clamped column
+//                                                                   leaves the image; left features broadcast over S)
+//   groupwise_correlation_4D                  submodule.py:163-169
+//   cfnet.cost_volume_generator               cfnet.py:470-497      (called twice per stage: "concat" and "gwc")
+//   torch.cat((gwc, concat, samples), dim=1)  cfnet.py:560-566 / 591-597
+// The reference chain materialises two [B,C,S,H,W] feature stacks per call (320 + 24 channels x 16 samples at 1/4
+// resolution: ~0.8 GB written and re-read per stage); here the only HBM traffic is the volume itself
+// ([B][S][H][W][CTp] floats, CTp = G + 2 Cc + 1 rounded up to 8: the GEMM-K step of the convolution that consumes it,
+// pad channels written as zeros) -- the feature rows of a workgroup's 64 columns are re-read from L2 for every sample.
+// Roofline: HBM, algorithmic bytes = volume once (+ features once).
+//
+// Forward: a workgroup owns (b, s, h, 64 columns).  Lane = column for the feature reads (NCHW rows: coalesced left
+// reads, near-coalesced gathers: neighbouring pixels carry neighbouring hypotheses), the four waves split the groups /
+// concat channels; results meet in an LDS tile [64][CTp + 1] and leave as one contiguous run of 16-byte stores.
+// Backward: a workgroup owns (b, h, 64 columns) and walks the S samples: the left-feature gradients accumulate in
+// registers (no atomics), the right-feature gradients are scattered with float atomics exactly like the reference's
+// gather backward (index_put with accumulate) -- run-to-run summation order is not fixed, as in the reference.
+#include "stx_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int SV_TW = 64;
+constexpr int SV_THREADS = 256;
+constexpr int SV_MAXGPW = 10;      // groups per wave (G <= 40)
+
+struct SvArgs {
+    const float *Lg, *Rg, *Lc, *Rc, *samples;
+    float* vol;
+    const float* gvol;
+    float *gLg, *gRg, *gLc, *gRc;
+    int B, H, W, S, G, cpg, Cc, CT, CTp;
+};
+
+// column of the right image a hypothesis points at: pos = w - sample (integer-valued floats), index clamped into the
+// row, `valid` false where the un-clamped position leaves [0, W-1] (submodule.py:331-346)
+__device__ __forceinline__ int sv_column(int w, float sample, int W, bool& valid) {
+    const float pos = (float)w - sample;
+    valid = !(pos < 0.f || pos > (float)(W - 1));
+    const float cl = pos < 0.f ? 0.f : (pos > (float)(W - 1) ? (float)(W - 1) : pos);
+    return (int)cl;
+}
+
+__global__ __launch_bounds__(SV_THREADS) void sampled_volume_fwd_kernel(SvArgs a) {
+    STX_DYN_SMEM(smem);
+    float* tile = reinterpret_cast<float*>(smem);               // [64][TS]
+    const int TS = a.CTp + 1;
+    const int tid = threadIdx.x, wl = tid & 63, wave = tid >> 6;
+    const int w0 = blockIdx.x * SV_TW, h = blockIdx.y, bs = blockIdx.z, b = bs / a.S;
+    const int HW = a.H * a.W, Cg = a.G * a.cpg;
+    const int w = w0 + wl, wc = w < a.W ? w : a.W - 1;            // (ragged last tile: clamped reads, stores masked)
+    const float sample = a.samples[((size_t)bs * a.H + h) * a.W + wc];
+    bool valid;
+    const int xi = sv_column(wc, sample, a.W, valid);
+    float* mine = tile + wl * TS;
+    if (a.G) {
+        const float* Lp = a.Lg + ((size_t)b * Cg * a.H + h) * a.W + wc;
+        const float* Rp = a.Rg + ((size_t)b * Cg * a.H + h) * a.W + xi;
+        const float inv = 1.f / (float)a.cpg;
+        for (int g = wave; g < a.G; g += 4) {
+            float acc = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < a.cpg; ++c) {
+                const size_t o = (size_t)(g * a.cpg + c) * HW;
+                acc = fmaf(Lp[o], Rp[o], acc);
+            }
+            mine[g] = valid ? acc * inv : 0.f;
+        }
+    }
+    for (int c = wave; c < a.Cc; c += 4) {
+        mine[a.G + c] = a.Lc[((size_t)(b * a.Cc + c) * a.H + h) * a.W + wc];
+        const float r = a.Rc[((size_t)(b * a.Cc + c) * a.H + h) * a.W + xi];
+        mine[a.G + a.Cc + c] = valid ? r : 0.f;
+    }
+    if (wave == 0) {
+        mine[a.G + 2 * a.Cc] = sample;
+        for (int c = a.CT; c < a.CTp; ++c) mine[c] = 0.f;
+    }
+    __syncthreads();
+    const int Q = a.CTp >> 2;
+    const int ncol = (a.W - w0) < SV_TW ? (a.W - w0) : SV_TW;
+    float* out = a.vol + (((size_t)bs * a.H + h) * a.W + w0) * a.CTp;
+    for (int idx = tid; idx < ncol * Q; idx += SV_THREADS) {
+        const int col = idx / Q, q = idx - col * Q;
+        const float* src = tile + col * TS + 4 * q;
+        stx_st4(out + (size_t)idx * 4, make_float4(src[0], src[1], src[2], src[3]));
+    }
+}
+
+template <int CPG>
+__global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a) {
+    STX_DYN_SMEM(smem);
+    float* tile = reinterpret_cast<float*>(smem);               // [64][TS]: the volume gradient of (s, h, 64 columns)
+    const int TS = a.CTp + 1;
+    const int tid = threadIdx.x, wl = tid & 63, wave = tid >> 6;
+    const int w0 = blockIdx.x * SV_TW, h = blockIdx.y, b = blockIdx.z;
+    const int HW = a.H * a.W, Cg = a.G * CPG;
+    const int w = w0 + wl, wc = w < a.W ? w : a.W - 1;
+    const bool live = w < a.W;
+    const int Q = a.CTp >> 2;
+    const int ncol = (a.W - w0) < SV_TW ? (a.W - w0) : SV_TW;
+    const float inv = 1.f / (float)CPG;
+    float gl[SV_MAXGPW][CPG];                                   // d/dLg of my groups' channels
+#pragma unroll
+    for (int k = 0; k < SV_MAXGPW; ++k)
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) gl[k][c] = 0.f;
+    float glc[4] = {0.f, 0.f, 0.f, 0.f};                        // d/dLc of concat channels wave, wave+4, .. (Cc <= 16)
+    const float* Lp = a.G ? a.Lg + ((size_t)b * Cg * a.H + h) * a.W + wc : nullptr;
+    for (int s = 0; s < a.S; ++s) {
+        const int bs = b * a.S + s;
+        __syncthreads();                                        // the previous sample's tile is no longer read
+        const float* src = a.gvol + (((size_t)bs * a.H + h) * a.W + w0) * a.CTp;
+        for (int idx = tid; idx < ncol * Q; idx += SV_THREADS) {
+            const int col = idx / Q, q = idx - col * Q;
+            const float4 v = stx_ld4(src + (size_t)idx * 4);
+            float* dst = tile + col * TS + 4 * q;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        const float sample = a.samples[((size_t)bs * a.H + h) * a.W + wc];
+        bool valid;
+        const int xi = sv_column(wc, sample, a.W, valid);
+        valid = valid && live;
+        const float* mine = tile + wl * TS;
+        if (a.G) {
+            const float* Rp = a.Rg + ((size_t)b * Cg * a.H + h) * a.W + xi;
+            float* gRp = a.gRg + ((size_t)b * Cg * a.H + h) * a.W + xi;
+#pragma unroll
+            for (int k = 0; k < SV_MAXGPW; ++k) {
+                const int g = wave + 4 * k;
+                if (g < a.G && valid) {                            // (invalid hypotheses carry no gradient on either side)
+                    const float gv = mine[g] * inv;
+#pragma unroll
+                    for (int c = 0; c < CPG; ++c) {
+                        const size_t o = (size_t)(g * CPG + c) * HW;
+                        gl[k][c] = fmaf(gv, Rp[o], gl[k][c]);
+                        atomicAdd(gRp + o, gv * Lp[o]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = wave + 4 * k;
+            if (c < a.Cc && live) {
+                glc[k] += mine[a.G + c];
+                if (valid) atomicAdd(a.gRc + ((size_t)(b * a.Cc + c) * a.H + h) * a.W + xi, mine[a.G + a.Cc + c]);
+            }
+        }
+    }
+    if (!live) return;
+    if (a.G) {
+        float* gLp = a.gLg + ((size_t)b * Cg * a.H + h) * a.W + w;
+#pragma unroll
+        for (int k = 0; k < SV_MAXGPW; ++k) {
+            const int g = wave + 4 * k;
+            if (g < a.G) {
+#pragma unroll
+                for (int c = 0; c < CPG; ++c) gLp[(size_t)(g * CPG + c) * HW] = gl[k][c];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = wave + 4 * k;
+        if (c < a.Cc) a.gLc[((size_t)(b * a.Cc + c) * a.H + h) * a.W + w] = glc[k];
+    }
+}
+
+int sv_check(const SvArgs& a, const char* who) {
+    STX_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.S > 0, "%s: empty shape", who);
+    STX_REQUIRE(a.G >= 0 && a.Cc >= 0 && (a.G > 0 || a.Cc > 0), "%s: no channels", who);
+    STX_REQUIRE(a.CTp >= a.CT && a.CTp % 4 == 0, "%s: padded channel count %d (need >= %d, multiple of 4)", who, a.CTp, a.CT);
+    STX_REQUIRE((long long)a.B * a.S <= 65535 && a.H <= 65535, "%s: grid too large", who);
+    return STX_OK;
+}
+
+}  // namespace
+
+// vol[b][s][h][w][:] = (group-wise correlation of Lg[.., w] and Rg[.., w - samples], G channels | Lc[.., w], Cc channels |
+// Rc[.., w - samples], Cc channels | samples | zero pad), hypotheses pointing outside the image contribute zeros on the
+// right-feature side.  Cg = G * (channels per group); CTp >= G + 2 Cc + 1, a multiple of 4.
+extern "C" int stx_sampled_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc, const float* Rc,
+                                      int Cc, const float* samples, float* vol, int B, int H, int W, int S, int CTp,
+                                      void* stream) {
+    stx_begin();
+    STX_REQUIRE(samples && vol, "sampled_volume_fwd: null operand");
+    STX_REQUIRE(G == 0 || (Lg && Rg && Cg > 0 && Cg % G == 0), "sampled_volume_fwd: %d channels are not divisible into %d groups", Cg, G);
+    STX_REQUIRE(Cc == 0 || (Lc && Rc), "sampled_volume_fwd: null concat features");
+    SvArgs a{};
+    a.Lg = Lg; a.Rg = Rg; a.Lc = Lc; a.Rc = Rc; a.samples = samples; a.vol = vol;
+    a.B = B; a.H = H; a.W = W; a.S = S; a.G = G; a.cpg = G ? Cg / G : 0; a.Cc = Cc; a.CT = G + 2 * Cc + 1; a.CTp = CTp;
+    if (int rc = sv_check(a, "sampled_volume_fwd")) return rc;
+    const size_t lds = (size_t)SV_TW * (CTp + 1) * 4;
+    STX_REQUIRE(lds <= 64 * 1024, "sampled_volume_fwd: %d channels exceed the LDS tile", CTp);
+    hipLaunchKernelGGL(sampled_volume_fwd_kernel, dim3(stx_cdiv(W, SV_TW), H, B * S), dim3(SV_THREADS), lds,
+                       (hipStream_t)stream, a);
+    return stx_check_launch("sampled_volume_fwd");
+}
+
+// Gradients of the above w.r.t. the four feature maps (the samples are integer hypotheses: no gradient).  gRg / gRc are
+// accumulated with atomics and are zeroed here first.
+extern "C" int stx_sampled_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc,
+                                      const float* samples, float* gLg, float* gRg, float* gLc, float* gRc, int B, int H,
+                                      int W, int S, int CTp, void* stream) {
+    stx_begin();
+    STX_REQUIRE(gvol && samples, "sampled_volume_bwd: null operand");
+    STX_REQUIRE(G == 0 || (Lg && Rg && gLg && gRg && Cg > 0 && Cg % G == 0), "sampled_volume_bwd: bad group features");
+    STX_REQUIRE(Cc == 0 || (gLc && gRc), "sampled_volume_bwd: null concat gradients");
+    SvArgs a{};
+    a.Lg = Lg; a.Rg = Rg; a.samples = samples; a.gvol = gvol; a.gLg = gLg; a.gRg = gRg; a.gLc = gLc; a.gRc = gRc;
+    a.B = B; a.H = H; a.W = W; a.S = S; a.G = G; a.cpg = G ? Cg / G : 0; a.Cc = Cc; a.CT = G + 2 * Cc + 1; a.CTp = CTp;
+    if (int rc = sv_check(a, "sampled_volume_bwd")) return rc;
+    STX_REQUIRE(G <= 4 * SV_MAXGPW && Cc <= 16, "sampled_volume_bwd: G = %d / Cc = %d exceed the kernel's register tiles", G, Cc);
+    STX_REQUIRE(G == 0 || a.cpg == 4 || a.cpg == 8, "sampled_volume_bwd: %d channels per group unsupported (4 or 8)", a.cpg);
+    const size_t lds = (size_t)SV_TW * (CTp + 1) * 4;
+    STX_REQUIRE(lds <= 64 * 1024, "sampled_volume_bwd: %d channels exceed the LDS tile", CTp);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W;
+    if (G && hipMemsetAsync(gRg, 0, (size_t)B * Cg * HW * 4, st) != hipSuccess) return stx_set_error(STX_ERR_LAUNCH, "sampled_volume_bwd: memset");
+    if (Cc && hipMemsetAsync(gRc, 0, (size_t)B * Cc * HW * 4, st) != hipSuccess) return stx_set_error(STX_ERR_LAUNCH, "sampled_volume_bwd: memset");
+    dim3 grid(stx_cdiv(W, SV_TW), H, B);
+    if (a.cpg == 8)
+        hipLaunchKernelGGL(sampled_volume_bwd_kernel<8>, grid, dim3(SV_THREADS), lds, st, a);
+    else
+        hipLaunchKernelGGL(sampled_volume_bwd_kernel<4>, grid, dim3(SV_THREADS), lds, st, a);
+    return stx_check_launch("sampled_volume_bwd");
+}

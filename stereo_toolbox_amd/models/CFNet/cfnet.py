@@ -212,9 +212,9 @@ class cfnet(nn.Module):
         samples = self.generate_disparity_samples(lo1, hi1, count).float()
         if self.forced_samples is not None:
             samples = self.forced_samples[0 if k == 3 else 1].to(samples)
-        v_cat, _ = self.cost_volume_generator(fl[f"concat_feature{k}"], fr[f"concat_feature{k}"], samples, "concat")
-        v_gwc, s5 = self.cost_volume_generator(fl[f"gw{k}"], fr[f"gw{k}"], samples, "gwc", groups)
-        vol = ops.to_ndhwc(torch.cat((v_gwc, v_cat, s5), dim=1))
+        # gather + group-wise correlation + concat + hypothesis channel in one kernel (stx_sampled_volume_fwd); the
+        # torch-op restatement of the reference's chain stays available as `cost_volume_generator` (API parity)
+        vol = ops.sampled_volume(fl[f"gw{k}"], fr[f"gw{k}"], fl.get(f"concat_feature{k}"), fr.get(f"concat_feature{k}"), samples, groups)
         cost0 = _run_dres(vol, d0, d1)
         out1 = hg2(cost0)
         out2 = hg3(out1)

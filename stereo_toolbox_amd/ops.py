@@ -166,6 +166,15 @@ def pad_input_channels(x, w):
     return _pad_channels(x, Cp), wp
 
 
+def pad_weight_channels(w, Cp):
+    """Zero-pad dim 1 (input channels) of a conv weight [Cout, Cin, k, k, k] to Cp."""
+    if w.shape[1] == Cp:
+        return w
+    wp = w.new_zeros(w.shape[0], Cp, *w.shape[2:])
+    wp[:, : w.shape[1]] = w
+    return wp
+
+
 # --------------------------------------------------------------------------------------- raw convs
 def conv_out_dims(D, H, W, ks, stride):
     pad = ks // 2
@@ -270,7 +279,15 @@ class ConvRawFn(torch.autograd.Function):
     def forward(ctx, x, w, ks, stride, transposed, want_stats):
         _chk(x, "x", 5)
         ctx.cin_true = None
-        if not transposed and x.shape[-1] % 8 != 0:
+        ctx.x_prepadded = False
+        if not transposed and x.shape[-1] != w.shape[1]:
+            # an activation that already carries zero pad channels up to the GEMM-K step (ops.sampled_volume): pad the
+            # weight only; the pad channels' input gradient is returned (and ignored by the producer)
+            if x.shape[-1] != (w.shape[1] + 7) // 8 * 8:
+                raise StxError(f"conv: input has {x.shape[-1]} channels, weight expects {w.shape[1]}")
+            ctx.cin_true, ctx.x_prepadded = w.shape[1], True
+            w = pad_weight_channels(w, x.shape[-1])
+        elif not transposed and x.shape[-1] % 8 != 0:
             # GEMM-K (input channels) in steps of 8: zero-pad odd widths (CFNet's 65- and 33-channel cascade volumes)
             ctx.cin_true = x.shape[-1]
             x, w = pad_input_channels(x, w)
@@ -337,7 +354,7 @@ class ConvRawFn(torch.autograd.Function):
                     x_w = x if Ci % 32 == 0 else _pad_channels(x, (Ci + 31) // 32 * 32)
                     gw = conv3d_wgrad(x_w, gz_w, ks, stride)[:Co, :Ci].reshape(w.shape)
         if ctx.cin_true is not None:
-            if gx is not None:
+            if gx is not None and not ctx.x_prepadded:
                 gx = gx[..., :ctx.cin_true].contiguous()
             if gw is not None:
                 gw = gw[:, :ctx.cin_true].contiguous()
@@ -538,6 +555,59 @@ def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         return CostVolumeFn.apply(*ts, maxdisp, num_groups, mask_left)
     return cost_volume_forward(*ts, maxdisp, num_groups, mask_left)
+
+
+class SampledVolumeFn(torch.autograd.Function):
+    """CFNet cascade-stage volume (stx_sampled_volume_fwd / _bwd): NDHWC [B, S, H, W, CTp], channels = G group
+    correlations | Cc left concat | Cc warped right concat | the hypothesis itself | zero pad to a multiple of 8."""
+
+    @staticmethod
+    def forward(ctx, Lg, Rg, Lc, Rc, samples, num_groups):
+        B, H, W, Cg, G, Cc = _cv_shapes(Lg, Lc, num_groups)
+        S = samples.shape[1]
+        CTp = (G + 2 * Cc + 1 + 7) // 8 * 8
+        vol = torch.empty(B, S, H, W, CTp, dtype=torch.float32, device=samples.device)
+        _call("stx_sampled_volume_fwd", _p(Lg), _p(Rg), Cg, G, _p(Lc), _p(Rc), Cc, _p(samples), _p(vol), B, H, W, S, CTp)
+        ctx.save_for_backward(Lg, Rg, samples)
+        ctx.cfg = (G, Cg, Cc, None if Lc is None else Lc.shape)
+        return vol
+
+    @staticmethod
+    def backward(ctx, gvol):
+        Lg, Rg, samples = ctx.saved_tensors
+        G, Cg, Cc, cshape = ctx.cfg
+        gvol = gvol.contiguous()
+        B, S, H, W, CTp = gvol.shape
+        gLg = torch.empty_like(Lg) if G else None
+        gRg = torch.empty_like(Rg) if G else None
+        gLc = gvol.new_empty(cshape) if Cc else None
+        gRc = gvol.new_empty(cshape) if Cc else None
+        _call("stx_sampled_volume_bwd", _p(gvol), _p(Lg), _p(Rg), Cg, G, Cc, _p(samples), _p(gLg), _p(gRg), _p(gLc),
+              _p(gRc), B, H, W, S, CTp)
+        return gLg, gRg, gLc, gRc, None, None
+
+
+def sampled_volume(Lg, Rg, Lc, Rc, samples, num_groups):
+    """Cascade-stage cost volume from per-pixel disparity hypotheses `samples` [B, S, H, W] (integer-valued floats, no
+    gradient): see include/stx_hip.h.  The channel axis is padded with zeros to a multiple of 8; `conv_block` accepts
+    such a volume for a convolution whose weight has the un-padded input width."""
+    ts = [t.contiguous() if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    for n, t in (("ref gwc", ts[0]), ("tgt gwc", ts[1]), ("ref concat", ts[2]), ("tgt concat", ts[3])):
+        _chk(t, n, 4)
+    samples = samples.detach().contiguous()
+    _chk(samples, "samples", 4)
+    if ts[0] is not None:
+        assert ts[0].shape[1] % num_groups == 0   # reference models/CFNet/submodule.py:165
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        return SampledVolumeFn.apply(*ts, samples, num_groups)
+    return SampledVolumeFn.forward(_NoCtx(), *ts, samples, num_groups)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when a Function's forward is used without a graph."""
+
+    def save_for_backward(self, *a):
+        pass
 
 
 class AcVolumeFn(torch.autograd.Function):

@@ -542,6 +542,51 @@ def test_ac_volume_backward(be):
     _close(gR, Rc.grad, rtol=1e-5)
 
 
+# ------------------------------------------------------------------------------ CFNet sampled (cascade) volume
+@pytest.mark.parametrize("case", [(1, 40, 4, 12, 5, 70, 6), (2, 20, 4, 6, 3, 33, 4), (1, 8, 8, 0, 2, 64, 3), (1, 0, 0, 8, 2, 20, 5)])
+def test_sampled_volume_fwd_bwd(be, case):
+    """stx_sampled_volume_fwd / _bwd against the oracle's restatement of SpatialTransformer + groupwise_correlation_4D +
+    cost_volume_generator + cat (CFNet/submodule.py:306-350, 163-169, cfnet.py:470-497, 560-566): CFNet's two stage
+    configurations (40 groups x 4 channels + 12 concat; 20 x 4 + 6), 8 channels per group, concat only; W = 70 / 33 leave
+    a ragged 64-column tile; hypotheses reach outside the image on both sides (clamped index, zeroed contribution)."""
+    B, G, cpg, Cc, H, W, S = case
+    torch.manual_seed(11)
+    Cg = G * cpg
+    Lg, Rg = (torch.randn(B, Cg, H, W).requires_grad_() if G else None for _ in range(2))
+    Lc, Rc = (torch.randn(B, Cc, H, W).requires_grad_() if Cc else None for _ in range(2))
+    samples = torch.randint(-4, W // 2, (B, S, H, W)).float()
+    parts = []
+    if G:
+        parts.append(O.cf_sampled_volume(Lg, Rg, samples, G))
+    if Cc:
+        parts.append(O.cf_sampled_volume(Lc, Rc, samples, None))
+    parts.append(samples.unsqueeze(1))
+    ref = torch.cat(parts, 1)                                   # [B, CT, S, H, W]
+    CT = ref.shape[1]
+    CTp = (CT + 7) // 8 * 8
+    dev = [be.dev(t.detach()) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    dsm = be.dev(samples)
+    vol = be.empty(B, S, H, W, CTp)
+    vol.fill_(7.0)
+    be.call("stx_sampled_volume_fwd", ptr(dev[0]), ptr(dev[1]), Cg, G, ptr(dev[2]), ptr(dev[3]), Cc, ptr(dsm), ptr(vol),
+            B, H, W, S, CTp)
+    got = vol.cpu()
+    _close(got[..., :CT].permute(0, 4, 1, 2, 3), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(got[..., CT:], torch.zeros(B, S, H, W, CTp - CT))
+    assert torch.equal(got[..., CT - 1], samples)
+    gv = torch.randn(B, S, H, W, CTp)
+    ref.backward(gv[..., :CT].permute(0, 4, 1, 2, 3))
+    outs = [be.empty(*t.shape) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    for o in outs:
+        if o is not None:
+            o.fill_(3.0)                                          # (the entry point zeroes the atomically accumulated ones)
+    be.call("stx_sampled_volume_bwd", ptr(be.dev(gv)), ptr(dev[0]), ptr(dev[1]), Cg, G, Cc, ptr(dsm), ptr(outs[0]),
+            ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), B, H, W, S, CTp)
+    for o, t in zip(outs, (Lg, Rg, Lc, Rc)):
+        if t is not None:
+            _close(o, t.grad, rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize("case", [(1500, 32), (300, 64), (100, 32), (257, 20)])
 def test_bn_finalize_many_rows(be, case):

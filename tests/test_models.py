@@ -713,3 +713,59 @@ def test_conv_block_autograd_layer_shapes(env, shape):
     if bn is not None:
         close(bn.weight.grad, gr.grad, "dgamma")
         close(bn.bias.grad, br.grad, "dbeta")
+
+
+@pytest.mark.parametrize("cfg", [(40, 4, 12, 32), (20, 4, 6, 16)], ids=["stage3_65ch", "stage2_33ch"])
+def test_sampled_volume_into_conv_autograd(env, cfg):
+    """CFNet cascade stage wiring (cfnet.py:553-571): ops.sampled_volume (zero-padded NDHWC volume from the HIP kernel) feeding
+    the stage's first conv block, whose weight has the un-padded 65 / 33 input channels -- forward, the four feature
+    gradients (left ones from registers, right ones from atomics) and the conv / BN parameter gradients against the
+    reference op chain (SpatialTransformer + groupwise_correlation_4D + cat + Conv3d + BatchNorm3d) in fp64."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from stereo_toolbox_amd import ops
+    from stereo_toolbox_amd.aggregation import conv_block
+    G, cpg, Cc, Cout = cfg
+    torch.manual_seed(G + Cc)
+    B, H, W, S = 1, 3, 20, 4
+    CT = G + 2 * Cc + 1
+    feats = [torch.randn(B, G * cpg, H, W), torch.randn(B, G * cpg, H, W), torch.randn(B, Cc, H, W), torch.randn(B, Cc, H, W)]
+    samples = torch.randint(-3, 12, (B, S, H, W)).float()
+    conv, bn = nn.Conv3d(CT, Cout, 3, 1, 1, bias=False), nn.BatchNorm3d(Cout)
+    with torch.no_grad():
+        conv.weight.mul_(3.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    # reference chain in fp64
+    fr = [t.double().requires_grad_() for t in feats]
+    wr = conv.weight.detach().double().requires_grad_()
+    gr, br = bn.weight.detach().double().requires_grad_(), bn.bias.detach().double().requires_grad_()
+    vol = torch.cat((O.cf_sampled_volume(fr[0], fr[1], samples.double(), G), O.cf_sampled_volume(fr[2], fr[3], samples.double(), None),
+                     samples.double().unsqueeze(1)), 1)
+    zr = F.relu(F.batch_norm(F.conv3d(vol, wr, None, 1, 1), None, None, gr, br, True, 0.1, bn.eps))
+    gy = torch.randn(zr.shape)
+    zr.backward(gy.double())
+    # product
+    conv, bn = conv.to(env.device).train(), bn.to(env.device).train()
+    fp = [t.to(env.device).requires_grad_() for t in feats]
+    with env.ctx():
+        v = ops.sampled_volume(fp[0], fp[1], fp[2], fp[3], samples.to(env.device), G)
+        assert v.shape == (B, S, H, W, (CT + 7) // 8 * 8)
+        y = conv_block(v, conv, bn, relu=True)
+        y.backward(gy.permute(0, 2, 3, 4, 1).contiguous().to(env.device))
+        with torch.no_grad():                                   # inference path with the pre-padded volume
+            conv.eval(); bn.eval()
+            y_inf = conv_block(ops.sampled_volume(fp[0], fp[1], fp[2], fp[3], samples.to(env.device), G), conv, bn, relu=True)
+    z_inf = F.relu(F.batch_norm(F.conv3d(vol.detach(), wr.detach(), None, 1, 1), bn.running_mean.cpu().double(),
+                                bn.running_var.cpu().double(), gr.detach(), br.detach(), False, 0.1, bn.eps))
+
+    def close(got, ref, what):
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= 2e-4 * ref.abs().max().item() + 1e-5, (what, err, ref.abs().max().item())
+    close(y.permute(0, 4, 1, 2, 3), zr.detach(), "out")
+    close(y_inf.permute(0, 4, 1, 2, 3), z_inf, "out (eval)")
+    for got, ref, what in zip(fp, fr, ("dLg", "dRg", "dLc", "dRc")):
+        close(got.grad, ref.grad, what)
+    close(conv.weight.grad, wr.grad, "dw")
+    close(bn.weight.grad, gr.grad, "dgamma")
+    close(bn.bias.grad, br.grad, "dbeta")

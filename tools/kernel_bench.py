@@ -98,6 +98,24 @@ def main():
         report("cost_volume_fwd_psm_concat", ms, nbytes=(Lp.numel() * 2 + vol.numel()) * 4)
         del Lg, Rg, vol, g
 
+    if want("sampled_volume"):
+        # CFNet cascade stage at 1/4 resolution: 40 groups x 4 channels + 12 concat channels, 16 hypotheses, 72-channel voxels
+        S, G, cpg, Cc, CTp = 16, 40, 4, 12, 72
+        Lg, Rg = torch.randn(B, G * cpg, H4, W4, device=dev), torch.randn(B, G * cpg, H4, W4, device=dev)
+        Lc, Rc = torch.randn(B, Cc, H4, W4, device=dev), torch.randn(B, Cc, H4, W4, device=dev)
+        base = torch.rand(B, 1, H4, W4, device=dev) * 30
+        smp = (base + torch.arange(S, device=dev).view(1, S, 1, 1)).floor()
+        vol = torch.empty(B, S, H4, W4, CTp, device=dev)
+        nb = (Lg.numel() * 2 + Lc.numel() * 2 + smp.numel() + vol.numel()) * 4
+        ms = timeit(lambda: lib.call("stx_sampled_volume_fwd", P(Lg), P(Rg), G * cpg, G, P(Lc), P(Rc), Cc, P(smp), P(vol),
+                                     B, H4, W4, S, CTp, stream()), it)
+        report("sampled_volume_fwd_cfnet_s3", ms, nbytes=nb)
+        g = [torch.empty_like(t) for t in (Lg, Rg, Lc, Rc)]
+        ms = timeit(lambda: lib.call("stx_sampled_volume_bwd", P(vol), P(Lg), P(Rg), G * cpg, G, Cc, P(smp), P(g[0]), P(g[1]),
+                                     P(g[2]), P(g[3]), B, H4, W4, S, CTp, stream()), it)
+        report("sampled_volume_bwd_cfnet_s3", ms, nbytes=nb + Lg.numel() * 8)
+        del Lg, Rg, vol, g
+
     convs = [  # name, level_in, Cin, Cout, ks, stride
         ("conv_64_32_L0", 0, 64, 32, 3, 1), ("conv_32_32_L0", 0, 32, 32, 3, 1), ("conv_32_64_s2_L0", 0, 32, 64, 3, 2),
         ("conv_64_64_L1", 1, 64, 64, 3, 1), ("conv_64_128_s2_L1", 1, 64, 128, 3, 2), ("conv_128_128_L2", 2, 128, 128, 3, 1),

@@ -59,15 +59,16 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_fwd_kernel(SvArgs a
     const int xi = sv_column(wc, sample, a.W, valid);
     float* mine = tile + wl * TS;
     if (a.G) {
-        const float* Lp = a.Lg + ((size_t)b * Cg * a.H + h) * a.W + wc;
-        const float* Rp = a.Rg + ((size_t)b * Cg * a.H + h) * a.W + xi;
+        // wave-uniform row bases + 32-bit lane offsets (one batch item's features are < 2^32 bytes: checked by the host)
+        const float* Lrow = a.Lg + ((size_t)b * Cg * a.H + h) * a.W;
+        const float* Rrow = a.Rg + ((size_t)b * Cg * a.H + h) * a.W;
         const float inv = 1.f / (float)a.cpg;
         for (int g = wave; g < a.G; g += 4) {
             float acc = 0.f;
 #pragma unroll 4
             for (int c = 0; c < a.cpg; ++c) {
-                const size_t o = (size_t)(g * a.cpg + c) * HW;
-                acc = fmaf(Lp[o], Rp[o], acc);
+                const unsigned o = (unsigned)(g * a.cpg + c) * (unsigned)HW;
+                acc = fmaf(Lrow[o + (unsigned)wc], Rrow[o + (unsigned)xi], acc);
             }
             mine[g] = valid ? acc * inv : 0.f;
         }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
 #pragma unroll
         for (int c = 0; c < CPG; ++c) gl[k][c] = 0.f;
     float glc[4] = {0.f, 0.f, 0.f, 0.f};                        // d/dLc of concat channels wave, wave+4, .. (Cc <= 16)
-    const float* Lp = a.G ? a.Lg + ((size_t)b * Cg * a.H + h) * a.W + wc : nullptr;
+    const size_t rowoff = ((size_t)b * Cg * a.H + h) * a.W;      // (wave-uniform; lane offsets below are 32-bit)
     for (int s = 0; s < a.S; ++s) {
         const int bs = b * a.S + s;
         __syncthreads();                                        // the previous sample's tile is no longer read
@@ -129,8 +130,9 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
         valid = valid && live;
         const float* mine = tile + wl * TS;
         if (a.G) {
-            const float* Rp = a.Rg + ((size_t)b * Cg * a.H + h) * a.W + xi;
-            float* gRp = a.gRg + ((size_t)b * Cg * a.H + h) * a.W + xi;
+            const float* Lrow = a.Lg + rowoff;
+            const float* Rrow = a.Rg + rowoff;
+            float* gRrow = a.gRg + rowoff;
 #pragma unroll
             for (int k = 0; k < SV_MAXGPW; ++k) {
                 const int g = wave + 4 * k;
@@ -138,11 +140,12 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
                     const float gv = mine[g] * inv;
 #pragma unroll
                     for (int c = 0; c < CPG; ++c) {
-                        const size_t o = (size_t)(g * CPG + c) * HW;
-                        gl[k][c] = fmaf(gv, Rp[o], gl[k][c]);
-                        atomicAdd(gRp + o, gv * Lp[o]);
+                        const unsigned o = (unsigned)(g * CPG + c) * (unsigned)HW;
+                        gl[k][c] = fmaf(gv, Rrow[o + (unsigned)xi], gl[k][c]);
+                        atomicAdd(gRrow + (o + (unsigned)xi), gv * Lrow[o + (unsigned)wc]);
                     }
                 }
+                STX_SCHED_BARRIER();       // one group's loads in flight at a time: all ten hoisted cost 440 VGPRs
             }
         }
 #pragma unroll
@@ -156,13 +159,13 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
     }
     if (!live) return;
     if (a.G) {
-        float* gLp = a.gLg + ((size_t)b * Cg * a.H + h) * a.W + w;
+        float* gLrow = a.gLg + rowoff;
 #pragma unroll
         for (int k = 0; k < SV_MAXGPW; ++k) {
             const int g = wave + 4 * k;
             if (g < a.G) {
 #pragma unroll
-                for (int c = 0; c < CPG; ++c) gLp[(size_t)(g * CPG + c) * HW] = gl[k][c];
+                for (int c = 0; c < CPG; ++c) gLrow[(unsigned)(g * CPG + c) * (unsigned)HW + (unsigned)w] = gl[k][c];
             }
         }
     }
@@ -178,6 +181,7 @@ int sv_check(const SvArgs& a, const char* who) {
     STX_REQUIRE(a.G >= 0 && a.Cc >= 0 && (a.G > 0 || a.Cc > 0), "%s: no channels", who);
     STX_REQUIRE(a.CTp >= a.CT && a.CTp % 4 == 0, "%s: padded channel count %d (need >= %d, multiple of 4)", who, a.CTp, a.CT);
     STX_REQUIRE((long long)a.B * a.S <= 65535 && a.H <= 65535, "%s: grid too large", who);
+    STX_REQUIRE((long long)a.G * a.cpg * a.H * a.W < (1ll << 30), "%s: feature maps of a batch item exceed 4 GiB", who);
     return STX_OK;
 }
 

@@ -303,7 +303,7 @@ extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double c
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
     stx_begin();
     STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
-    static const int v1 = getenv("STX_BN_FINALIZE_V1") ? 1 : 0;                      // A/B switch: first-generation kernel
+    const int v1 = getenv("STX_BN_FINALIZE_V1") ? 1 : 0;   // A/B switch (read per call): first-generation kernel
     if (C % 4 == 0 && nrows >= 256 && !v1)
         hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(BN_FIN_THREADS), 0, (hipStream_t)stream, partials, nrows, C,
                            count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);

@@ -1361,7 +1361,7 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     // 32 x 32 channel slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums
     // and applies the epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).  STX_MARCH_V2=0: first generation.
     static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
-    static const int v2_6464 = getenv("STX_MARCH_6464") ? atoi(getenv("STX_MARCH_6464")) : 0;   // tuning: 64 -> 64 as 2 x 2 slices
+    const int v2_6464 = getenv("STX_MARCH_6464") ? atoi(getenv("STX_MARCH_6464")) : 0;   // tuning (read per call): 64 -> 64 as 2 x 2 slices
     if (v2_env && ks == 3 && stride == 1 &&
         ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32) || (v2_6464 && Cin == 64 && Cout <= 64))) {
         MarchArgs m2;
@@ -1573,7 +1573,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     int rc = stx_check_launch("conv3d_wgrad");
     if (rc) return rc;
     const int total = npairs * T * 1024;
-    static const int red_v1 = getenv("STX_WGRAD_REDUCE_V1") ? 1 : 0;          // A/B switch: first-generation slab reduction
+    const int red_v1 = getenv("STX_WGRAD_REDUCE_V1") ? 1 : 0;   // A/B switch (read per call): first-generation slab reduction
     if (red_v1)
         hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st,
                            workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);   // KS=1 producer uses 4 waves

@@ -62,8 +62,23 @@ def pack(w, mode):
     return wp
 
 
+# A/B switches that libstx_hip.so reads on every call (not cached in statics): they can be flipped inside one process, so
+# a whole comparison costs one interpreter start.  (label, kernel filter, environment)
+AB_SETS = [
+    ("head: first generation", "head", {"STX_HEAD_V1": "1"}),
+    ("bn_finalize: first generation", "bn_finalize", {"STX_BN_FINALIZE_V1": "1"}),
+    ("wgrad slab reduce: first generation", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad", {"STX_WGRAD_REDUCE_V1": "1"}),
+    ("cost volume bwd: first generation", "cost_volume_bwd", {"STX_CVB_OLD": "1"}),
+    ("cost volume bwd: run schedule", "cost_volume_bwd", {"STX_CVB_TEAM": "0"}),
+    ("cost volume bwd: team, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_NSET": "2"}),
+    ("cost volume bwd: team, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_NSET": "4"}),
+    ("64->64 L1 as 2 x 2 march slices", "conv_64_64_L1_fwd", {"STX_MARCH_6464": "1"}),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--ab", action="store_true", help="after the table: re-time the kernels of AB_SETS under their switch")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter(s) on kernel names, comma separated")
     ap.add_argument("--skip-wgrad", action="store_true")
@@ -71,14 +86,28 @@ def main():
     ap.add_argument("--W", type=int, default=960)
     ap.add_argument("--D", type=int, default=192)
     a = ap.parse_args()
+    run_table(a, a.only)
+    if a.ab:
+        for label, flt, env in AB_SETS:
+            print(json.dumps({"ab": label, "env": env}), flush=True)
+            os.environ.update(env)
+            try:
+                run_table(a, flt, only_exact=True)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+
+
+def run_table(a, only_arg, only_exact=False):
     B, H4, W4, D4 = 1, a.H // 4, a.W // 4, a.D // 4
     L = {0: (D4, H4, W4), 1: (D4 // 2, H4 // 2, W4 // 2), 2: (D4 // 4, H4 // 4, W4 // 4)}
     it = a.iters
 
-    only = [t for t in a.only.split(",") if t]
+    only = [t for t in only_arg.split(",") if t]
 
     def want(n):
-        return not only or any(t in n for t in only)
+        # a section asks with its prefix ("cost_volume", "head") or a full kernel name; a filter matches either way
+        return not only or any(t in n or (only_exact and n in t) for t in only)
 
     if want("cost_volume"):
         Lg, Rg = torch.randn(B, 320, H4, W4, device=dev), torch.randn(B, 320, H4, W4, device=dev)

@@ -490,7 +490,9 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     if ((long long)D * H * W * CT * 4 >= (1ll << 31) || (long long)Cg * H * W * 4 >= (1ll << 31)) return -1;
     a.macros = (int)macros;
     // team schedule (see above): one row team per XCD
-    const int team_env = getenv("STX_CVB_TEAM") ? atoi(getenv("STX_CVB_TEAM")) : 1;
+    // (GPU call O, 576x960: run schedule 0.201 ms, team schedule 0.207-0.222 ms depending on the prefetch depth, first
+    // generation 0.303 ms: the team schedule halves the HBM reads but its lock-step costs more than that saves -> opt-in)
+    const int team_env = getenv("STX_CVB_TEAM") ? atoi(getenv("STX_CVB_TEAM")) : 0;
     a.nteams = 8;
     a.team = (team_env && 2 * a.nt > 16 && 2 * a.nt <= 32 && nch == 6 && B * H >= a.nteams && !getenv("STX_CVB_GRID")) ? 1 : 0;
     const size_t lds = ((size_t)2 * (CVB2_DC * cvb_pitch(G) + G) + (size_t)CVB2_RING * (Cg + 4)) * 4;

@@ -433,6 +433,61 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_gather2_kernel(
     gcost[(((size_t)b * Dc + dc) * Hc + hc) * Wc + wc] = acc;
 }
 
+// Third generation of the gather (GPU call O: the branch-free kernel above is SLOWER than the first version, 0.30 vs
+// 0.22 ms for the whole backward: its 144 dword loads per cell have a lane stride of 16 bytes, i.e. 16 texture-addresser
+// cycles each).  A cell's candidate pixels in a row are contiguous, and neighbouring cells' windows start `1/scale`
+// pixels apart -- with the window start rounded down to a multiple of 4 pixels every lane reads whole float4s and, at the
+// usual scale of 1/4, the wave's float4s of one load instruction are CONTIGUOUS (1 KiB per instruction).  16 pixels per
+// row from the aligned start cover every footprint up to 13 pixels; hd_weight is zero for pixels that do not touch the
+// cell, so no footprint bookkeeping is needed.  Requires W % 4 == 0 (16-byte aligned rows).
+template <bool AC>
+__global__ __launch_bounds__(HD_THREADS) void head_bwd_gather4_kernel(
+    const float* __restrict__ gpix, float* __restrict__ gcost, int Dc, int Hc, int Wc, int H, int W, int fh) {
+    const int wc = blockIdx.x * HD_THREADS + threadIdx.x;
+    const int hc = blockIdx.y % Hc, dc = blockIdx.y / Hc, b = blockIdx.z;
+    if (wc >= Wc) return;
+    const float rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
+    int h_lo, w_lo;
+    if (AC) {
+        h_lo = rh > 0.f ? (int)(((float)hc - 1.f) / rh) - 1 : 0;
+        w_lo = rw > 0.f ? (int)(((float)wc - 1.f) / rw) - 1 : 0;
+    } else {
+        h_lo = (int)(((float)hc - 1.f + 0.5f) / rh - 0.5f) - 1;
+        w_lo = (int)(((float)wc - 1.f + 0.5f) / rw - 0.5f) - 1;
+    }
+    h_lo = h_lo < 0 ? 0 : h_lo;
+    w_lo = w_lo < 0 ? 0 : w_lo;
+    const int a_lo = w_lo & ~3;                                   // aligned window start: pixels a_lo .. a_lo + 15
+    float kw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) kw[j] = (a_lo + j < W) ? hd_weight<AC>(a_lo + j, rw, Wc, wc) : 0.f;
+    unsigned oq[4];                                               // the four float4s of a row (clamped into the row)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oq[q] = (unsigned)(a_lo + 4 * q < W ? a_lo + 4 * q : W - 4);
+    const float* gp = gpix + (((size_t)b * Dc + dc) * H) * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < HD_GF; ++i) {
+        const int hh = h_lo + i;
+        const float kh = (i < fh && hh < H) ? hd_weight<AC>(hh, rh, Hc, hc) : 0.f;   // (uniform over the workgroup)
+        const float* rowp = gp + (size_t)(hh < H ? hh : H - 1) * W;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = stx_ld4(rowp + oq[q]);
+        float row = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            row = fmaf(kw[4 * q + 0], v[q].x, row);
+            row = fmaf(kw[4 * q + 1], v[q].y, row);
+            row = fmaf(kw[4 * q + 2], v[q].z, row);
+            row = fmaf(kw[4 * q + 3], v[q].w, row);
+        }
+        acc = fmaf(kh, row, acc);
+        if ((i & 3) == 3) STX_SCHED_BARRIER();                   // 16 float4 loads in flight (all 48: 221 VGPRs)
+    }
+    gcost[(((size_t)b * Dc + dc) * Hc + hc) * Wc + wc] = acc;
+}
+
 // disp[b,h,w] = sum_d d * x[b,d,h,w]
 __global__ __launch_bounds__(HD_THREADS) void softargmax_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                  int D, int HW) {
@@ -503,10 +558,11 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 
 }  // namespace
 
-// LDS-staged per-pixel kernels when their tables fit comfortably (two workgroups per CU); STX_HEAD_V1 = first generation
-static bool hd_use_lds(size_t lds) {
-    const int v1 = getenv("STX_HEAD_V1") ? 1 : 0;                  // (read per call: tests switch generations)
-    return !v1 && lds <= 80 * 1024;
+// LDS-staged per-pixel kernels when their tables fit comfortably (two workgroups per CU).  STX_HEAD_V1 = bit mask of the
+// kernels to run in their first generation: 1 forward, 2 backward per-pixel pass, 4 backward gather (7 = all)
+static int hd_v1_mask() { const char* e = getenv("STX_HEAD_V1"); return e ? atoi(e) : 0; }   // (read per call: tests switch generations)
+static bool hd_use_lds(size_t lds, int bit) {
+    return !(hd_v1_mask() & bit) && lds <= 80 * 1024;
 }
 
 template <bool AC>
@@ -515,7 +571,7 @@ static int head_fwd_launch(const float* cost, float* disp, float* stats, int B, 
     STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
     dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
     const size_t lds = hd_lds_bytes(Dc, D);
-    if (hd_use_lds(lds)) {
+    if (hd_use_lds(lds, 1)) {
         if (lds > 64 * 1024)
             hipFuncSetAttribute((const void*)head_fwd_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(head_fwd_lds_kernel<AC>, grid, dim3(HD_THREADS), lds, (hipStream_t)stream, cost, disp, stats,
@@ -549,7 +605,7 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
     STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = hd_lds_bytes(Dc, D);
-    if (hd_use_lds(lds)) {
+    if (hd_use_lds(lds, 2)) {
         if (lds > 64 * 1024)
             hipFuncSetAttribute((const void*)head_bwd_pix_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
@@ -570,7 +626,11 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
         fh = 2 * stx_cdiv(H, Hc) + 3;
         fw = 2 * stx_cdiv(W, Wc) + 3;
     }
-    if (fh <= HD_GF && fw <= HD_GF && !getenv("STX_HEAD_V1"))
+    const int gsel = getenv("STX_HEAD_GATHER") ? atoi(getenv("STX_HEAD_GATHER")) : 4;      // A/B: 2 = second generation
+    if (fh <= HD_GF && fw <= 13 && W % 4 == 0 && W >= 16 && gsel == 4 && !(hd_v1_mask() & 4))
+        hipLaunchKernelGGL(head_bwd_gather4_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
+                           workspace, gcost, Dc, Hc, Wc, H, W, fh);
+    else if (fh <= HD_GF && fw <= HD_GF && !(hd_v1_mask() & 4))
         hipLaunchKernelGGL(head_bwd_gather2_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
                            workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);
     else

@@ -65,13 +65,19 @@ def pack(w, mode):
 # A/B switches that libstx_hip.so reads on every call (not cached in statics): they can be flipped inside one process, so
 # a whole comparison costs one interpreter start.  (label, kernel filter, environment)
 AB_SETS = [
-    ("head: first generation", "head", {"STX_HEAD_V1": "1"}),
+    ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
+    ("head: first-generation backward per-pixel pass only", "head", {"STX_HEAD_V1": "2"}),
+    ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),
+    ("head: second-generation backward gather (dword loads)", "head", {"STX_HEAD_GATHER": "2"}),
     ("bn_finalize: first generation", "bn_finalize", {"STX_BN_FINALIZE_V1": "1"}),
     ("wgrad slab reduce: first generation", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad", {"STX_WGRAD_REDUCE_V1": "1"}),
     ("cost volume bwd: first generation", "cost_volume_bwd", {"STX_CVB_OLD": "1"}),
     ("cost volume bwd: run schedule", "cost_volume_bwd", {"STX_CVB_TEAM": "0"}),
-    ("cost volume bwd: team, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_NSET": "2"}),
-    ("cost volume bwd: team, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_NSET": "4"}),
+    ("cost volume bwd: team, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "2"}),
+    ("cost volume bwd: team, 3 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "3"}),
+    ("cost volume bwd: team, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "4"}),
+    ("cost volume bwd: run schedule, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "0", "STX_CVB_NSET": "2"}),
+    ("cost volume bwd: run schedule, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "0", "STX_CVB_NSET": "4"}),
     ("64->64 L1 as 2 x 2 march slices", "conv_64_64_L1_fwd", {"STX_MARCH_6464": "1"}),
 ]
 

@@ -560,7 +560,10 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 
 // LDS-staged per-pixel kernels when their tables fit comfortably (two workgroups per CU).  STX_HEAD_V1 = bit mask of the
 // kernels to run in their first generation: 1 forward, 2 backward per-pixel pass, 4 backward gather (7 = all)
-static int hd_v1_mask() { const char* e = getenv("STX_HEAD_V1"); return e ? atoi(e) : 0; }   // (read per call: tests switch generations)
+// Default 2 (GPU call P, 576x960 D=192, kernel trace): forward 95.4 -> 76.7 us with the LDS kernel, but the backward
+// per-pixel pass is SLOWER with it (93.1 -> 102.7 us: 50 KB of LDS per workgroup leave 3 waves per SIMD where the first
+// version runs 8, and its walk is issue-bound either way); gather 132.3 -> 62.9 us (third generation).
+static int hd_v1_mask() { const char* e = getenv("STX_HEAD_V1"); return e ? atoi(e) : 2; }   // (read per call: tests switch generations)
 static bool hd_use_lds(size_t lds, int bit) {
     return !(hd_v1_mask() & bit) && lds <= 80 * 1024;
 }

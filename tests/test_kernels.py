@@ -191,10 +191,7 @@ def test_head2_fwd_bwd(be, case, ac, gen, monkeypatch):
     generations (LDS-staged tables / first version); W = 300 spans two workgroups with a ragged tail, D < Dc leaves
     coarse planes without an output disparity, gain 3000 has cost steps far beyond the exp range (the LDS kernel's
     bound-shifted sum underflows and it must redo the walk with the exact maximum)."""
-    if gen == "v1":
-        monkeypatch.setenv("STX_HEAD_V1", "7")
-    else:
-        monkeypatch.delenv("STX_HEAD_V1", raising=False)
+    monkeypatch.setenv("STX_HEAD_V1", "7" if gen == "v1" else "0")      # (the product default mixes generations: see head.hip)
     B, Dc, Hc, Wc, D, H, W, gain = case
     torch.manual_seed(3)
     cost = (torch.randn(B, 1, Dc, Hc, Wc) * gain).requires_grad_()
@@ -210,7 +207,10 @@ def test_head2_fwd_bwd(be, case, ac, gen, monkeypatch):
     gc = be.empty(B, 1, Dc, Hc, Wc)
     ws = be.empty(be.raw("stx_head_bwd_workspace_floats")(B, Dc, H, W))
     be.call("stx_head_bwd2", ptr(be.dev(g)), ptr(dcost), ptr(disp), ptr(stats), ptr(gc), ptr(ws), B, Dc, Hc, Wc, D, H, W, ac)
-    _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
+    if gain <= 5:
+        _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
+    else:                                   # (same fast-exp effect on the probabilities: 1e-4 of the gradient's scale on gfx950)
+        _close(gc, cost.grad, rtol=3e-4, atol=1e-4)
 
 
 def test_estimators(be):

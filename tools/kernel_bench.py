@@ -66,7 +66,7 @@ def pack(w, mode):
 # a whole comparison costs one interpreter start.  (label, kernel filter, environment)
 AB_SETS = [
     ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
-    ("head: first-generation backward per-pixel pass only", "head", {"STX_HEAD_V1": "2"}),
+    ("head: LDS-staged kernels everywhere (backward per-pixel pass too)", "head", {"STX_HEAD_V1": "0"}),
     ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),
     ("head: second-generation backward gather (dword loads)", "head", {"STX_HEAD_GATHER": "2"}),
     ("bn_finalize: first generation", "bn_finalize", {"STX_BN_FINALIZE_V1": "1"}),

@@ -857,7 +857,72 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
 // A workgroup owns TWO rows of 32 input columns; each row is shared by two waves that split the 8
 // classes 13/14 taps ({111,100,010,000} / {011,101,110,001}); accumulators of a wave's four
 // classes persist over the K-chunks so the input tile is staged once per chunk.
-template <int NT, int CK>
+// The (class, tap) work list of one wave set, enumerated at compile time: 13 entries for the classes {111,100,010,000},
+// 14 for {011,101,110,001}.  slot = accumulator set of the class, tap = weight tap, (dd, dh, dw) = input offset.
+struct DcEntries { int n; int slot[14], tap[14], dd[14], dh[14], dw[14]; };
+constexpr DcEntries dc_entries(int cset) {
+    DcEntries e{};
+    const int tab[2][4] = {{7, 4, 2, 0}, {3, 5, 6, 1}};
+    int n = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int cls = tab[cset][c];
+        const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
+        for (int sd = 0; sd <= pd; ++sd)
+            for (int sh = 0; sh <= ph; ++sh)
+                for (int sw = 0; sw <= pw; ++sw) {
+                    // parity 0: (k=1, delta=0); parity 1: s=0 -> (k=0, delta=1), s=1 -> (k=2, delta=0)
+                    const int kd = pd ? (sd ? 2 : 0) : 1, kh = ph ? (sh ? 2 : 0) : 1, kw = pw ? (sw ? 2 : 0) : 1;
+                    e.slot[n] = c;
+                    e.tap[n] = (kd * 3 + kh) * 3 + kw;
+                    e.dd[n] = pd ? (sd ? 0 : 1) : 0;
+                    e.dh[n] = ph ? (sh ? 0 : 1) : 0;
+                    e.dw[n] = pw ? (sw ? 0 : 1) : 0;
+                    ++n;
+                }
+    }
+    e.n = n;
+    return e;
+}
+
+// One K chunk of the transposed convolution for a wave: the work list above as straight-line code, the weight operands
+// of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The loop nest in the
+// kernel below has run-time bounds; hipcc keeps it rolled and waits for each tap's loads right before its first MFMA:
+// an L2 round trip per 16 MFMAs -- GPU call O: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes.)
+template <int CSET, int NT, int CK>
+__device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
+    constexpr DcEntries E = dc_entries(CSET);
+    constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8;
+    float4 bv[2][QS][NT];
+    auto load_b = [&](int t, int buf) {
+        const float* wtap = wq + (size_t)E.tap[t] * NQ * NT * 256;
+#pragma unroll
+        for (int q = 0; q < QS; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[buf][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+    };
+    load_b(0, 0);
+#pragma unroll
+    for (int t = 0; t < E.n; ++t) {
+        if (t + 1 < E.n) load_b(t + 1, (t + 1) & 1);
+        STX_SCHED_BARRIER();
+        const int toff = ((E.dd[t] * EH + E.dh[t]) * EW + E.dw[t]) * VS;
+#pragma unroll
+        for (int q = 0; q < QS; ++q) {
+            const float4 av = stx_ld4(atile + toff + q * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 b = bv[t & 1][q][nt];
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
+            }
+        }
+        STX_SCHED_BARRIER();
+    }
+}
+
+template <int NT, int CK, bool PIPE>
 __global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a) {
     constexpr int TH = 2;
     constexpr int ED = 2, EH = TH + 1, EW = 33;
@@ -895,6 +960,11 @@ __global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a
         }
         __syncthreads();
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
+        if (PIPE) {
+            if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
+            else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int cls = cls_tab[cset][c];
@@ -1479,8 +1549,11 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     size_t lds = (size_t)2 * 3 * 33 * 36 * 4;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (NT == 1) rc = launch_with_lds(deconv3d_igemm_kernel<1, 32>, grid, lds, st, a);
-    else rc = launch_with_lds(deconv3d_igemm_kernel<2, 32>, grid, lds, st, a);
+    const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;   // A/B (read per call): 0 = rolled tap loops
+    if (NT == 1) rc = pipe ? launch_with_lds(deconv3d_igemm_kernel<1, 32, true>, grid, lds, st, a)
+                           : launch_with_lds(deconv3d_igemm_kernel<1, 32, false>, grid, lds, st, a);
+    else rc = pipe ? launch_with_lds(deconv3d_igemm_kernel<2, 32, true>, grid, lds, st, a)
+                   : launch_with_lds(deconv3d_igemm_kernel<2, 32, false>, grid, lds, st, a);
     if (rc) return rc;
     return stx_check_launch("deconv3d_fwd");
 }

@@ -65,6 +65,7 @@ def pack(w, mode):
 # A/B switches that libstx_hip.so reads on every call (not cached in statics): they can be flipped inside one process, so
 # a whole comparison costs one interpreter start.  (label, kernel filter, environment)
 AB_SETS = [
+    ("transposed conv: rolled tap loops (first generation)", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "0"}),
     ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
     ("head: LDS-staged kernels everywhere (backward per-pixel pass too)", "head", {"STX_HEAD_V1": "0"}),
     ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),

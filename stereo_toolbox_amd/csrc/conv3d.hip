@@ -888,11 +888,11 @@ constexpr DcEntries dc_entries(int cset) {
 // of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The loop nest in the
 // kernel below has run-time bounds; hipcc keeps it rolled and waits for each tap's loads right before its first MFMA:
 // an L2 round trip per 16 MFMAs -- GPU call O: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes.)
-template <int CSET, int NT, int CK>
+template <int CSET, int NT, int CK, bool APRE>
 __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
     constexpr DcEntries E = dc_entries(CSET);
     constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8;
-    float4 bv[2][QS][NT];
+    float4 bv[2][QS][NT], av[2][QS];
     auto load_b = [&](int t, int buf) {
         const float* wtap = wq + (size_t)E.tap[t] * NQ * NT * 256;
 #pragma unroll
@@ -900,30 +900,41 @@ __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const floa
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[buf][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
     };
-    load_b(0, 0);
-#pragma unroll
-    for (int t = 0; t < E.n; ++t) {
-        if (t + 1 < E.n) load_b(t + 1, (t + 1) & 1);
-        STX_SCHED_BARRIER();
+    auto load_a = [&](int t, int buf) {
         const int toff = ((E.dd[t] * EH + E.dh[t]) * EW + E.dw[t]) * VS;
 #pragma unroll
+        for (int q = 0; q < QS; ++q) av[buf][q] = stx_ld4(atile + toff + q * 8);
+    };
+    load_b(0, 0);
+    if (APRE) load_a(0, 0);
+#pragma unroll
+    for (int t = 0; t < E.n; ++t) {
+        if (t + 1 < E.n) {
+            load_b(t + 1, (t + 1) & 1);
+            if (APRE) load_a(t + 1, (t + 1) & 1);              // (APRE: the LDS operands one entry ahead as well)
+        }
+        STX_SCHED_BARRIER();
+        if (!APRE) load_a(t, t & 1);
+#pragma unroll
         for (int q = 0; q < QS; ++q) {
-            const float4 av = stx_ld4(atile + toff + q * 8);
+            const float4 a4 = av[t & 1][q];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float4 b = bv[t & 1][q][nt];
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
             }
         }
         STX_SCHED_BARRIER();
     }
 }
 
-template <int NT, int CK, bool PIPE>
-__global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a) {
+// PIPE: 0 = rolled tap loops (first generation), 1 = straight-line tap list with the weights one entry ahead,
+// 2 = LDS operands one entry ahead as well
+template <int NT, int CK, int PIPE>
+__global__ __launch_bounds__(CONV_THREADS, 2) void deconv3d_igemm_kernel(ConvArgs a) {
     constexpr int TH = 2;
     constexpr int ED = 2, EH = TH + 1, EW = 33;
     constexpr int VS = CK + 4, NF4 = CK / 4;
@@ -961,8 +972,8 @@ __global__ __launch_bounds__(CONV_THREADS) void deconv3d_igemm_kernel(ConvArgs a
         __syncthreads();
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
         if (PIPE) {
-            if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
-            else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
+            if (cset == 0) deconv_chunk_taps<0, NT, CK, PIPE == 2>(tile + abase, wq, NQ, acc);
+            else deconv_chunk_taps<1, NT, CK, PIPE == 2>(tile + abase, wq, NQ, acc);
             continue;
         }
 #pragma unroll
@@ -1546,14 +1557,21 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     a.nDt = Di; a.nHt = stx_cdiv(Hi, 2); a.nWt = stx_cdiv(Wi, 32);
     const int NT = conv_nt(Cout);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
-    size_t lds = (size_t)2 * 3 * 33 * 36 * 4;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;   // A/B (read per call): 0 = rolled tap loops
-    if (NT == 1) rc = pipe ? launch_with_lds(deconv3d_igemm_kernel<1, 32, true>, grid, lds, st, a)
-                           : launch_with_lds(deconv3d_igemm_kernel<1, 32, false>, grid, lds, st, a);
-    else rc = pipe ? launch_with_lds(deconv3d_igemm_kernel<2, 32, true>, grid, lds, st, a)
-                   : launch_with_lds(deconv3d_igemm_kernel<2, 32, false>, grid, lds, st, a);
+    // A/B switches (read per call).  STX_DECONV_PIPE: 0 rolled tap loops / 1 weights one tap ahead / 2 LDS operands too;
+    // STX_DECONV_CK: K chunk (32 or 16 channels: 64 output channels with 32-channel chunks need 372 VGPRs = one wave
+    // per SIMD)
+    const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;
+    const int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 32;
+    const size_t lds = (size_t)2 * 3 * 33 * ((ck == 16 ? 16 : 32) + 4) * 4;
+#define DC_LAUNCH(NT_, CK_)                                                                        \
+    rc = pipe == 2   ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 2>, grid, lds, st, a)       \
+         : pipe == 1 ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 1>, grid, lds, st, a)       \
+                     : launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 0>, grid, lds, st, a)
+    if (NT == 1) { if (ck == 16) { DC_LAUNCH(1, 16); } else { DC_LAUNCH(1, 32); } }
+    else { if (ck == 16) { DC_LAUNCH(2, 16); } else { DC_LAUNCH(2, 32); } }
+#undef DC_LAUNCH
     if (rc) return rc;
     return stx_check_launch("deconv3d_fwd");
 }

@@ -934,7 +934,7 @@ __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const floa
 // PIPE: 0 = rolled tap loops (first generation), 1 = straight-line tap list with the weights one entry ahead,
 // 2 = LDS operands one entry ahead as well
 template <int NT, int CK, int PIPE>
-__global__ __launch_bounds__(CONV_THREADS, 2) void deconv3d_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_kernel(ConvArgs a) {
     constexpr int TH = 2;
     constexpr int ED = 2, EH = TH + 1, EW = 33;
     constexpr int VS = CK + 4, NF4 = CK / 4;
@@ -1563,14 +1563,17 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     // STX_DECONV_CK: K chunk (32 or 16 channels: 64 output channels with 32-channel chunks need 372 VGPRs = one wave
     // per SIMD)
     const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;
-    const int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 32;
-    const size_t lds = (size_t)2 * 3 * 33 * ((ck == 16 ? 16 : 32) + 4) * 4;
+    // (GPU call S, 576x960: 128->64 0.223 ms with 372 VGPRs and 32-channel chunks -> 0.168 ms with the occupancy hint
+    //  -> 0.143 ms with 16-channel chunks (15.8 KB of LDS: four workgroups per CU); 64->32 0.327 -> 0.289 -> 0.254 ms)
+    int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 16;
+    if (ck != 8 && ck != 16 && ck != 32) ck = 16;
+    const size_t lds = (size_t)2 * 3 * 33 * (ck + 4) * 4;
 #define DC_LAUNCH(NT_, CK_)                                                                        \
     rc = pipe == 2   ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 2>, grid, lds, st, a)       \
          : pipe == 1 ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 1>, grid, lds, st, a)       \
                      : launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 0>, grid, lds, st, a)
-    if (NT == 1) { if (ck == 16) { DC_LAUNCH(1, 16); } else { DC_LAUNCH(1, 32); } }
-    else { if (ck == 16) { DC_LAUNCH(2, 16); } else { DC_LAUNCH(2, 32); } }
+    if (NT == 1) { if (ck == 8) { DC_LAUNCH(1, 8); } else if (ck == 16) { DC_LAUNCH(1, 16); } else { DC_LAUNCH(1, 32); } }
+    else { if (ck == 8) { DC_LAUNCH(2, 8); } else if (ck == 16) { DC_LAUNCH(2, 16); } else { DC_LAUNCH(2, 32); } }
 #undef DC_LAUNCH
     if (rc) return rc;
     return stx_check_launch("deconv3d_fwd");

@@ -123,7 +123,10 @@ __device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[
 // ------------------------------------------------------------------------------------------
 // Direct convolution, kernel KS^3 (pad KS/2), stride S.
 template <int KS, int S, int TD, int TH, int NT, int CK>
-__global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) {
+// (occupancy hint: without it hipcc spends 132-180 VGPRs on the 1-2 column-block variants and two workgroups share a CU;
+//  with it the 8- and 16-channel chunk variants take 101 without spilling and four do -- GPU call T: 64->64 L1
+//  0.486 -> 0.430 ms with 8-channel chunks)
+__global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void conv3d_igemm_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3d_igemm_kernel(ConvArgs a) 
 // written to LDS after it, between the two barriers that separate the items.  The global-memory latency of the
 // staging is therefore always covered by a full tap loop; what stays exposed is the register -> LDS copy.
 template <int KS, int S, int TD, int TH, int NT, int CK>
-__global__ __launch_bounds__(CONV_THREADS) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
+__global__ __launch_bounds__(CONV_THREADS, CK == 8 ? 2 : 1) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
     constexpr int PAD = KS / 2;
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;
@@ -1364,9 +1367,13 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
 }  // namespace
 
 // Cin chunk used by the kernels for a given Cin (multiple of 8).  STX_CONV_CK overrides (tuning).
-static int conv_pick_ck(int Cin) {
+// 3x3x3: 8-channel chunks (GPU call T: the LDS tile shrinks to 26 KB and the register budget to ~100, so up to four
+// workgroups share a CU instead of two: 64->64 L1 0.486 -> 0.430 ms, 128->128 L2 0.242 -> 0.232 ms); 1x1x1 (HBM-bound,
+// no halo): 32-channel chunks.
+static int conv_pick_ck(int Cin, int ks) {
     static const int env = getenv("STX_CONV_CK") ? atoi(getenv("STX_CONV_CK")) : 0;
     if (env && Cin % env == 0) return env;
+    if (ks == 3) return 8;
     return (Cin % 32 == 0) ? 32 : 8;
 }
 // 32-wide MFMA column blocks used for N output channels (1, 2 or 4).
@@ -1514,7 +1521,7 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         return stx_check_launch("conv3d_fwd(march)");
     }
     // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: keep it to 8-channel K chunks (79 KB).
-    int CK = (stride == 2) ? 8 : conv_pick_ck(Cin);
+    int CK = (stride == 2) ? 8 : conv_pick_ck(Cin, ks);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -1565,8 +1572,9 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;
     // (GPU call S, 576x960: 128->64 0.223 ms with 372 VGPRs and 32-channel chunks -> 0.168 ms with the occupancy hint
     //  -> 0.143 ms with 16-channel chunks (15.8 KB of LDS: four workgroups per CU); 64->32 0.327 -> 0.289 -> 0.254 ms)
-    int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 16;
-    if (ck != 8 && ck != 16 && ck != 32) ck = 16;
+    // (call T: 8-channel chunks 0.140 / 0.251 ms, 16-channel 0.157 / 0.280, 32-channel 0.153 / 0.266 on the same box)
+    int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 8;
+    if (ck != 8 && ck != 16 && ck != 32) ck = 8;
     const size_t lds = (size_t)2 * 3 * 33 * (ck + 4) * 4;
 #define DC_LAUNCH(NT_, CK_)                                                                        \
     rc = pipe == 2   ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 2>, grid, lds, st, a)       \

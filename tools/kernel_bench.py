@@ -68,8 +68,8 @@ AB_SETS = [
     ("transposed conv: rolled tap loops (first generation)", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "0"}),
     ("transposed conv: weights AND LDS operands one tap ahead", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "2"}),
     ("transposed conv: 32-channel K chunks", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "32"}),
-    ("transposed conv: 8-channel K chunks", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "8"}),
-    ("transposed conv: 8-channel K chunks, rolled loops", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "8", "STX_DECONV_PIPE": "0"}),
+    ("transposed conv: 16-channel K chunks", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "16"}),
+    ("transposed conv: 16-channel K chunks, LDS operands ahead", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "16", "STX_DECONV_PIPE": "2"}),
     ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
     ("head: LDS-staged kernels everywhere (backward per-pixel pass too)", "head", {"STX_HEAD_V1": "0"}),
     ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),

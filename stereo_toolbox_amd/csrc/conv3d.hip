@@ -247,7 +247,9 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void con
 // written to LDS after it, between the two barriers that separate the items.  The global-memory latency of the
 // staging is therefore always covered by a full tap loop; what stays exposed is the register -> LDS copy.
 template <int KS, int S, int TD, int TH, int NT, int CK>
-__global__ __launch_bounds__(CONV_THREADS, CK == 8 ? 2 : 1) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
+// (occupancy hint for the stride-1 8-channel-chunk variants only: 328 -> 221 VGPRs without spilling; the stride-2 ones
+//  spill under the same cap and measured 0.152 -> 0.205 ms on 64->128, GPU call U)
+__global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
     constexpr int PAD = KS / 2;
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;

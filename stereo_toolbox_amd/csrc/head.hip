@@ -380,62 +380,12 @@ __global__ __launch_bounds__(HD_THREADS) void head_bwd_gather_kernel(
     gcost[(((size_t)b * Dc + dc) * Hc + hc) * Wc + wc] = acc;
 }
 
-// Second generation of the gather: the first version recomputes both lerp weights (two hd_src each) for every one of the
-// fh x fw candidate pixels of a cell -- ~25 instructions per candidate, 0.128 ms at 576x960, pure VALU time.  Here the
-// fh row weights and fw column weights of the cell are computed once into registers (footprints up to 12 x 12: scale
-// factors up to 4.5), the window is walked with a predicated load + fma per candidate.
-constexpr int HD_GF = 12;
+constexpr int HD_GF = 12;      // footprint bound (rows) of the float4-window gather below
 
-template <bool AC>
-__global__ __launch_bounds__(HD_THREADS) void head_bwd_gather2_kernel(
-    const float* __restrict__ gpix, float* __restrict__ gcost, int Dc, int Hc, int Wc, int H, int W,
-    int fh, int fw) {
-    const int wc = blockIdx.x * HD_THREADS + threadIdx.x;
-    const int hc = blockIdx.y % Hc, dc = blockIdx.y / Hc, b = blockIdx.z;
-    if (wc >= Wc) return;
-    const float rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
-    int h_lo, w_lo;
-    if (AC) {
-        h_lo = rh > 0.f ? (int)(((float)hc - 1.f) / rh) - 1 : 0;
-        w_lo = rw > 0.f ? (int)(((float)wc - 1.f) / rw) - 1 : 0;
-    } else {
-        h_lo = (int)(((float)hc - 1.f + 0.5f) / rh - 0.5f) - 1;
-        w_lo = (int)(((float)wc - 1.f + 0.5f) / rw - 0.5f) - 1;
-    }
-    h_lo = h_lo < 0 ? 0 : h_lo;
-    w_lo = w_lo < 0 ? 0 : w_lo;
-    // weights (zero outside the footprint / the image) and clamped, always valid, offsets: the window walk below is
-    // branch-free -- all loads of a row are in flight together (a predicated load per candidate serialises 144 round trips)
-    // and each load is `global_load v, v_coloffset, s[row]` with no address arithmetic
-    float kh[HD_GF], kw[HD_GF];
-    unsigned ow[HD_GF];                                      // candidate column j (clamped)
-#pragma unroll
-    for (int i = 0; i < HD_GF; ++i) {
-        const int hh = h_lo + i, ww = w_lo + i;
-        kh[i] = (i < fh && hh < H) ? hd_weight<AC>(hh, rh, Hc, hc) : 0.f;
-        kw[i] = (i < fw && ww < W) ? hd_weight<AC>(ww, rw, Wc, wc) : 0.f;
-        ow[i] = (unsigned)(ww < W ? ww : W - 1);
-    }
-    const float* gp = gpix + (((size_t)b * Dc + dc) * H) * W;
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < HD_GF; ++i) {
-        const int hh = h_lo + i < H ? h_lo + i : H - 1;      // (the candidate rows are the same for the whole workgroup)
-        const float* rowp = gp + (size_t)hh * W;             // wave-uniform: derived from blockIdx only
-        float v[HD_GF];
-#pragma unroll
-        for (int j = 0; j < HD_GF; ++j) v[j] = rowp[ow[j]];
-        float row = 0.f;
-#pragma unroll
-        for (int j = 0; j < HD_GF; ++j) row = fmaf(kw[j], v[j], row);
-        acc = fmaf(kh[i], row, acc);
-    }
-    gcost[(((size_t)b * Dc + dc) * Hc + hc) * Wc + wc] = acc;
-}
-
-// Third generation of the gather (GPU call O: the branch-free kernel above is SLOWER than the first version, 0.30 vs
-// 0.22 ms for the whole backward: its 144 dword loads per cell have a lane stride of 16 bytes, i.e. 16 texture-addresser
-// cycles each).  A cell's candidate pixels in a row are contiguous, and neighbouring cells' windows start `1/scale`
+// Second generation of the gather.  The first version recomputes both lerp weights (two hd_src each) for every one of the
+// fh x fw candidate pixels of a cell -- ~25 instructions per candidate, 0.132 ms at 576x960, pure VALU time.  (A branch-free
+// variant with the weights hoisted and one dword load per candidate measured SLOWER, GPU call O/P: 0.21 ms -- its 144 loads
+// per cell have a lane stride of 16 bytes, i.e. 16 texture-addresser cycles each.)  A cell's candidate pixels in a row are contiguous, and neighbouring cells' windows start `1/scale`
 // pixels apart -- with the window start rounded down to a multiple of 4 pixels every lane reads whole float4s and, at the
 // usual scale of 1/4, the wave's float4s of one load instruction are CONTIGUOUS (1 KiB per instruction).  16 pixels per
 // row from the aligned start cover every footprint up to 13 pixels; hd_weight is zero for pixels that do not touch the
@@ -629,13 +579,9 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
         fh = 2 * stx_cdiv(H, Hc) + 3;
         fw = 2 * stx_cdiv(W, Wc) + 3;
     }
-    const int gsel = getenv("STX_HEAD_GATHER") ? atoi(getenv("STX_HEAD_GATHER")) : 4;      // A/B: 2 = second generation
-    if (fh <= HD_GF && fw <= 13 && W % 4 == 0 && W >= 16 && gsel == 4 && !(hd_v1_mask() & 4))
+    if (fh <= HD_GF && fw <= 13 && W % 4 == 0 && W >= 16 && !(hd_v1_mask() & 4))
         hipLaunchKernelGGL(head_bwd_gather4_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
                            workspace, gcost, Dc, Hc, Wc, H, W, fh);
-    else if (fh <= HD_GF && fw <= HD_GF && !(hd_v1_mask() & 4))
-        hipLaunchKernelGGL(head_bwd_gather2_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
-                           workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);
     else
         hipLaunchKernelGGL(head_bwd_gather_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
                            workspace, gcost, Dc, Hc, Wc, H, W, fh, fw);

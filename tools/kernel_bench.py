@@ -73,7 +73,6 @@ AB_SETS = [
     ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
     ("head: LDS-staged kernels everywhere (backward per-pixel pass too)", "head", {"STX_HEAD_V1": "0"}),
     ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),
-    ("head: second-generation backward gather (dword loads)", "head", {"STX_HEAD_GATHER": "2"}),
     ("bn_finalize: first generation", "bn_finalize", {"STX_BN_FINALIZE_V1": "1"}),
     ("wgrad slab reduce: first generation", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad", {"STX_WGRAD_REDUCE_V1": "1"}),
     ("cost volume bwd: first generation", "cost_volume_bwd", {"STX_CVB_OLD": "1"}),

@@ -35,6 +35,7 @@ struct SvArgs {
     const float* gvol;
     float *gLg, *gRg, *gLc, *gRc;
     int B, H, W, S, G, cpg, Cc, CT, CTp;
+    int nsplit;                    // backward: workgroups (grid.z) sharing the groups of one (b, h, tile)
 };
 
 // column of the right image a hypothesis points at: pos = w - sample (integer-valued floats), index clamped into the
@@ -141,22 +142,37 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_fwd_kernel(SvArgs a
     }
 }
 
-template <int CPG>
-__global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a) {
+// PRIV: the right-feature gradients of the workgroup accumulate in an LDS window of SV_XW columns ([w0 - SV_XB, w0 + 63]:
+// hypotheses are non-negative disparities, so the gather column lies at or left of the pixel) with LDS atomics and are added
+// to memory once at the end -- one global atomic per (channel, window column) instead of one per (channel, pixel,
+// hypothesis): 16 x fewer for CFNet's stage 3 (GPU call O: 88 M global float atomics = 1.6 ms).  Columns outside the window
+// fall back to global atomics.  The groups are split over `a.nsplit` workgroups (grid.z) so that the window fits the LDS.
+constexpr int SV_XB = 96, SV_XW = SV_XB + SV_TW;
+
+template <int CPG, bool PRIV, int GPW>      // GPW: groups per wave (4 GPW >= groups of the workgroup)
+__global__ __launch_bounds__(SV_THREADS, GPW == 5 ? 2 : 1) void sampled_volume_bwd_kernel(SvArgs a) {
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);               // [64][TS]: the volume gradient of (s, h, 64 columns)
     const int TS = a.CTp + 1;
+    float* accw = tile + SV_TW * TS;                             // PRIV: [GH * CPG + Cc][SV_XW]
     const int tid = threadIdx.x, wl = tid & 63, wave = tid >> 6;
-    const int w0 = blockIdx.x * SV_TW, h = blockIdx.y, b = blockIdx.z;
+    const int w0 = blockIdx.x * SV_TW, h = blockIdx.y, b = blockIdx.z / a.nsplit, part = blockIdx.z % a.nsplit;
+    const int GH = (a.G + a.nsplit - 1) / a.nsplit;              // groups per workgroup
+    const int g_lo = part * GH, g_hi = g_lo + GH < a.G ? g_lo + GH : a.G;
+    const int ncc = part == 0 ? a.Cc : 0;                        // the concat channels ride with the first part
     const int HW = a.H * a.W, Cg = a.G * CPG;
     const int w = w0 + wl, wc = w < a.W ? w : a.W - 1;
     const bool live = w < a.W;
     const int Q = a.CTp >> 2;
     const int ncol = (a.W - w0) < SV_TW ? (a.W - w0) : SV_TW;
     const float inv = 1.f / (float)CPG;
-    float gl[SV_MAXGPW][CPG];                                   // d/dLg of my groups' channels
+    const int x_lo = w0 - SV_XB;
+    const int nacc = (GH * CPG + a.Cc) * SV_XW;
+    if (PRIV)
+        for (int i = tid; i < nacc; i += SV_THREADS) accw[i] = 0.f;
+    float gl[GPW][CPG];                                   // d/dLg of my groups' channels
 #pragma unroll
-    for (int k = 0; k < SV_MAXGPW; ++k)
+    for (int k = 0; k < GPW; ++k)
 #pragma unroll
         for (int c = 0; c < CPG; ++c) gl[k][c] = 0.f;
     float glc[4] = {0.f, 0.f, 0.f, 0.f};                        // d/dLc of concat channels wave, wave+4, .. (Cc <= 16)
@@ -176,21 +192,25 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
         bool valid;
         const int xi = sv_column(wc, sample, a.W, valid);
         valid = valid && live;
+        const int xl = xi - x_lo;
+        const bool inwin = PRIV && xl >= 0 && xl < SV_XW;
         const float* mine = tile + wl * TS;
         if (a.G) {
             const float* Lrow = a.Lg + rowoff;
             const float* Rrow = a.Rg + rowoff;
             float* gRrow = a.gRg + rowoff;
 #pragma unroll
-            for (int k = 0; k < SV_MAXGPW; ++k) {
-                const int g = wave + 4 * k;
-                if (g < a.G && valid) {                            // (invalid hypotheses carry no gradient on either side)
+            for (int k = 0; k < GPW; ++k) {
+                const int g = g_lo + wave + 4 * k;
+                if (g < g_hi && valid) {                           // (invalid hypotheses carry no gradient on either side)
                     const float gv = mine[g] * inv;
 #pragma unroll
                     for (int c = 0; c < CPG; ++c) {
                         const unsigned o = (unsigned)(g * CPG + c) * (unsigned)HW;
                         gl[k][c] = fmaf(gv, Rrow[o + (unsigned)xi], gl[k][c]);
-                        atomicAdd(gRrow + (o + (unsigned)xi), gv * Lrow[o + (unsigned)wc]);
+                        const float v = gv * Lrow[o + (unsigned)wc];
+                        if (inwin) atomicAdd(accw + ((g - g_lo) * CPG + c) * SV_XW + xl, v);
+                        else atomicAdd(gRrow + (o + (unsigned)xi), v);
                     }
                 }
                 STX_SCHED_BARRIER();       // one group's loads in flight at a time: all ten hoisted cost 440 VGPRs
@@ -199,9 +219,31 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = wave + 4 * k;
-            if (c < a.Cc && live) {
+            if (c < ncc && live) {
                 glc[k] += mine[a.G + c];
-                if (valid) atomicAdd(a.gRc + ((size_t)(b * a.Cc + c) * a.H + h) * a.W + xi, mine[a.G + a.Cc + c]);
+                if (valid) {
+                    const float v = mine[a.G + a.Cc + c];
+                    if (inwin) atomicAdd(accw + (GH * CPG + c) * SV_XW + xl, v);
+                    else atomicAdd(a.gRc + ((size_t)(b * a.Cc + c) * a.H + h) * a.W + xi, v);
+                }
+            }
+        }
+    }
+    if (PRIV) {
+        __syncthreads();
+        // the window goes to memory: lane = window column (coalesced), one atomic per non-zero entry (neighbouring tiles'
+        // windows overlap)
+        const int nrow = (g_hi - g_lo) * CPG + ncc;
+        for (int i = tid; i < nrow * SV_XW; i += SV_THREADS) {
+            const int r = i / SV_XW, col = i - r * SV_XW;
+            const int x = x_lo + col;
+            const int rl = r < (g_hi - g_lo) * CPG ? r : GH * CPG + (r - (g_hi - g_lo) * CPG);     // LDS row of output row r
+            const float v = accw[rl * SV_XW + col];
+            if (x >= 0 && x < a.W && v != 0.f) {
+                if (r < (g_hi - g_lo) * CPG)
+                    atomicAdd(a.gRg + rowoff + (size_t)(g_lo * CPG + r) * HW + x, v);
+                else
+                    atomicAdd(a.gRc + ((size_t)(b * a.Cc + (r - (g_hi - g_lo) * CPG)) * a.H + h) * a.W + x, v);
             }
         }
     }
@@ -209,9 +251,9 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
     if (a.G) {
         float* gLrow = a.gLg + rowoff;
 #pragma unroll
-        for (int k = 0; k < SV_MAXGPW; ++k) {
-            const int g = wave + 4 * k;
-            if (g < a.G) {
+        for (int k = 0; k < GPW; ++k) {
+            const int g = g_lo + wave + 4 * k;
+            if (g < g_hi) {
 #pragma unroll
                 for (int c = 0; c < CPG; ++c) gLrow[(unsigned)(g * CPG + c) * (unsigned)HW + (unsigned)w] = gl[k][c];
             }
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(SV_THREADS) void sampled_volume_bwd_kernel(SvArgs a
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = wave + 4 * k;
-        if (c < a.Cc) a.gLc[((size_t)(b * a.Cc + c) * a.H + h) * a.W + w] = glc[k];
+        if (c < ncc) a.gLc[((size_t)(b * a.Cc + c) * a.H + h) * a.W + w] = glc[k];
     }
 }
 
@@ -278,16 +320,38 @@ extern "C" int stx_sampled_volume_bwd(const float* gvol, const float* Lg, const 
     if (int rc = sv_check(a, "sampled_volume_bwd")) return rc;
     STX_REQUIRE(G <= 4 * SV_MAXGPW && Cc <= 16, "sampled_volume_bwd: G = %d / Cc = %d exceed the kernel's register tiles", G, Cc);
     STX_REQUIRE(G == 0 || a.cpg == 4 || a.cpg == 8, "sampled_volume_bwd: %d channels per group unsupported (4 or 8)", a.cpg);
-    const size_t lds = (size_t)SV_TW * (CTp + 1) * 4;
-    STX_REQUIRE(lds <= 64 * 1024, "sampled_volume_bwd: %d channels exceed the LDS tile", CTp);
+    const size_t lds_tile = (size_t)SV_TW * (CTp + 1) * 4;
+    STX_REQUIRE(lds_tile <= 64 * 1024, "sampled_volume_bwd: %d channels exceed the LDS tile", CTp);
     hipStream_t st = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
     if (G && hipMemsetAsync(gRg, 0, (size_t)B * Cg * HW * 4, st) != hipSuccess) return stx_set_error(STX_ERR_LAUNCH, "sampled_volume_bwd: memset");
     if (Cc && hipMemsetAsync(gRc, 0, (size_t)B * Cc * HW * 4, st) != hipSuccess) return stx_set_error(STX_ERR_LAUNCH, "sampled_volume_bwd: memset");
-    dim3 grid(stx_cdiv(W, SV_TW), H, B);
-    if (a.cpg == 8)
-        hipLaunchKernelGGL(sampled_volume_bwd_kernel<8>, grid, dim3(SV_THREADS), lds, st, a);
-    else
-        hipLaunchKernelGGL(sampled_volume_bwd_kernel<4>, grid, dim3(SV_THREADS), lds, st, a);
+    // LDS-privatised right gradients: split the groups over 1, 2 or 4 workgroups until the window fits (<= 80 KB keeps
+    // two workgroups per CU); STX_SV_BWD_V1 = global atomics only (first version, A/B)
+    const int cpg = a.cpg ? a.cpg : 4;
+    int nsplit = 0;
+    if (!getenv("STX_SV_BWD_V1"))
+        for (int n = 1; n <= 4 && !nsplit; n *= 2) {
+            const size_t win = ((size_t)stx_cdiv(G, n) * cpg + Cc) * SV_XW * 4;
+            if (lds_tile + win <= (n < 4 ? 80 : 160) * 1024 && (long long)B * n <= 65535) nsplit = n;
+        }
+    const bool priv = nsplit > 0;
+    a.nsplit = priv ? nsplit : 1;
+    const size_t lds = lds_tile + (priv ? ((size_t)stx_cdiv(G, a.nsplit) * cpg + Cc) * SV_XW * 4 : 0);
+    dim3 grid(stx_cdiv(W, SV_TW), H, B * a.nsplit);
+    const bool small = stx_cdiv(G, a.nsplit) <= 20;               // <= 5 groups per wave: half the accumulator registers
+#define SV_BWD(CPG_, PRIV_, GPW_)                                                                                \
+    {                                                                                                            \
+        if (lds > 64 * 1024)                                                                                     \
+            hipFuncSetAttribute((const void*)sampled_volume_bwd_kernel<CPG_, PRIV_, GPW_>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((sampled_volume_bwd_kernel<CPG_, PRIV_, GPW_>), grid, dim3(SV_THREADS), lds, st, a);  \
+    }
+    if (a.cpg == 8) {
+        if (priv && small) SV_BWD(8, true, 5) else if (priv) SV_BWD(8, true, 10) else SV_BWD(8, false, 10)
+    } else {
+        if (priv && small) SV_BWD(4, true, 5) else if (priv) SV_BWD(4, true, 10) else SV_BWD(4, false, 10)
+    }
+#undef SV_BWD
     return stx_check_launch("sampled_volume_bwd");
 }

@@ -546,18 +546,27 @@ def test_ac_volume_backward(be):
 
 
 # ------------------------------------------------------------------------------ CFNet sampled (cascade) volume
-@pytest.mark.parametrize("case", [(1, 40, 4, 12, 5, 70, 6), (2, 20, 4, 6, 3, 33, 4), (1, 8, 8, 0, 2, 64, 3), (1, 0, 0, 8, 2, 20, 5)])
-def test_sampled_volume_fwd_bwd(be, case):
+@pytest.mark.parametrize("variant", ["lds_window", "global_atomics"])
+@pytest.mark.parametrize("case", [(1, 40, 4, 12, 5, 70, 6), (2, 20, 4, 6, 3, 33, 4), (1, 8, 8, 0, 2, 64, 3), (1, 0, 0, 8, 2, 20, 5),
+                                  (1, 8, 4, 4, 2, 200, 3), (1, 40, 8, 12, 1, 66, 2)])
+def test_sampled_volume_fwd_bwd(be, case, variant, monkeypatch):
     """stx_sampled_volume_fwd / _bwd against the oracle's restatement of SpatialTransformer + groupwise_correlation_4D +
     cost_volume_generator + cat (CFNet/submodule.py:306-350, 163-169, cfnet.py:470-497, 560-566): CFNet's two stage
     configurations (40 groups x 4 channels + 12 concat; 20 x 4 + 6), 8 channels per group, concat only; W = 70 / 33 leave
-    a ragged 64-column tile; hypotheses reach outside the image on both sides (clamped index, zeroed contribution)."""
+    a ragged 64-column tile; hypotheses reach outside the image on both sides (clamped index, zeroed contribution).
+    Backward in both forms: right-feature gradients through the workgroup's LDS window (W = 200 with hypotheses up to 150
+    columns puts many gather columns left of the 96-column window -> its global-atomic fallback; 320 + 12 channels split
+    the groups over two workgroups) and with global atomics only (STX_SV_BWD_V1)."""
+    if variant == "global_atomics":
+        monkeypatch.setenv("STX_SV_BWD_V1", "1")
+    else:
+        monkeypatch.delenv("STX_SV_BWD_V1", raising=False)
     B, G, cpg, Cc, H, W, S = case
     torch.manual_seed(11)
     Cg = G * cpg
     Lg, Rg = (torch.randn(B, Cg, H, W).requires_grad_() if G else None for _ in range(2))
     Lc, Rc = (torch.randn(B, Cc, H, W).requires_grad_() if Cc else None for _ in range(2))
-    samples = torch.randint(-4, W // 2, (B, S, H, W)).float()
+    samples = torch.randint(-4, 150 if W == 200 else W // 2, (B, S, H, W)).float()
     parts = []
     if G:
         parts.append(O.cf_sampled_volume(Lg, Rg, samples, G))

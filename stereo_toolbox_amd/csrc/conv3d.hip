@@ -122,7 +122,9 @@ __device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[
 
 // ------------------------------------------------------------------------------------------
 // Direct convolution, kernel KS^3 (pad KS/2), stride S.
-template <int KS, int S, int TD, int TH, int NT, int CK>
+// VPAD: LDS padding per staged voxel in floats (4 = conflict-free operand reads; 0 = the opt-in dense layout of the
+// stride-2 kernel, whose 5 x 5 x 66-voxel halo tile then takes 53 KB instead of 79 KB -> three workgroups per CU)
+template <int KS, int S, int TD, int TH, int NT, int CK, int VPAD = 4>
 // (occupancy hint: without it hipcc spends 132-180 VGPRs on the 1-2 column-block variants and two workgroups share a CU;
 //  with it the 8- and 16-channel chunk variants take 101 without spilling and four do -- GPU call T: 64->64 L1
 //  0.486 -> 0.430 ms with 8-channel chunks)
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void con
     constexpr int EWH = (EW + 1) / 2;
     constexpr int EWS = (S == 2) ? 2 * EWH : EW;     // LDS slots per row (S=2: even/odd de-interleaved)
     constexpr int MT = TD * TH / 4;
-    constexpr int VS = CK + 4;
+    constexpr int VS = CK + VPAD;
     constexpr int NF4 = CK / 4;
     static_assert(TD * TH % 4 == 0, "tile must split over 4 waves");
     STX_DYN_SMEM(smem);
@@ -1544,7 +1546,13 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
             if (rc > 0) return rc;
         }
     }
+    // opt-in, not yet timed on the chip (prepared after the last GPU call of round 2): stride 2 with the dense LDS tile
+    const int s2_dense = getenv("STX_CONV_S2_DENSE") ? atoi(getenv("STX_CONV_S2_DENSE")) : 0;
     if (ks == 3 && stride == 1) rc = conv_dispatch<3, 1>(a, NT, CK, grid, st);
+    else if (ks == 3 && s2_dense && NT == 2 && CK == 8) {
+        const size_t lds = (size_t)5 * 5 * 66 * 8 * 4;
+        rc = launch_with_lds(conv3d_igemm_kernel<3, 2, CONV_TD, CONV_TH, 2, 8, 0>, grid, lds, st, a);
+    }
     else if (ks == 3) rc = conv_dispatch<3, 2>(a, NT, CK, grid, st);
     else rc = conv_dispatch<1, 1>(a, NT, CK, grid, st);
     if (rc) return rc;

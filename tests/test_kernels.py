@@ -339,6 +339,20 @@ def test_conv3d_fwd(be, case):
     _close(got2, ref2)
 
 
+def test_conv3d_stride2_dense_lds_tile(be, monkeypatch):
+    """Opt-in stride-2 variant with the un-padded LDS tile (STX_CONV_S2_DENSE=1, 32 -> 64 channels: the first convolution
+    of every hourglass): same results as the default layout, ragged H / W / D included."""
+    monkeypatch.setenv("STX_CONV_S2_DENSE", "1")
+    torch.manual_seed(15)
+    for B, D, H, W in ((1, 5, 6, 45), (2, 4, 4, 70)):
+        x = torch.randn(B, 32, D, H, W)
+        w = torch.randn(64, 32, 3, 3, 3) * 0.1
+        ref = F.conv3d(x, w, None, 2, 1)
+        got, st = run_conv(be, x, w, 3, 2, stats=True)
+        _close(got, ref)
+        _close(st[:, 0].sum(0), ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize("case", [(1, 64, 32, 2, 3, 33), (2, 128, 64, 2, 4, 20), (1, 32, 32, 1, 2, 40)])
 def test_deconv3d_fwd(be, case):
     B, Cin, Cout, D, H, W = case

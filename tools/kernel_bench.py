@@ -65,6 +65,7 @@ def pack(w, mode):
 # A/B switches that libstx_hip.so reads on every call (not cached in statics): they can be flipped inside one process, so
 # a whole comparison costs one interpreter start.  (label, kernel filter, environment)
 AB_SETS = [
+    ("stride-2 32->64 with the dense (un-padded) LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": "1"}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": "1"}),
     ("transposed conv: rolled tap loops (first generation)", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "0"}),
     ("transposed conv: weights AND LDS operands one tap ahead", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "2"}),

@@ -86,7 +86,8 @@ int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stre
  *   mode 2: ConvTranspose forward (w = [Cin][Cout][T]) and stride-2 conv dgrad. */
 long long stx_conv3d_packed_floats(int K, int N, int T);
 int stx_conv3d_pack_weight(const float* w, float* wp, int A, int B, int T, int mode, void* stream);
-/* out = act(conv(x) * scale[c] + bias[c] + residual); scale/bias/residual may be NULL; if `stats` != NULL the
+/* out = act(conv(x) * scale[c] + bias[c] + residual); `relu` is the activation code: 0 none, 1 ReLU, 2 Mish
+ * (x * tanh(softplus(x)), models/PCWNet/submodule.py:11-18); scale/bias/residual may be NULL; if `stats` != NULL the
  * per-workgroup (sum, sum of squares) of the RAW conv output are written to stats[B*blocks][2][Cout]
  * (blocks = stx_conv3d_fwd_blocks(Do,Ho,Wo)) for train-mode BatchNorm. Cin % 8 == 0, Cout <= 128. */
 int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo);

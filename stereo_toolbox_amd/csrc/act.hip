@@ -9,27 +9,10 @@ namespace {
 
 constexpr int ACT_THREADS = 256;
 
-// tanh(softplus(x)) = tanh(log(1 + e^x)) = ((1 + e^x)^2 - 1) / ((1 + e^x)^2 + 1) = n / (n + 2),  n = e^x (e^x + 2):
-// one exp and one division instead of libm's log1pf + tanhf (GPU call O: 0.19 ms for a 212 MB volume = 0.28 of the HBM
-// roofline, pure VALU time).  No cancellation anywhere (n >= 0); above torch's softplus threshold of 20 the factor is 1.
-__device__ __forceinline__ float mish_tanh_sp(float x, float& w) {
-    w = stx_exp(x < 20.f ? x : 20.f);
-    const float n = w * (w + 2.f);
-    return x > 20.f ? 1.f : __fdividef(n, n + 2.f);
-}
-
-__device__ __forceinline__ float mish_f(float x) {
-    float w;
-    return x * mish_tanh_sp(x, w);
-}
-
-// d/dx [x * tanh(softplus(x))] = t + x * (1 - t^2) * softplus'(x), softplus'(x) = sigmoid(x) (1 above the threshold)
-__device__ __forceinline__ float mish_grad_f(float x) {
-    float w;
-    const float t = mish_tanh_sp(x, w);
-    const float ds = x > 20.f ? 1.f : __fdividef(w, 1.f + w);
-    return t + x * (1.f - t * t) * ds;
-}
+// (the arithmetic lives in stx_common.h: stx_mish / stx_mish_grad -- n / (n + 2) with n = e^x (e^x + 2), one exp and one
+// division instead of libm's log1pf + tanhf; GPU call O -> V: 0.19 -> 0.077 ms for a 212 MB volume)
+__device__ __forceinline__ float mish_f(float x) { return stx_mish(x); }
+__device__ __forceinline__ float mish_grad_f(float x) { return stx_mish_grad(x); }
 
 __global__ __launch_bounds__(ACT_THREADS) void mish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               size_t nquads) {

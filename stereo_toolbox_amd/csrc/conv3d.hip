@@ -44,7 +44,7 @@ struct ConvArgs {
     float* stats;           // [nblocks][2][Cout] partial sums of raw output, or null
     int Di, Hi, Wi, Cin;
     int Do, Ho, Wo, Cout;
-    int relu;
+    int relu;               // activation code: 0 none, 1 ReLU, 2 Mish (stx_act)
     int nDt, nHt, nWt;
 };
 
@@ -82,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32
             s2 = fmaf(v, v, s2);
             v = fmaf(v, sc, bs);
             if (a.residual) v += a.residual[idx];
-            if (a.relu) v = v > 0.f ? v : 0.f;
+            v = stx_act(v, a.relu);
             a.out[idx] = v;
         }
     }
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3d_march_kernel(MarchArgs ma) {
                     s2[nt] = fmaf(v, v, s2[nt]);
                     v = fmaf(v, sc, bs);
                     if (a.residual) v += a.residual[idx];
-                    if (a.relu) v = v > 0.f ? v : 0.f;
+                    v = stx_act(v, a.relu);
                     a.out[idx] = v;
                 }
             }
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             s2 = fmaf(v, v, s2);
             v = fmaf(v, sc, bs);
             if (a.residual) v += a.residual[idx];
-            if (a.relu) v = v > 0.f ? v : 0.f;
+            v = stx_act(v, a.relu);
             a.out[idx] = v;
         }
     };

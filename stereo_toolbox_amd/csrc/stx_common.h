@@ -90,6 +90,30 @@ static inline void stx_begin() { (void)hipGetLastError(); }
 
 static inline int stx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Activation code of the conv / BN-apply epilogues (the C-ABI's `relu` argument): 0 none, 1 ReLU, 2 Mish.
+// Mish (reference models/PCWNet/submodule.py:11-18): x * tanh(softplus(x)) with tanh(log(1 + e^x)) = n / (n + 2),
+// n = e^x (e^x + 2) -- one exp and one division, no cancellation (n >= 0); above torch's softplus threshold of 20 the
+// factor is 1.  `w` returns e^min(x, 20) for the derivative.
+__device__ __forceinline__ float stx_mish_tanh_sp(float x, float& w) {
+    w = stx_exp(x < 20.f ? x : 20.f);
+    const float n = w * (w + 2.f);
+    return x > 20.f ? 1.f : __fdividef(n, n + 2.f);
+}
+__device__ __forceinline__ float stx_mish(float x) {
+    float w;
+    return x * stx_mish_tanh_sp(x, w);
+}
+// d/dx [x * tanh(softplus(x))] = t + x * (1 - t^2) * sigmoid(x)   (sigmoid -> 1 above the threshold)
+__device__ __forceinline__ float stx_mish_grad(float x) {
+    float w;
+    const float t = stx_mish_tanh_sp(x, w);
+    const float ds = x > 20.f ? 1.f : __fdividef(w, 1.f + w);
+    return t + x * (1.f - t * t) * ds;
+}
+__device__ __forceinline__ float stx_act(float v, int code) {
+    return code == 1 ? (v > 0.f ? v : 0.f) : (code == 2 ? stx_mish(v) : v);
+}
+
 __device__ __forceinline__ float4 stx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void stx_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // 16-byte store with the non-temporal hint (streamed output that the writing CU never re-reads)

@@ -337,6 +337,8 @@ def test_conv3d_fwd(be, case):
     got2, _ = run_conv(be, x, w, ks, s, sc, bs, res, 1)
     ref2 = F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res)
     _close(got2, ref2)
+    got3, _ = run_conv(be, x, w, ks, s, sc, bs, res, 2)              # activation code 2: Mish in the epilogue
+    _close(got3, F.mish(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res), rtol=1e-4, atol=1e-5)
 
 
 def test_conv3d_stride2_dense_lds_tile(be, monkeypatch):

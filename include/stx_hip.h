@@ -145,7 +145,9 @@ int stx_bn_reduce_blocks(void);
 int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                     float* mean, float* invstd, void* stream);
-/* out = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + z2 when scale2 == NULL]) over [nvox][C] */
+/* out = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + z2 when scale2 == NULL]) over [nvox][C]; `relu` = activation code
+ * (0 none, 1 ReLU, 2 Mish) here and in the backward passes below; Mish is differentiated at the pre-activation value,
+ * which stx_bn_bwd_reduce2 / _apply2 recompute from z and the scale / shift vectors (y = NULL) */
 int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2, const float* scale2,
                  const float* shift2, float* out, long long nvox, int C, int relu, void* stream);
 /* sums[3][C] = sum g, sum g*xhat1, sum g*xhat2 with g = gy*[y>0]; partials: scratch of stx_bn_reduce_blocks()*3*C floats */

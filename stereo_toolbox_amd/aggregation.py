@@ -114,8 +114,8 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     """One fused block on NDHWC tensors.
     second = (x2, conv2, bn2): adds BN2(conv2(x2)) before the activation (hourglass redir path).
     residual: NDHWC tensor added before the activation.
-    mish: Mish instead of ReLU (PCWNet / CFNet family): fused into the conv epilogue in inference, a separate streaming
-    pass (stx_mish_fwd / _bwd) on the autograd path."""
+    mish: Mish instead of ReLU (PCWNet / CFNet family): fused into the conv epilogue in inference and into the BatchNorm
+    apply / backward passes in training (differentiated at the recomputed pre-activation value)."""
     if mish and relu:
         raise ops.StxError("conv_block: relu and mish are mutually exclusive")
     if second is not None and residual is not None:
@@ -123,10 +123,12 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     mods = [conv, bn] + ([second[1], second[2]] if second is not None else [])
     grad = _needs_grad(x, residual, *(m for m in mods if m is not None), *([second[0]] if second else []))
     train_bn = (bn is not None and bn.training) or (second is not None and second[2].training)
-    if mish and (grad or train_bn):   # autograd path: Mish stays a separate streaming pass (forward + backward kernels)
+    if mish and (grad or train_bn) and (bn is None or residual is not None):
+        # autograd path without a BatchNorm to fuse into: Mish as its own streaming pass (forward + backward kernels)
         return ops.mish(conv_block(x, conv, bn, relu=False, second=second, residual=residual))
     if mish:
-        relu = 2                      # inference: activation code 2 of the conv epilogue (no extra pass over the volume)
+        # activation code 2: conv epilogue (inference) / BN apply and the two BN backward passes (train), no extra pass
+        relu = 2
 
     if not grad and not train_bn:   # ---- inference: everything folded into conv epilogues
         if second is not None:

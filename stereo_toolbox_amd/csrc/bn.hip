@@ -143,9 +143,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(
             }
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
-        if (relu) {
-            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        if (relu) {                                             // activation code: 1 ReLU, 2 Mish (stx_common.h)
+            v.x = stx_act(v.x, relu); v.y = stx_act(v.y, relu); v.z = stx_act(v.z, relu); v.w = stx_act(v.w, relu);
         }
         stx_st4(out + i * 4, v);
     }
@@ -194,8 +193,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
             } else {
                 yy = stx_ld4(y + o);
             }
-            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            if (relu == 2) {                                    // Mish: yy is the pre-activation value (remask path only)
+                g.x *= stx_mish_grad(yy.x); g.y *= stx_mish_grad(yy.y); g.z *= stx_mish_grad(yy.z); g.w *= stx_mish_grad(yy.w);
+            } else {
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            }
         }
         s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
         s[4] = fmaf(g.x, (a.x - m1.x) * i1.x, s[4]); s[5] = fmaf(g.y, (a.y - m1.y) * i1.y, s[5]);
@@ -258,8 +261,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
             } else {
                 yy = stx_ld4(y + i * 4);
             }
-            g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-            g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            if (relu == 2) {                                    // Mish: yy is the pre-activation value (remask path only)
+                g.x *= stx_mish_grad(yy.x); g.y *= stx_mish_grad(yy.y); g.z *= stx_mish_grad(yy.z); g.w *= stx_mish_grad(yy.w);
+            } else {
+                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+            }
         }
         if (gout) stx_st4(gout + i * 4, g);
         const float4 sg = stx_ld4(sums + c);
@@ -334,6 +341,7 @@ extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* 
     STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
     STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2) || (scale2 && shift2))),
                 "bn_bwd_reduce: the relu mask needs y or the forward pass's scale / shift vectors");
+    STX_REQUIRE(relu != 2 || !y, "bn_bwd_reduce: Mish (activation code 2) differentiates the pre-activation value: pass y = NULL and the scale / shift vectors");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_RED_BLOCKS), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
                        z2, mean2, invstd2, scale1, shift1, scale2, shift2, partials, (size_t)nvox, C, relu);
@@ -352,6 +360,7 @@ extern "C" int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
     STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2 && dz2) || (scale2 && shift2))),
                 "bn_bwd_apply: the relu mask needs y or the forward pass's scale / shift vectors");
+    STX_REQUIRE(relu != 2 || !y, "bn_bwd_apply: Mish (activation code 2) differentiates the pre-activation value: pass y = NULL and the scale / shift vectors");
     const size_t nquads = (size_t)nvox * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
                        mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, scale1, shift1, scale2, shift2, sums, dz1, dz2,

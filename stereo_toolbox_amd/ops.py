@@ -410,6 +410,7 @@ class BnActFn(torch.autograd.Function):
             scale = gamma * invstd
             return scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd
 
+        relu = int(relu)
         sc1, sh1, m1, i1 = affine(z1, gamma1, beta1, bn1)
         two = z2 is not None
         if two:
@@ -418,6 +419,9 @@ class BnActFn(torch.autograd.Function):
         else:
             sc2 = sh2 = m2 = i2 = None
             y = bn_apply(z1, sc1, sh1, residual, None, None, relu)
+        relu = int(relu)                                  # activation code: 0 none, 1 ReLU, 2 Mish
+        if relu == 2 and residual is not None:
+            raise StxError("BnActFn: Mish with a plain residual is not wired (no model of the family uses it)")
         ctx.relu, ctx.two, ctx.has_res = relu, two, residual is not None
         ctx.train1 = bn1["training"]
         ctx.train2 = bn2["training"] if two else False
@@ -425,7 +429,7 @@ class BnActFn(torch.autograd.Function):
         # ReLU mask for the backward pass: a block without a plain residual recomputes sign(y) from z1 / z2 and the
         # scale / shift vectors used above (bit-identical expression, operands the backward kernels read anyway), so
         # the activated volume is not kept alive by this node and not re-read by its two backward passes
-        ctx.remask = relu and residual is None
+        ctx.remask = bool(relu) and residual is None
         keep_y = y if (relu and not ctx.remask) else None
         ctx.save_for_backward(z1, gamma1, m1, i1, z2, gamma2, m2, i2, keep_y, sc1 if ctx.remask else None,
                               sh1 if ctx.remask else None, sc2 if (ctx.remask and two) else None,

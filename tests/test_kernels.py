@@ -616,6 +616,61 @@ def test_sampled_volume_fwd_bwd(be, case, variant, monkeypatch):
 
 
 # ------------------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize("two", [False, True])
+def test_bn_mish_fused_fwd_bwd(be, two):
+    """Activation code 2 of the BatchNorm passes (PCWNet / CFNet blocks in train mode): y = Mish(BN1(z1) [+ BN2(z2)]) from
+    stx_bn_apply, gradients from stx_bn_bwd_reduce2 / _apply2, which differentiate Mish at the pre-activation value they
+    recompute from z and the forward pass's scale / shift vectors -- against torch autograd of batch_norm + F.mish."""
+    nvox, C = 900, 32
+    torch.manual_seed(12)
+    z1 = (torch.randn(nvox, C) * 2 + 1).requires_grad_()
+    z2 = (torch.randn(nvox, C) + 0.5).requires_grad_() if two else None
+    g1, b1 = (torch.rand(C) + 0.5).requires_grad_(), torch.randn(C).requires_grad_()
+    g2, b2 = (torch.rand(C) + 0.5).requires_grad_(), torch.randn(C).requires_grad_()
+    pre = F.batch_norm(z1, None, None, g1, b1, True, 0.1, 1e-5)
+    if two:
+        pre = pre + F.batch_norm(z2, None, None, g2, b2, True, 0.1, 1e-5)
+    yr = F.mish(pre)
+
+    def fin(z, g, b):
+        chunks = z.detach().chunk(5)
+        part = be.dev(torch.stack([torch.stack([c.sum(0), (c * c).sum(0)]) for c in chunks]))
+        outs = [be.empty(C) for _ in range(4)]
+        be.call("stx_bn_finalize", ptr(part), len(chunks), C, float(nvox), ptr(be.dev(g.detach())), ptr(be.dev(b.detach())),
+                None, None, 0.1, 1e-5, *[ptr(o) for o in outs])
+        return outs
+
+    sc1, sh1, m1, i1 = fin(z1, g1, b1)
+    sc2 = sh2 = m2 = i2 = None
+    if two:
+        sc2, sh2, m2, i2 = fin(z2, g2, b2)
+    d1, d2 = be.dev(z1.detach()), (be.dev(z2.detach()) if two else None)
+    out = be.empty(nvox, C)
+    be.call("stx_bn_apply", ptr(d1), ptr(sc1), ptr(sh1), ptr(d2), ptr(sc2), ptr(sh2), ptr(out), nvox, C, 2)
+    _close(out, yr.detach(), rtol=1e-5, atol=1e-5)
+    gy = torch.randn(nvox, C)
+    yr.backward(gy)
+    dgy = be.dev(gy)
+    NB = be.raw("stx_bn_reduce_blocks")()
+    part, sums = be.empty(NB, 3, C), be.empty(3, C)
+    be.call("stx_bn_bwd_reduce2", ptr(dgy), None, ptr(d1), ptr(m1), ptr(i1), ptr(d2), ptr(m2), ptr(i2), ptr(sc1), ptr(sh1),
+            ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2)
+    dz1, dz2 = be.empty(nvox, C), (be.empty(nvox, C) if two else None)
+    be.call("stx_bn_bwd_apply2", ptr(dgy), None, ptr(d1), ptr(m1), ptr(i1), ptr(be.dev(g1.detach())), ptr(d2), ptr(m2), ptr(i2),
+            ptr(be.dev(g2.detach())) if two else None, ptr(sc1), ptr(sh1), ptr(sc2), ptr(sh2), ptr(sums), ptr(dz1), ptr(dz2), None,
+            nvox, C, 2)
+    _close(dz1, z1.grad, rtol=1e-4, atol=1e-5)
+    _close(sums[1], g1.grad, rtol=1e-4, atol=1e-4)
+    _close(sums[0], b1.grad, rtol=1e-4, atol=1e-4)
+    if two:
+        _close(dz2, z2.grad, rtol=1e-4, atol=1e-5)
+        _close(sums[2], g2.grad, rtol=1e-4, atol=1e-4)
+    from stereo_toolbox_amd._capi import StxError
+    with pytest.raises(StxError):          # Mish cannot be differentiated from the activated output
+        be.call("stx_bn_bwd_reduce2", ptr(dgy), ptr(out), ptr(d1), ptr(m1), ptr(i1), ptr(d2), ptr(m2), ptr(i2), ptr(sc1), ptr(sh1),
+                ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2)
+
+
 @pytest.mark.parametrize("case", [(1500, 32), (300, 64), (100, 32), (257, 20)])
 def test_bn_finalize_many_rows(be, case):
     """stx_bn_finalize with as many partial rows as the L0 convolutions emit (the channel-quad kernel serves

@@ -406,9 +406,10 @@ def main(argv=None):
                        "workload": f"{work}, {H}x{W} pairs (reference pad_to_2x shape), batch {B}/GPU, fp32, "
                                    "synthetic randn inputs, deterministic filler weights",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "grad_sync": (f"flat fp32 buffer, {args.buckets} overlapped all-reduce range(s)"
-                                     if mode == "train" and not (args.no_overlap or args.graph) else
-                                     ("flat fp32 buffer, 1 all-reduce after backward" if mode == "train" else "none")),
+                       "grad_sync": ("none" if mode != "train" else
+                                     "none (single rank: flat fp32 buffer packed, no collective)" if world == 1 else
+                                     f"flat fp32 buffer, {gsync.nb} overlapped all-reduce range(s)" if gsync.overlap else
+                                     "flat fp32 buffer, 1 all-reduce after backward"),
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roof,
         }

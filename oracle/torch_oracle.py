@@ -327,21 +327,25 @@ def gwcnet_forward(sd, left, right, maxdisp, use_concat_volume, training=False, 
     cx = Ctx(sd, training)
     gl, cl = features_gwc(cx, left, use_concat_volume)
     gr, cr = features_gwc(cx, right, use_concat_volume)
+    out = gwcnet_aggregate(cx, gl, gr, cl, cr, maxdisp, left.shape[2], left.shape[3])
+    return (out, cx) if return_ctx else out
+
+
+def gwcnet_aggregate(cx, gl, gr, cl, cr, maxdisp, H, W):
+    """GwcNet/gwcnet.py:175-224 from the 1/4-resolution features onwards (gl / gr: 320-channel gwc features, cl / cr: the
+    12-channel concat features or None) -- the hand-written part of the product, separable for error attribution."""
     vol = build_gwc_volume(gl, gr, maxdisp // 4, 40)
-    if use_concat_volume:
+    if cl is not None:
         vol = torch.cat((vol, build_concat_volume(cl, cr, maxdisp // 4)), 1)
     cost0 = dres0(cx, vol)
     cost0 = dres1(cx, cost0) + cost0
     out1 = hourglass_gwc(cx, cost0, "dres2")
     out2 = hourglass_gwc(cx, out1, "dres3")
     out3 = hourglass_gwc(cx, out2, "dres4")
-    H, W = left.shape[2], left.shape[3]
-    if training:
-        preds = [regression_head(classif(cx, o, f"classif{i}"), maxdisp, H, W)
-                 for i, o in enumerate((cost0, out1, out2, out3))]
-        return (preds, cx) if return_ctx else preds
-    pred = regression_head(classif(cx, out3, "classif3"), maxdisp, H, W)
-    return (pred, cx) if return_ctx else pred
+    if cx.training:
+        return [regression_head(classif(cx, o, f"classif{i}"), maxdisp, H, W)
+                for i, o in enumerate((cost0, out1, out2, out3))]
+    return regression_head(classif(cx, out3, "classif3"), maxdisp, H, W)
 
 
 def psmnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):

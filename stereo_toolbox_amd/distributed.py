@@ -6,7 +6,8 @@ ROCm, "gloo" on CPU.  The whole gradient of these models is 21-29 MB: every para
 view into one flat buffer, so a step issues no gradient copies and
 
   * `buckets=1` (default): exactly one all-reduce after backward();
-  * `buckets=K, overlap=True`: the flat buffer is cut into K contiguous ranges (registration order);
+  * `buckets=K, overlap=True` (ONE backward() per step; a second one before finish() raises): the flat buffer is cut
+    into K contiguous ranges (registration order);
     a range is all-reduced asynchronously from an autograd hook as soon as its last gradient has been
     accumulated, i.e. the aggregation / classifier ranges (registered last, differentiated first)
     travel over xGMI while the 2-D feature CNN is still in its backward pass.  `finish()` waits.
@@ -97,8 +98,15 @@ class FlatGradSync:
                 v.copy_(p.grad)
                 p.grad = v
             b = self.bucket_of[i]
+            if self._launched[b] or self._pending[b] <= 0:
+                # a second backward() before finish() (gradient accumulation, one backward per loss): the range is
+                # already on the wire (or done) -- more local gradient added now would differ across ranks, silently
+                raise RuntimeError("FlatGradSync(overlap=True) supports exactly one backward() per zero_grad() / "
+                                   "detach_grads(): a gradient arrived for a range that was already all-reduced. Use "
+                                   "overlap=False for gradient accumulation (finish() then reduces once, after the "
+                                   "last backward).")
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._launched[b]:
+            if self._pending[b] == 0:
                 self._launch(b)
         return hook
 

@@ -3,8 +3,8 @@
 The dense volume builders, the 3-D convolutions, Mish on volumes and the regressions run on the HIP kernels (the
 multi-scale volumes of CFNet are GwcNet volumes at 1/8, 1/16 and 1/32 resolution).  The cascade's per-pixel search
 range machinery (variance, uniform sampler) acts on small 2-D maps and stays stock torch; the sampled cost volumes of
-the two cascade stages (`SpatialTransformer` gather + `groupwise_correlation_4D`) are stock torch ops for now
-(a gather-correlation kernel is the next step for this family).
+the two cascade stages (`SpatialTransformer` gather + `groupwise_correlation_4D` + `cat`) are one HIP kernel
+(`ops.sampled_volume`, csrc/sampled_volume.hip, forward + backward).
 """
 import numpy as np
 import torch

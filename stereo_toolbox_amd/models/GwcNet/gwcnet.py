@@ -96,6 +96,11 @@ class GwcNet(nn.Module):
 
     def forward(self, left, right):
         fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+
+    def aggregate(self, fl, fr, H, W):
+        """Everything behind the 2-D feature CNN (reference gwcnet.py:175-224): the hand-written part of the model.
+        fl / fr: feature dicts of the two views ("gwc_feature" [B,320,H/4,W/4], optionally "concat_feature")."""
         vol = ops.cost_volume(fl["gwc_feature"], fr["gwc_feature"], fl.get("concat_feature"),
                               fr.get("concat_feature"), self.maxdisp // 4, self.num_groups, mask_left=True)
         cost0 = convbn_block(vol, self.dres0[0], relu=True)
@@ -105,7 +110,6 @@ class GwcNet(nn.Module):
         out1 = self.dres2(cost0)
         out2 = self.dres3(out1)
         out3 = self.dres4(out2)
-        H, W = left.shape[2], left.shape[3]
         if self.training:
             return [ops.regression_head(run_classifier(c, o), self.maxdisp, H, W)
                     for c, o in ((self.classif0, cost0), (self.classif1, out1), (self.classif2, out2),

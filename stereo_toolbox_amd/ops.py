@@ -8,7 +8,6 @@ Activation convention inside the 3-D path: dense channels-last tensors of shape 
 ("NDHWC").  `to_ncdhw` / `to_ndhwc` give zero-copy logical views for the public API.
 """
 import ctypes
-import threading
 
 import torch
 
@@ -18,14 +17,10 @@ _P = ctypes.c_void_p
 
 
 # --------------------------------------------------------------------------------------- plumbing
-class _ArgDevices(threading.local):
-    """Devices of the tensors converted by _p() since the last launch (per host thread)."""
-
-    def __init__(self):
-        self.devs = []
-
-
-_ARGS = _ArgDevices()
+class _DevPtr(ctypes.c_void_p):
+    """A device pointer that remembers the device of the tensor it came from: _call() reads the launch device off its
+    own arguments, so nothing survives between launches (an exception between building the arguments and the launch
+    cannot leak state into the next one)."""
 
 
 def _stream(dev=None):
@@ -35,8 +30,9 @@ def _stream(dev=None):
 def _p(t):
     if t is None:
         return None
-    _ARGS.devs.append(t.device)
-    return _P(t.data_ptr())
+    p = _DevPtr(t.data_ptr())
+    p.dev = t.device
+    return p
 
 
 def _chk(t, name, dims=None):
@@ -57,11 +53,13 @@ def _call(name, *args):
     """Launch one C-ABI entry point on the device that OWNS the operands, on that device's current stream
     (`model.to('cuda:1')` without `torch.cuda.set_device(1)` -- the way evaluation/sceneflow_test.py:22 and
     generalization_eval.py use `device=` -- must not launch on cuda:0's stream).  Operands on different devices raise."""
-    devs, _ARGS.devs = _ARGS.devs, []
-    dev = devs[0] if devs else None
-    for d in devs:
-        if d != dev:
-            raise StxError(f"{name}: operands live on different devices ({dev} and {d})")
+    dev = None
+    for a in args:
+        if isinstance(a, _DevPtr):
+            if dev is None:
+                dev = a.dev
+            elif a.dev != dev:
+                raise StxError(f"{name}: operands live on different devices ({dev} and {a.dev})")
     if dev is not None and dev.type == "cuda" and dev.index != torch.cuda.current_device():
         with torch.cuda.device(dev):
             get_lib().call(name, *args, _stream(dev))
@@ -410,7 +408,9 @@ class BnActFn(torch.autograd.Function):
             scale = gamma * invstd
             return scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd
 
-        relu = int(relu)
+        relu = int(relu)                                  # activation code: 0 none, 1 ReLU, 2 Mish
+        if relu == 2 and residual is not None:            # (before anything is launched or any running statistic moves)
+            raise StxError("BnActFn: Mish with a plain residual is not wired (no model of the family uses it)")
         sc1, sh1, m1, i1 = affine(z1, gamma1, beta1, bn1)
         two = z2 is not None
         if two:
@@ -419,9 +419,6 @@ class BnActFn(torch.autograd.Function):
         else:
             sc2 = sh2 = m2 = i2 = None
             y = bn_apply(z1, sc1, sh1, residual, None, None, relu)
-        relu = int(relu)                                  # activation code: 0 none, 1 ReLU, 2 Mish
-        if relu == 2 and residual is not None:
-            raise StxError("BnActFn: Mish with a plain residual is not wired (no model of the family uses it)")
         ctx.relu, ctx.two, ctx.has_res = relu, two, residual is not None
         ctx.train1 = bn1["training"]
         ctx.train2 = bn2["training"] if two else False

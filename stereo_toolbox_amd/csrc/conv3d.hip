@@ -671,6 +671,13 @@ constexpr int MW2_SLOT = MW2_EH * MW2_EW * MW2_VS;                  // floats pe
 constexpr int MW2_NF4 = (MW2_EH * MW2_EW * 8 + 255) / 256;          // staging float4 per thread
 constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed weights [tap][q][lane][4]
 
+// BS ("blocked sums"): the 27 x 32 products of an output element are not accumulated as ONE sequential fp32 chain of 864
+// fused multiply-adds but as nine chunks of 96 (one kh row of taps each, started from zero) that are then added up --
+// the rounding error of a sequential fp32 sum of n terms grows like n, that of c-term chunks like sqrt(n^2 / c + n c):
+// 2.9x smaller here, the level of the AVX-512 blocked sums of the reference's CPU path.  (Attribution on the emulator,
+// GwcNet_GC(192): these layers alone caused half of the product's distance from an fp64 evaluation.)  Cost: two more
+// accumulator sets in registers and 16 VALU adds per 48 MFMAs, issued in the shadow of the next chunk's MFMAs.
+template <bool BS>
 __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const ConvArgs& a = ma.c;
     STX_DYN_SMEM(smem);
@@ -745,6 +752,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     // (the finished output plane dprev) interleaved with the MFMA groups
     auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done, int dprev, int epi0) {
         float4 av[2][4], bv[2][4];
+        f32x16 tmp = zero16(), pend = zero16();                      // BS: chunk in progress / finished chunk not yet added
         auto load_tap = [&](int t9, int buf) {
             const int kh = t9 / 3, kw = t9 % 3;
             const float* sl = pbuf + abase + (kh * MW2_EW + kw) * MW2_VS;
@@ -761,12 +769,20 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
             STX_SCHED_BARRIER();
             const int cb = t9 & 1;
+            if (BS && t9 % 3 == 0) tmp = zero16();                   // (an all-zero C operand is an inline constant)
+            f32x16& dst = BS ? tmp : acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, acc, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, dst, 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, dst, 0, 0, 0);
+            }
+            if (BS) {
+                // the chunk that ended with the previous tap is added while this tap's MFMAs run (its last MFMA has
+                // retired by now); the last chunk of the plane is added at once (one MFMA latency per 144 MFMAs)
+                if (t9 == 3 || t9 == 6) acc += pend;
+                if (t9 % 3 == 2) { if (t9 == 8) acc += tmp; else pend = tmp; }
             }
             if (with_epi) {
                 // rows epi0 + t9 (and the last slice takes what is left of its half): 16 rows over 18 taps
@@ -1466,7 +1482,10 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         if ((long long)m2.ncols * a.Do < (1ll << 31)) {
             const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
             const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
-            hipFuncSetAttribute((const void*)conv3d_marchw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            // STX_MARCH_BS=0: one sequential accumulation chain per output (first version of the kernel; A/B)
+            static const int bs_env = getenv("STX_MARCH_BS") ? atoi(getenv("STX_MARCH_BS")) : 1;
+            hipFuncSetAttribute((const void*)conv3d_marchw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipFuncSetAttribute((const void*)conv3d_marchw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
             const int nk = Cin / 32, nn = stx_cdiv(Cout, 32);
             for (int ns = 0; ns < nn; ++ns)
@@ -1478,7 +1497,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
-                    hipLaunchKernelGGL(conv3d_marchw_kernel, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
+                    if (bs_env) hipLaunchKernelGGL(conv3d_marchw_kernel<true>, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
+                    else hipLaunchKernelGGL(conv3d_marchw_kernel<false>, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
                 }
             return stx_check_launch("conv3d_fwd(march v2)");
         }

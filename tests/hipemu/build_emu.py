@@ -17,7 +17,25 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DSTX_HIPEMU", "-ffp-contra
          "-Wno-unused-value", "-Wno-deprecated-declarations", "-I", HERE, "-I", CSRC]
 
 
-def build_emu(force=False, verbose=False):
+def asan_runtime():
+    """Shared AddressSanitizer runtime of the emulator's compiler (to LD_PRELOAD into the python process)."""
+    r = subprocess.run([CXX, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = os.path.realpath(r.stdout.strip())
+    return p if os.path.isfile(p) else None
+
+
+def build_emu(force=False, verbose=False, asan=None):
+    """asan (default: environment STX_EMU_ASAN=1): AddressSanitizer build into _build_asan/ -- out-of-bounds reads and
+    writes of kernel code on the tensors' host buffers and on the emulated LDS abort the process (SURVEY.md section 5:
+    the GPU would read / write past the buffer silently).  The python process must LD_PRELOAD asan_runtime()."""
+    global OUT, LIB
+    if asan is None:
+        asan = os.environ.get("STX_EMU_ASAN") == "1"
+    flags = list(FLAGS)
+    if asan:
+        OUT = os.path.join(HERE, "_build_asan")
+        LIB = os.path.join(OUT, "libstx_emu.so")
+        flags += ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-shared-libsan"]
     os.makedirs(OUT, exist_ok=True)
     deps = [os.path.join(HERE, "hipemu.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -28,7 +46,7 @@ def build_emu(force=False, verbose=False):
         objs.append(o)
         newest = max(os.path.getmtime(p) for p in [s] + deps)
         if force or not os.path.exists(o) or os.path.getmtime(o) < newest:
-            jobs.append([CXX, *FLAGS, "-c", s, "-o", o])
+            jobs.append([CXX, *flags, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -41,7 +59,7 @@ def build_emu(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([CXX, "-shared", "-fPIC", *objs, "-o", LIB])
+        run([CXX, "-shared", "-fPIC", *(["-fsanitize=address", "-shared-libsan"] if asan else []), *objs, "-o", LIB])
     return LIB
 
 

@@ -1,0 +1,249 @@
+"""SURVEY.md section 5 hygiene for the hand-written kernels.
+
+* run-to-run BITWISE reproducibility of every kernel that is deterministic by construction (no float atomics: builders,
+  convolutions, weight gradients, BatchNorm passes, heads, classifier tails, depth-wise convs).  A data race or an
+  order-dependent reduction shows up as a differing bit on the GPU (`-m gpu`); on the emulator the test pins the contract.
+  (Not covered, by design: stx_sampled_volume_bwd accumulates right-feature gradients with float atomics like the
+  reference's gather backward.)
+* finite-difference ("gradcheck-style") checks of every custom autograd backward of stereo_toolbox_amd/ops.py through the
+  PRODUCT host code on the emulator build of the kernels: directional derivative (f(x + e v) - f(x - e v)) / 2e against
+  <analytic grad, v>, tiny shapes, fp32 (the kernels have no fp64 path), one random direction per input.
+"""
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.backends import be, ndhwc, ptr  # noqa: F401
+from tests.test_kernels import pack
+
+
+def _twice(be, fn, outs_fn):
+    """fn(outs) launches kernels writing into the tensors of `outs`; run on two fresh output sets, compare bit for bit."""
+    a, b = outs_fn(), outs_fn()
+    fn(a)
+    fn(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x.cpu(), y.cpu()), f"output {i} differs between two runs"
+
+
+def test_run_to_run_bitwise_reproducibility(be):
+    big = be.name == "hip"
+    torch.manual_seed(77)
+    # ---- cost volume (GwcNet_GC channel configuration), forward and backward
+    B, H, W, D = (1, 24, 120, 48) if big else (1, 2, 40, 20)
+    Lg, Rg = be.dev(torch.randn(B, 320, H, W)), be.dev(torch.randn(B, 320, H, W))
+    Lc, Rc = be.dev(torch.randn(B, 12, H, W)), be.dev(torch.randn(B, 12, H, W))
+    gv = be.dev(torch.randn(B, D, H, W, 64))
+    _twice(be, lambda o: be.call("stx_cost_volume_fwd", ptr(Lg), ptr(Rg), 320, 40, ptr(Lc), ptr(Rc), 12, None, ptr(o[0]),
+                                 B, H, W, D, 1), lambda: [be.empty(B, D, H, W, 64)])
+    _twice(be, lambda o: be.call("stx_cost_volume_bwd", ptr(gv), ptr(Lg), ptr(Rg), 320, 40, 12, ptr(o[0]), ptr(o[1]),
+                                 ptr(o[2]), ptr(o[3]), B, H, W, D, 1),
+           lambda: [be.empty(B, 320, H, W), be.empty(B, 320, H, W), be.empty(B, 12, H, W), be.empty(B, 12, H, W)])
+    # ---- convolutions: march (32->32), implicit GEMM (64->64), stride 2, 1x1, transposed; + BN partial sums
+    Dv, Hv, Wv = (12, 24, 80) if big else (3, 5, 37)
+    for Cin, Cout, ks, s in ((32, 32, 3, 1), (64, 32, 3, 1), (64, 64, 3, 1), (32, 64, 3, 2), (64, 64, 1, 1), (128, 128, 3, 1)):
+        if not big and Cin == 128:
+            continue
+        x = be.dev(torch.randn(1, Dv, Hv, Wv, Cin))
+        wp = pack(be, torch.randn(Cout, Cin, ks, ks, ks) * 0.1, 0)
+        pad = ks // 2
+        Do, Ho, Wo = [(d + 2 * pad - ks) // s + 1 for d in (Dv, Hv, Wv)]
+        nb = be.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+        _twice(be, lambda o: be.call("stx_conv3d_fwd", ptr(x), ptr(wp), ptr(o[0]), None, None, None, ptr(o[1]), 1, Dv, Hv, Wv,
+                                     Cin, Cout, ks, s, 0),
+               lambda: [be.empty(1, Do, Ho, Wo, Cout), be.empty(nb, 2, Cout)])
+        if Cin % 32 == 0 and Cout % 32 == 0:
+            gy = be.dev(torch.randn(1, Do, Ho, Wo, Cout))
+            n = be.raw("stx_conv3d_wgrad_workspace_floats")(1, Do, Ho, Wo, Cin, Cout, ks, s)
+            ws = be.empty(n)
+            _twice(be, lambda o: be.call("stx_conv3d_wgrad", ptr(x), ptr(gy), ptr(o[0]), ptr(ws), 1, Dv, Hv, Wv, Cin, Do, Ho,
+                                         Wo, Cout, ks, s), lambda: [be.empty(Cout, Cin, ks ** 3)])
+    x = be.dev(torch.randn(1, Dv, Hv, Wv, 64))
+    wp = pack(be, torch.randn(64, 32, 3, 3, 3) * 0.1, 2)
+    nb = be.raw("stx_deconv3d_fwd_blocks")(Dv, Hv, Wv)
+    _twice(be, lambda o: be.call("stx_deconv3d_fwd", ptr(x), ptr(wp), ptr(o[0]), None, None, None, ptr(o[1]), 1, Dv, Hv, Wv,
+                                 64, 32, 2 * Dv, 2 * Hv, 2 * Wv, 0),
+           lambda: [be.empty(1, 2 * Dv, 2 * Hv, 2 * Wv, 32), be.empty(nb, 2, 32)])
+    # ---- classifier tail
+    x = be.dev(torch.randn(1, Dv, Hv, Wv, 32))
+    w1 = be.dev(torch.randn(1, 32, 27) * 0.1)
+    gy = be.dev(torch.randn(1, Dv, Hv, Wv))
+    ws = be.empty(be.raw("stx_conv3d_c1_wgrad_workspace_floats")(32))
+    _twice(be, lambda o: be.call("stx_conv3d_c1_fwd", ptr(x), ptr(w1), None, ptr(o[0]), 1, Dv, Hv, Wv, 32),
+           lambda: [be.empty(1, Dv, Hv, Wv)])
+    _twice(be, lambda o: be.call("stx_conv3d_c1_wgrad", ptr(x), ptr(gy), ptr(o[0]), ptr(ws), 1, Dv, Hv, Wv, 32),
+           lambda: [be.empty(1, 32, 27)])
+    _twice(be, lambda o: be.call("stx_conv3d_c1_dgrad", ptr(gy), ptr(w1), ptr(o[0]), 1, Dv, Hv, Wv, 32),
+           lambda: [be.empty(1, Dv, Hv, Wv, 32)])
+    # ---- train-mode BatchNorm passes
+    nvox, C = Dv * Hv * Wv, 32
+    z, g = be.dev(torch.randn(nvox, C)), be.dev(torch.randn(nvox, C))
+    sc, sh = be.dev(torch.rand(C) + 0.5), be.dev(torch.randn(C) * 0.1)
+    mean, inv = be.dev(torch.randn(C) * 0.1), be.dev(torch.rand(C) + 0.5)
+    part = be.dev(torch.randn(300, 2, C).abs())
+    _twice(be, lambda o: be.call("stx_bn_finalize", ptr(part), 300, C, float(nvox), ptr(sc), ptr(sh), None, None, 0.1, 1e-5,
+                                 ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3])), lambda: [be.empty(C) for _ in range(4)])
+    _twice(be, lambda o: be.call("stx_bn_apply", ptr(z), ptr(sc), ptr(sh), None, None, None, ptr(o[0]), nvox, C, 1),
+           lambda: [be.empty(nvox, C)])
+    NB = be.raw("stx_bn_reduce_blocks")()
+    scratch = be.empty(NB, 3, C)
+    _twice(be, lambda o: be.call("stx_bn_bwd_reduce2", ptr(g), None, ptr(z), ptr(mean), ptr(inv), None, None, None, ptr(sc),
+                                 ptr(sh), None, None, ptr(scratch), ptr(o[0]), nvox, C, 1), lambda: [be.empty(3, C)])
+    sums = be.dev(torch.randn(3, C))
+    _twice(be, lambda o: be.call("stx_bn_bwd_apply2", ptr(g), None, ptr(z), ptr(mean), ptr(inv), ptr(sc), None, None, None,
+                                 None, ptr(sc), ptr(sh), None, None, ptr(sums), ptr(o[0]), None, None, nvox, C, 1),
+           lambda: [be.empty(nvox, C)])
+    # ---- regression head
+    Bh, Dc, Hc, Wc = (1, 12, 16, 40) if big else (1, 4, 5, 7)
+    Dh, Hh, Wh = 4 * Dc, 4 * Hc, 4 * Wc
+    cost = be.dev(torch.randn(Bh, Dc, Hc, Wc) * 3)
+    _twice(be, lambda o: be.call("stx_head_fwd", ptr(cost), ptr(o[0]), ptr(o[1]), Bh, Dc, Hc, Wc, Dh, Hh, Wh),
+           lambda: [be.empty(Bh, Hh, Wh), be.empty(Bh, Hh, Wh, 2)])
+    disp, stats = be.empty(Bh, Hh, Wh), be.empty(Bh, Hh, Wh, 2)
+    be.call("stx_head_fwd", ptr(cost), ptr(disp), ptr(stats), Bh, Dc, Hc, Wc, Dh, Hh, Wh)
+    gd = be.dev(torch.randn(Bh, Hh, Wh))
+    ws = be.empty(be.raw("stx_head_bwd_workspace_floats")(Bh, Dc, Hh, Wh))
+    _twice(be, lambda o: be.call("stx_head_bwd", ptr(gd), ptr(cost), ptr(disp), ptr(stats), ptr(o[0]), ptr(ws), Bh, Dc, Hc,
+                                 Wc, Dh, Hh, Wh), lambda: [be.empty(Bh, Dc, Hc, Wc)])
+    # ---- ACVNet depth-wise patch convolution and its weight gradient
+    Cp = 40
+    xp, gp = be.dev(torch.randn(1, Dv, Hv, Wv, Cp)), be.dev(torch.randn(1, Dv, Hv, Wv, Cp))
+    wdw = be.dev(torch.randn(Cp, 9))
+    dil = be.dev(torch.tensor([1] * 2 + [2] * 4 + [3] * 4, dtype=torch.int32))
+    _twice(be, lambda o: be.call("stx_dwconv_hw_fwd", ptr(xp), ptr(wdw), ptr(dil), ptr(o[0]), 1, Dv, Hv, Wv, Cp, 0),
+           lambda: [be.empty(1, Dv, Hv, Wv, Cp)])
+    wsd = be.empty(be.raw("stx_dwconv_hw_wgrad_workspace_floats")(Cp))
+    _twice(be, lambda o: be.call("stx_dwconv_hw_wgrad", ptr(xp), ptr(gp), ptr(dil), ptr(o[0]), ptr(wsd), 1, Dv, Hv, Wv, Cp),
+           lambda: [be.empty(Cp, 9)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _directional(fn, inputs, eps=3e-3, tol=3e-2, seed=0):
+    """fn(*inputs) -> tensor (or list of tensors).  Checks <grad_i, v_i> against the central difference for every input."""
+    g = torch.Generator().manual_seed(seed)
+
+    def flat(y):
+        return torch.cat([t.reshape(-1) for t in y]) if isinstance(y, (list, tuple)) else y.reshape(-1)
+
+    xs = [t.clone().requires_grad_() for t in inputs]
+    y = flat(fn(*xs))
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    for i, x in enumerate(xs):
+        v = torch.randn(x.shape, generator=g)
+        v *= float(x.detach().abs().mean()) / (v.norm() / (x.numel() ** 0.5))     # step relative to the input's magnitude
+        with torch.no_grad():
+            args_p = [t.detach() + (eps * v if j == i else 0) for j, t in enumerate(inputs)]
+            args_m = [t.detach() - (eps * v if j == i else 0) for j, t in enumerate(inputs)]
+            fd = ((flat(fn(*args_p)).double() - flat(fn(*args_m)).double()) * gy.double()).sum().item() / (2 * eps)
+        an = (x.grad.double() * v.double()).sum().item()
+        scale = max(abs(an), abs(fd), 1e-3 * (x.grad.norm().item() * v.norm().item()))
+        assert abs(an - fd) <= tol * scale, f"input {i}: analytic {an:.6e} vs finite difference {fd:.6e}"
+
+
+def test_finite_difference_gradients():
+    from stereo_toolbox_amd import ops
+    from stereo_toolbox_amd.aggregation import conv_block
+    from tests.emu_util import emu_product_path
+    torch.manual_seed(3)
+    with emu_product_path():
+        # builders (bilinear in the gwc features, linear in the concat features), both concat semantics
+        Lg, Rg, Lc, Rc = torch.randn(1, 16, 2, 19), torch.randn(1, 16, 2, 19), torch.randn(1, 4, 2, 19), torch.randn(1, 4, 2, 19)
+        for ml in (True, False):
+            _directional(lambda a, b, c, d: ops.cost_volume(a, b, c, d, 6, 4, mask_left=ml), [Lg, Rg, Lc, Rc], seed=1)
+        # ACVNet attention-weighted concat volume
+        prob = torch.softmax(torch.randn(1, 5, 2, 19), 1)
+        _directional(lambda a, b, p: ops.ac_volume(a, b, p, 5), [Lc, Rc, prob], seed=2)
+        # CFNet cascade volume (features only; the integer samples carry no gradient)
+        smp = torch.randint(-2, 9, (1, 3, 2, 19)).float()
+        _directional(lambda a, b, c, d: ops.sampled_volume(a, b, c, d, smp, 4), [Lg, Rg, Lc, Rc], seed=3)
+        # depth-wise patch convolution
+        dil = torch.tensor([1, 2], dtype=torch.int32)
+        _directional(lambda x, w: ops.dwconv_hw(x, w, dil), [torch.randn(1, 2, 5, 9, 8), torch.randn(8, 9)], seed=4)
+        # conv / transposed conv / classifier tail + train-mode BatchNorm (+ReLU, residual, second branch), as blocks
+        conv = nn.Conv3d(8, 8, 3, 1, 1, bias=False)
+        bn = nn.BatchNorm3d(8).train()
+        x = torch.randn(1, 3, 4, 9, 8)
+        res = torch.randn(1, 3, 4, 9, 8)
+        _directional(lambda a, w: _block(conv_block, a, conv, bn, w, None, None, relu=True),
+                     [x, conv.weight.detach().clone()], eps=3e-4, seed=5)   # (ReLU kinks: small step)
+        _directional(lambda a, w, g, b: _block(conv_block, a, conv, bn, w, g, b, relu=False),       # smooth: BN affine too
+                     [x, conv.weight.detach().clone(), torch.rand(8) + 0.5, torch.randn(8)], seed=16)
+        _directional(lambda a, r, w: _block(conv_block, a, conv, bn, w, None, None, relu=False, residual=r),
+                     [x, res, conv.weight.detach().clone()], seed=6)
+        conv2 = nn.Conv3d(8, 32, 3, 2, 1, bias=False)
+        bn2 = nn.BatchNorm3d(32).train()
+        _directional(lambda a, w: _block(conv_block, a, conv2, bn2, w, None, None, relu=True),
+                     [torch.randn(1, 4, 4, 10, 8), conv2.weight.detach().clone()], eps=3e-4, seed=7)
+        dc = nn.ConvTranspose3d(32, 8, 3, padding=1, output_padding=1, stride=2, bias=False)
+        bnd = nn.BatchNorm3d(8).train()
+        redir = nn.Conv3d(8, 8, 1, 1, 0, bias=False)
+        bnr = nn.BatchNorm3d(8).train()
+        xs, xf = torch.randn(1, 2, 2, 5, 32), torch.randn(1, 4, 4, 10, 8)
+
+        def hour(a, f, wd, wr):
+            dc.weight.data, redir.weight.data = wd, wr
+            for m in (bnd, bnr):
+                m.reset_running_stats()
+            return conv_block(a, dc, bnd, relu=True, second=(f, redir, bnr))
+        dc.weight.requires_grad_(False)
+        redir.weight.requires_grad_(False)
+        _directional(lambda a, f: hour(a, f, dc.weight.data, redir.weight.data), [xs, xf], eps=3e-4, seed=8)
+        c1 = nn.Conv3d(16, 1, 3, 1, 1, bias=False)
+        _directional(lambda a, w: _block(conv_block, a, c1, None, w, None, None), [torch.randn(1, 3, 4, 9, 16),
+                                                                                   c1.weight.detach().clone()], seed=9)
+        # regression head (both interpolation rules), soft-argmax, Mish
+        cost = torch.randn(1, 4, 5, 7) * 2
+        _directional(lambda c: ops.regression_head(c, 16, 20, 28), [cost], seed=10)
+        _directional(lambda c: ops.regression_head(c, 16, 20, 28, align_corners=True), [cost], seed=11)
+        p = torch.softmax(torch.randn(1, 12, 3, 5) * 2, 1)
+        _directional(lambda t: ops.softargmax(t, 12, True), [p], seed=12)
+        _directional(lambda t: ops.mish(t), [torch.randn(2, 3, 4, 8) * 2], seed=13)
+        # (the modal estimators are piecewise: their mode support jumps under any finite step -- their backward kernel is
+        #  checked against autograd through the oracle, whose gradients are pinned to the reference's: test_kernels.py)
+
+
+def _block(conv_block, x, conv, bn, w, gamma, beta, **kw):
+    """conv_block with the module's parameters replaced by graph tensors (so that finite differences can move them)."""
+    _set(conv, "weight", w)
+    if bn is not None:
+        bn.reset_running_stats()
+        if gamma is not None:
+            _set(bn, "weight", gamma)
+            _set(bn, "bias", beta)
+    return conv_block(x, conv, bn, **kw)
+
+
+def _set(mod, name, t):
+    """Replace a Parameter by a plain (possibly graph) tensor attribute of the same name."""
+    if name in mod._parameters:
+        del mod._parameters[name]
+    setattr(mod, name, t)
+
+
+@pytest.mark.slow
+def test_emulator_kernel_suite_under_address_sanitizer():
+    """ASAN host build of the kernel sources (tests/hipemu/build_emu.py, STX_EMU_ASAN=1): a slice of the kernel-level
+    suite -- every kernel family at ragged shapes -- runs in a subprocess with the sanitizer runtime preloaded; any
+    out-of-bounds access of kernel code on the tensors' buffers or on the emulated LDS aborts it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("STX_RUN_ASAN") != "1":
+        pytest.skip("opt-in (STX_RUN_ASAN=1): builds every kernel source with -fsanitize=address, ~7 min on 8 cores; "
+                    "last run: profiles/r03_asan_emulator.txt")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    from build_emu import asan_runtime
+    rt = asan_runtime()
+    if rt is None:
+        pytest.skip("no shared AddressSanitizer runtime next to the emulator's compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STX_EMU_ASAN="1", LD_PRELOAD=rt,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:detect_stack_use_after_return=0:use_sigaltstack=0")
+    sel = ("test_cost_volume_fwd_bwd or test_conv3d_fwd or test_deconv3d_fwd or test_conv3d_wgrad or test_bn_train_fwd_bwd "
+           "or test_head_fwd_bwd or test_conv3d_c1_fwd_wgrad or test_dwconv_hw_fwd_bwd or test_sampled_volume_fwd_bwd "
+           "or test_estimators or test_mish")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels.py", "-x", "-q", "-m", "not gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "AddressSanitizer" not in tail, tail

@@ -69,20 +69,22 @@ def test_gwcnet_eval_parity(env, concat):
     assert (got - ref).abs().max().item() < 1e-3
 
 
-def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None):
-    """Gradient parity.  With an fp64 evaluation of the oracle available the tolerance is calibrated:
-    the product may be at most 20x as far from fp64 as the fp32 oracle itself is, with `rtol` of the
-    tensor's max as the floor.  (Train-mode BN backward subtracts batch means -- catastrophic
-    cancellation for small-magnitude gradients -- so the fp32 error of a tensor is set by its
-    conditioning, which the oracle-vs-fp64 distance measures; the factor covers the difference
-    between a sequential K=27*Cin fp32 MFMA accumulation chain and MKL-DNN's blocked sums.)"""
+GRAD_FACTOR = 3.0     # product-vs-fp64 may be at most this many times the fp32 oracle's own distance from fp64
+PRED_FACTOR = 1.5
+
+
+def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=None):
+    """Gradient parity.  With an fp64 evaluation of the oracle available the tolerance is calibrated: the product may be
+    at most GRAD_FACTOR x as far from fp64 as the fp32 oracle itself is, with `rtol` of the tensor's max as the floor.
+    (Train-mode BN backward subtracts batch means -- catastrophic cancellation for small-magnitude gradients -- so the
+    fp32 error of a tensor is set by its conditioning, which the oracle-vs-fp64 distance measures.  Achieved on the GPU
+    at the benchmarked shape: 1.0-1.8 x, profiles/r02_parity_report.jsonl.)"""
     if rtol is None:
-        # floor: 0.2 % of the tensor's max on the emulator (bit-exact fp32 MFMA model, CPU 2-D convs);
-        # 1 % on the GPU, where the stock 2-D feature CNN runs MIOpen's benchmark-selected algorithms
-        # (Winograd / implicit GEMM, chosen by timing, i.e. varying from run to run) whose fp32 error
-        # is larger than MKL-DNN's and is amplified by the train-mode BatchNorms downstream.
-        rtol = 1e-2 if next(model.parameters()).is_cuda else 2e-3
+        # floor: 0.2 % of the tensor's max on the emulator (bit-exact fp32 MFMA model, CPU 2-D convs); 0.5 % on the GPU,
+        # where the stock 2-D feature CNN runs MIOpen's benchmark-selected algorithms (varying from run to run)
+        rtol = 5e-3 if next(model.parameters()).is_cuda else 2e-3
     worst = 0.0
+    worst_ratio, worst_key = 0.0, None
     n = 0
     for k, p in model.named_parameters():
         if skip_prefix and k.startswith(skip_prefix):
@@ -96,17 +98,35 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None):
             r64 = ref64_sd[k].grad
             e_prod = (p.grad.cpu().double() - r64).abs().max().item()
             e_orc = (r.double() - r64).abs().max().item()
-            tol = max(rtol * scale, 20 * e_orc) + 1e-6
+            tol = max(rtol * scale, GRAD_FACTOR * e_orc) + 1e-6
+            ratio = e_prod / max(e_orc, rtol * scale / GRAD_FACTOR, 1e-30)
+            if ratio > worst_ratio:
+                worst_ratio, worst_key = ratio, k
         else:
             e_prod = (p.grad.cpu() - r).abs().max().item()
             tol = rtol * scale + 1e-6
         worst = max(worst, e_prod / (scale + 1e-8))
         assert e_prod <= tol, f"{k}: grad err {e_prod:.3e} vs scale {scale:.3e} (tol {tol:.3e})"
         n += 1
+    if log is not None:
+        log(worst_rel_to_max=worst, worst_ratio_to_oracle_fp32_error=worst_ratio, worst_ratio_tensor=worst_key, tensors=n)
     return n, worst
 
 
-def test_gwcnet_gc_train_parity(env):
+def _check_preds(preds, rp, rp64):
+    """Train-mode predictions: batch-stat BN re-normalises every layer, which amplifies fp32 rounding differences between
+    two correct implementations -- the product must be as close to the oracle's fp64 evaluation as the fp32 oracle is
+    (x PRED_FACTOR), floor 1e-3 px (the eval-mode bar), never worse than 5e-3 px."""
+    worst = 0.0
+    for a, b, c in zip(preds, rp, rp64):
+        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
+        e_orc = (b.detach().double() - c.detach()).abs().max().item()
+        assert e_prod < max(1e-3, PRED_FACTOR * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+        worst = max(worst, e_prod / max(e_orc, 1e-3 / PRED_FACTOR))
+    return worst
+
+
+def test_gwcnet_gc_train_parity(env, parity_log):
     from stereo_toolbox_amd.models import GwcNet_GC
     H, W, D, B = _shape(env)
     m, sd = _filled(GwcNet_GC, D)
@@ -130,12 +150,9 @@ def test_gwcnet_gc_train_parity(env):
             for k, v in sd.items()}
     rp64 = O.gwcnet_forward(sd64, left.double(), right.double(), D, True, training=True)
     O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
-    for a, b, c in zip(preds, rp, rp64):
-        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
-        e_orc = (b.detach().double() - c.detach()).abs().max().item()
-        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+    _check_preds(preds, rp, rp64)
     assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
-    n, worst = _check_grads(m, ref_sd, sd64)
+    n, worst = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"gwcnet_gc_train_grads[{env.name}]", **f))
     assert n > 250
     msd = m.state_dict()
     for k, v in cx.new_stats.items():   # BN running statistics updated like torch's
@@ -166,7 +183,7 @@ def test_acvnet_eval_parity(env, flags):
     assert (got - ref).abs().max().item() < 1e-3
 
 
-def test_acvnet_train_parity(env):
+def test_acvnet_train_parity(env, parity_log):
     from stereo_toolbox_amd.models import ACVNet
     H, W, D, B = _acv_shape(env)
     m, sd = _filled(ACVNet, D)
@@ -185,11 +202,8 @@ def test_acvnet_train_parity(env):
     rp64 = O.acvnet_forward(sd64, left.double(), right.double(), D, training=True)
     O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
     assert len(preds) == 4          # [pred_attention, pred0, pred1, pred2] (acv.py:235)
-    for a, b, c in zip(preds, rp, rp64):
-        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
-        e_orc = (b.detach().double() - c.detach()).abs().max().item()
-        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
-    n, _ = _check_grads(m, ref_sd, sd64)
+    _check_preds(preds, rp, rp64)
+    n, _ = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"acvnet_train_grads[{env.name}]", **f))
     assert n > 280
 
 
@@ -220,10 +234,7 @@ def test_psmnet_aggregation_parity(env):
             for k, v in sd.items()}
     rp64 = O.psmnet_aggregate(O.Ctx(sd64, True), fl.double(), fr.double(), D, 4 * h4, 4 * w4)
     sum(p.sum() * w for p, w in zip(rp64, (0.5, 0.7, 1.0))).backward()
-    for a, b, c in zip(preds, rp, rp64):
-        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
-        e_orc = (b.detach().double() - c.detach()).abs().max().item()
-        assert e_prod < max(1e-3, 3 * e_orc) and e_prod < 5e-3, (e_prod, e_orc)
+    _check_preds(preds, rp, rp64)
     _check_grads(m, ref_sd, sd64, skip_prefix="feature_extraction")
 
 
@@ -336,42 +347,39 @@ def test_full_size_eval_parity(tag, parity_log):
     assert e_mean < 3e-4
 
 
-@pytest.mark.gpu
-def test_gwcnet_gc_full_size_train_step_parity(parity_log):
-    """The BENCHMARKED workload (BASELINE.json configs[2]): one GwcNet_GC(192) train step on a 576x960 pair, batch 1 --
-    4 predictions, loss, 9 named gradients and a BN running mean against the reference's own fp64 run
-    (tests/golden/fullsize_gwc_gc_train.npz, generated from /root/reference).  Tolerances are calibrated with the distance
-    of the reference's fp32 run from its fp64 run (stored per tensor): batch-stat BN amplifies fp32 rounding between two
-    correct implementations, so the product must be as close to fp64 as fp32 arithmetic allows -- 3x (predictions) /
-    20x (gradients, as in _check_grads) the reference's own fp32 distance, floors 1e-3 px and 1 % of the tensor's max."""
-    from stereo_toolbox_amd.models import GwcNet_GC
+def _full_size_train_step(ctor, gold_name, B, tag, parity_log, rm_module):
+    """One train step of `ctor`(192) on B 576x960 pairs against the REFERENCE's own fp64 run (fixture generated from
+    /root/reference by tests/golden/make_golden_fullsize*.py).  Tolerances are calibrated with the distance of the
+    reference's fp32 run from its fp64 run (stored per tensor): batch-stat BN amplifies fp32 rounding between two correct
+    implementations, so the product must be as close to fp64 as fp32 arithmetic allows -- PRED_FACTOR x (predictions,
+    floor 1e-3 px) / GRAD_FACTOR x (gradients, floor 0.5 % of the tensor's max) the reference's own fp32 distance."""
     from stereo_toolbox_amd.utils import state_dict_digest
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
-    gold = _gold("fullsize_gwc_gc_train.npz")
+    gold = _gold(gold_name)
     H, W, D = 576, 960, 192
-    m, sd = _filled(GwcNet_GC, D)
+    m, sd = _filled(ctor, D)
     assert state_dict_digest(sd) == int(gold["digest"]), "filler weights differ from the fixture's"
     m = m.cuda().train()
-    left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
-    gt = synthetic_tensor((1, H, W), 3, lo=0.0, hi=190.0)
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    gt = synthetic_tensor((B, H, W), 3, lo=0.0, hi=190.0)
     preds = m(left.cuda(), right.cuda())
     loss = O.smooth_l1_multi(preds, gt.cuda(), D, LOSS_W)
     loss.backward()
     torch.cuda.synchronize()
     s = int(gold["stride"])
     rec = {}
+    assert len(preds) == 4
     for i, p in enumerate(preds):
         ref64 = torch.from_numpy(gold[f"pred{i}_64"])
         e_prod = (p.detach().cpu()[:, ::s, ::s].double() - ref64).abs().max().item()
         e_ref32 = float(gold[f"pred{i}_e32"])
         rec[f"pred{i}"] = (e_prod, e_ref32)
-        assert e_prod < max(1e-3, 3 * e_ref32), (i, e_prod, e_ref32)   # (reference fp32 itself: 1.3e-3 .. 4.6e-3 px here)
+        assert e_prod < max(1e-3, PRED_FACTOR * e_ref32), (i, e_prod, e_ref32)
     l64, l32 = float(gold["loss64"]), float(gold["loss32"])
     rec["loss"] = (abs(loss.item() - l64), abs(l32 - l64))
     assert abs(loss.item() - l64) < max(1e-4 * abs(l64), 5 * abs(l32 - l64)), (loss.item(), l64, l32)
     named = dict(m.named_parameters())
-    worst = 0.0
     for key in gold.files:
         if not key.startswith("grad64:"):
             continue
@@ -379,17 +387,36 @@ def test_gwcnet_gc_full_size_train_step_parity(parity_log):
         g = named[k].grad.detach().cpu()
         r64 = torch.from_numpy(gold[key])
         if g.shape != r64.shape:
-            g = g[:r64.shape[0]]                                            # dres3.conv5.0.weight: first 32 input channels stored
+            g = g[:r64.shape[0]]                                            # large tensors: leading slice stored
         e_prod = (g.double() - r64.double()).abs().max().item()
         e_ref32, scale = float(gold["grad_e32:" + k]), float(gold["grad_scale:" + k])
         rec["grad:" + k] = (e_prod / scale, e_ref32 / scale)
-        worst = max(worst, e_prod / scale)
-        assert e_prod <= max(1e-2 * scale, 20 * e_ref32) + 1e-6, (k, e_prod, e_ref32, scale)
-    rm = m.dres2.conv4[0][1].running_mean.detach().cpu()
+        assert e_prod <= max(5e-3 * scale, GRAD_FACTOR * e_ref32) + 1e-6, (k, e_prod, e_ref32, scale)
+    rm = rm_module(m).running_mean.detach().cpu()
     rm64 = torch.from_numpy(gold["rm64:dres2.conv4.0.1"])
     assert (rm - rm64).abs().max().item() < 1e-4 * max(1.0, rm64.abs().max().item())
-    parity_log("full_size_train_step[gwc_gc_576x960]",
+    parity_log(f"full_size_train_step[{tag}]",
                **{k: {"product_vs_ref_fp64": float(f"{a:.4e}"), "ref_fp32_vs_fp64": float(f"{b:.4e}")} for k, (a, b) in rec.items()})
+
+
+@pytest.mark.gpu
+def test_gwcnet_gc_full_size_train_step_parity(parity_log):
+    """The BENCHMARKED workload (BASELINE.json configs[2]): one GwcNet_GC(192) train step on a 576x960 pair, batch 1 --
+    4 predictions, loss, 9 named gradients and a BN running mean (tests/golden/fullsize_gwc_gc_train.npz)."""
+    from stereo_toolbox_amd.models import GwcNet_GC
+    _full_size_train_step(GwcNet_GC, "fullsize_gwc_gc_train.npz", 1, "gwc_gc_576x960", parity_log,
+                          lambda m: m.dres2.conv4[0][1])
+
+
+@pytest.mark.gpu
+def test_acvnet_full_size_train_step_parity(parity_log):
+    """BASELINE.json configs[3]'s per-GPU workload: one ACVNet(192) train step on a batch of TWO 576x960 pairs (global
+    batch 16 over 8 GPUs) -- [pred_attention, pred0, pred1, pred2] (reference acv.py:233-235), loss, 13 named gradients
+    (attention branch, patch convs, windowed attention, concatconv, 2-D CNN) and a BN running mean
+    (tests/golden/fullsize_acv_train.npz)."""
+    from stereo_toolbox_amd.models import ACVNet
+    _full_size_train_step(ACVNet, "fullsize_acv_train.npz", 2, "acv_576x960_b2", parity_log,
+                          lambda m: m.dres2.conv4[0][1])
 
 
 @pytest.mark.gpu

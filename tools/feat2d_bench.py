@@ -1,27 +1,55 @@
-"""Times the stock-PyTorch 2-D feature extractor (fwd+bwd, both views) in NCHW vs channels_last."""
-import os, sys, time, torch
+"""Times the stock-PyTorch 2-D feature extractor of GwcNet_GC (fwd+bwd, both views, 576x960) in NCHW and channels_last.
+
+  python tools/feat2d_bench.py [--fmt nchw|nhwc|both] [--iters N] [--no-eval] [--no-benchmark]
+Run under `rocprofv3 --kernel-trace --stats` (with a warm MIOPEN_USER_DB_PATH, otherwise the solver search floods the
+trace) for the per-kernel split: convolutions / MIOpen BatchNorm / elementwise / layout transposes."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from stereo_toolbox_amd.models.GwcNet.gwcnet import feature_extraction
-torch.backends.cudnn.benchmark = True
+from stereo_toolbox_amd.models.GwcNet.gwcnet import feature_extraction  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fmt", default="both")
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--no-eval", action="store_true")
+ap.add_argument("--no-benchmark", action="store_true")
+a = ap.parse_args()
+torch.backends.cudnn.benchmark = not a.no_benchmark
 dev = torch.device("cuda:0")
-for fmt in ("nchw", "nhwc"):
+for fmt in (("nchw", "nhwc") if a.fmt == "both" else (a.fmt,)):
     m = feature_extraction(True, 12).to(dev).train()
     x = [torch.randn(1, 3, 576, 960, device=dev) for _ in range(2)]
     if fmt == "nhwc":
         m = m.to(memory_format=torch.channels_last)
         x = [t.contiguous(memory_format=torch.channels_last) for t in x]
+
     def step():
         outs = [m(t) for t in x]
         loss = sum(o["gwc_feature"].square().mean() + o["concat_feature"].square().mean() for o in outs)
         loss.backward()
-    for _ in range(4): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    for _ in range(4):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
     print(fmt, "fwd+bwd both views: %.2f ms" % (dt * 1e3), flush=True)
+    if a.no_eval:
+        continue
     with torch.no_grad():
         m.eval()
-        for _ in range(3): [m(t) for t in x]
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(10): [m(t) for t in x]
-        torch.cuda.synchronize(); print(fmt, "eval fwd both views: %.2f ms" % ((time.perf_counter() - t0) / 10 * 1e3), flush=True)
+        for _ in range(3):
+            [m(t) for t in x]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            [m(t) for t in x]
+        torch.cuda.synchronize()
+        print(fmt, "eval fwd both views: %.2f ms" % ((time.perf_counter() - t0) / a.iters * 1e3), flush=True)

@@ -281,7 +281,8 @@ def main(argv=None):
 
     from stereo_toolbox_amd import models, ops
     from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
-    from stereo_toolbox_amd.utils import fill_state_dict
+    from stereo_toolbox_amd.utils import fill_state_dict, use_tuning_db
+    tuning_db = None if emu else use_tuning_db()      # MIOpen find results of the 2-D CNN's shapes (warm-up time only)
 
     model_name, mode, H, W, B, metric = CONFIGS[args.config]
     H, W, B = args.height or H, args.width or W, args.batch or B
@@ -410,7 +411,9 @@ def main(argv=None):
                                      "none (single rank: flat fp32 buffer packed, no collective)" if world == 1 else
                                      f"flat fp32 buffer, {gsync.nb} overlapped all-reduce range(s)" if gsync.overlap else
                                      "flat fp32 buffer, 1 all-reduce after backward"),
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hipGraph replay" if args.graph else "eager",
+                       "miopen_user_db": (os.path.relpath(tuning_db, ROOT) if tuning_db and tuning_db.startswith(ROOT)
+                                          else tuning_db)},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -140,6 +140,12 @@ int stx_scale_channels(const float* x, const float* s, float* out, long long nvo
  * nn.BatchNorm3d of convbn_3d (models/GwcNet/submodule.py:17-20) in train() mode and the adds/ReLUs that follow it
  * (GwcNet/gwcnet.py:96-103,185; PSMNet/stackhourglass.py:31-48). */
 int stx_bn_reduce_blocks(void);
+/* Batch statistics of a channels-last activation z [nvox][C] whose producer has no fused epilogue -- the nn.BatchNorm2d
+ * layers behind the MIOpen convolutions of the 2-D feature CNN (models/GwcNet/gwcnet.py:12-65 `convbn`, BasicBlock):
+ * partials [stx_bn_stats_rows(nvox, C)][2][C] = per-workgroup (sum z, sum z^2), the row format stx_bn_finalize takes.
+ * C: multiple of 4 with C/4 dividing 256. */
+int stx_bn_stats_rows(long long nvox, int C);
+int stx_bn_stats(const float* z, float* partials, long long nvox, int C, void* stream);
 /* partials [nrows][2][C] (from the conv epilogue) -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
  * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance, like torch. */
 int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,

@@ -67,6 +67,8 @@ SIGNATURES = {
     "stx_sampled_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # bn.hip
     "stx_bn_reduce_blocks": [],
+    "stx_bn_stats_rows": [_L, _I],
+    "stx_bn_stats": [_P, _P, _L, _I, _P],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

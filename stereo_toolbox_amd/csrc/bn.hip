@@ -221,6 +221,47 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     }
 }
 
+// partials[blk][0][C] = sum z, partials[blk][1][C] = sum z^2 over the workgroup's voxels: batch statistics of a channels-last
+// activation whose producer has no fused epilogue (the MIOpen convolutions of the 2-D feature CNN; the 3-D convolutions
+// emit these sums themselves).  Same row format as the conv epilogues' slabs -> stx_bn_finalize.
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __restrict__ z, float* __restrict__ partials,
+                                                              size_t nvox, int C) {
+    __shared__ float red[BN_THREADS * 8];
+    const int tid = threadIdx.x;
+    const int CQ = C >> 2;
+    const int cq = tid % CQ, vl = tid / CQ, VPB = BN_THREADS / CQ;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    const size_t step = (size_t)gridDim.x * VPB;
+    size_t v = (size_t)blockIdx.x * VPB + vl;
+    for (; v + 3 * step < nvox; v += 4 * step) {                 // four independent 16-byte loads in flight per lane
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = stx_ld4(z + (v + u * step) * C + 4 * cq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s[0] += a[u].x; s[1] += a[u].y; s[2] += a[u].z; s[3] += a[u].w;
+            s[4] = fmaf(a[u].x, a[u].x, s[4]); s[5] = fmaf(a[u].y, a[u].y, s[5]);
+            s[6] = fmaf(a[u].z, a[u].z, s[6]); s[7] = fmaf(a[u].w, a[u].w, s[7]);
+        }
+    }
+    for (; v < nvox; v += step) {
+        const float4 a = stx_ld4(z + v * C + 4 * cq);
+        s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w;
+        s[4] = fmaf(a.x, a.x, s[4]); s[5] = fmaf(a.y, a.y, s[5]); s[6] = fmaf(a.z, a.z, s[6]); s[7] = fmaf(a.w, a.w, s[7]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[k * BN_THREADS + tid] = s[k];
+    __syncthreads();
+    for (int idx = tid; idx < 8 * CQ; idx += BN_THREADS) {
+        const int k = idx / CQ, q = idx % CQ;
+        float t = 0.f;
+        for (int j = q; j < BN_THREADS; j += CQ) t += red[k * BN_THREADS + j];      // fixed order: deterministic
+        partials[((size_t)blockIdx.x * 2 + (k >> 2)) * C + 4 * q + (k & 3)] = t;
+    }
+}
+
 // sums[m] = sum over rows of partials[r][m], fp64 accumulate; one workgroup per column.
 __global__ __launch_bounds__(BN_THREADS) void bn_colsum_kernel(const float* __restrict__ partials, int nrows, int M,
                                                                float* __restrict__ sums) {
@@ -318,6 +359,23 @@ extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double c
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     return stx_check_launch("bn_finalize");
+}
+
+extern "C" int stx_bn_stats_rows(long long nvox, int C) {
+    stx_begin();
+    if (C < 4 || C % 4 != 0 || BN_THREADS % (C / 4) != 0 || nvox < 1) return 0;
+    const long long vpb = BN_THREADS / (C / 4);
+    const long long g = (nvox + 4 * vpb - 1) / (4 * vpb);          // >= 4 voxels per lane before another workgroup is added
+    return (int)(g > BN_RED_BLOCKS ? BN_RED_BLOCKS : (g < 1 ? 1 : g));
+}
+
+extern "C" int stx_bn_stats(const float* z, float* partials, long long nvox, int C, void* stream) {
+    stx_begin();
+    STX_REQUIRE(z && partials && nvox > 0, "bn_stats: null operand");
+    STX_REQUIRE(C >= 4 && C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_stats: C=%d unsupported (multiple of 4 dividing 1024)", C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(stx_bn_stats_rows(nvox, C)), dim3(BN_THREADS), 0, (hipStream_t)stream, z, partials,
+                       (size_t)nvox, C);
+    return stx_check_launch("bn_stats");
 }
 
 extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2,

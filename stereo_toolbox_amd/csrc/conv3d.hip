@@ -672,12 +672,22 @@ constexpr int MW2_NF4 = (MW2_EH * MW2_EW * 8 + 255) / 256;          // staging f
 constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed weights [tap][q][lane][4]
 
 // BS ("blocked sums"): the 27 x 32 products of an output element are not accumulated as ONE sequential fp32 chain of 864
-// fused multiply-adds but as nine chunks of 96 (one kh row of taps each, started from zero) that are then added up --
-// the rounding error of a sequential fp32 sum of n terms grows like n, that of c-term chunks like sqrt(n^2 / c + n c):
-// 2.9x smaller here, the level of the AVX-512 blocked sums of the reference's CPU path.  (Attribution on the emulator,
-// GwcNet_GC(192): these layers alone caused half of the product's distance from an fp64 evaluation.)  Cost: two more
-// accumulator sets in registers and 16 VALU adds per 48 MFMAs, issued in the shadow of the next chunk's MFMAs.
-template <bool BS>
+// fused multiply-adds: the contribution of each of the three input planes (288 products) gets its own accumulator,
+// started from zero, and the three partial sums are added in the epilogue.  The rounding error of a sequential fp32 sum
+// of n terms grows like n, that of c-term chunks like sqrt(n^2 / c + n c): 1.7x smaller here.  (Attribution on the
+// emulator, GwcNet_GC(192): the sequential chains of these layers alone caused half of the product's distance from an
+// fp64 evaluation.)  Cost: three more accumulator sets in registers (six rotate in two 3-cycles instead of three in
+// one), two VALU adds per output element in the epilogue; the MFMA stream is unchanged.
+// (Finer chunks -- one accumulator per kh row, added to the running sum with VALU adds between the taps -- were tried
+//  first, GPU calls B/C/E of round 3: on the chip element 15 of the freshly written accumulator tuple came back without
+//  the last one to three MFMAs of its chain whenever hipcc placed its v_accvgpr_read first behind the minimal wait, in
+//  two of the three rotations; the host emulator and a stand-alone test of the same instruction pattern
+//  (tools/ubench/mfma_tail_read.hip) are correct.  Not pursued: every accumulator read of this kernel is at least 16 MFMAs
+//  behind the chain that wrote it.)
+// ILV: the eight ds_read_b128 of the NEXT tap are dealt one per two MFMAs of the current tap (sched_group_barrier) instead of
+// being issued as one 8 KB burst in front of them (a wave alone on its SIMD pays for its own read burst: MI355X guide,
+// "two waves per SIMD", item 7).
+template <int BS, int ILV = 0>
 __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const ConvArgs& a = ma.c;
     STX_DYN_SMEM(smem);
@@ -732,12 +742,12 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const float bs = (a.bias && n < ma.ncout) ? a.bias[ma.oo + n] : 0.f;
 
     // one output row (voxel) of a finished plane: partial sums of an earlier K slice, BN statistics, affine, residual, ReLU
-    auto emit_row = [&](const f32x16& done, int r, int dprev) {
+    auto emit_row = [&](const f32x16& done0, const f32x16& done1, const f32x16& done, int r, int dprev) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int oh = oh0 + th * MW2_R + row / MW2_MW, ow = ow0 + row % MW2_MW;
         if (oh < a.Ho && ow < a.Wo && n < ma.ncout && ma.ablate != 2) {
             const size_t idx = ((((size_t)b * a.Do + dprev) * a.Ho + oh) * a.Wo + ow) * ma.os + ma.oo + n;
-            float v = done[r];
+            float v = BS ? (done0[r] + done1[r]) + done[r] : done[r];        // BS: partial sums of the planes p-2, p-1, p
             if (ma.acc_in) v += ma.acc_in[idx];
             s1 += v;
             s2 = fmaf(v, v, s2);
@@ -750,9 +760,9 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
 
     // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
     // (the finished output plane dprev) interleaved with the MFMA groups
-    auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done, int dprev, int epi0) {
+    auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done0, const f32x16& done1,
+                         const f32x16& done, int dprev, int epi0) {
         float4 av[2][4], bv[2][4];
-        f32x16 tmp = zero16(), pend = zero16();                      // BS: chunk in progress / finished chunk not yet added
         auto load_tap = [&](int t9, int buf) {
             const int kh = t9 / 3, kw = t9 % 3;
             const float* sl = pbuf + abase + (kh * MW2_EW + kw) * MW2_VS;
@@ -767,58 +777,60 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
             if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
-            STX_SCHED_BARRIER();
+            if (!ILV) STX_SCHED_BARRIER();
             const int cb = t9 & 1;
-            if (BS && t9 % 3 == 0) tmp = zero16();                   // (an all-zero C operand is an inline constant)
-            f32x16& dst = BS ? tmp : acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, dst, 0, 0, 0);
-                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, dst, 0, 0, 0);
-                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, dst, 0, 0, 0);
-                dst = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, dst, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, acc, 0, 0, 0);
             }
-            if (BS) {
-                // the chunk that ended with the previous tap is added while this tap's MFMAs run (its last MFMA has
-                // retired by now); the last chunk of the plane is added at once (one MFMA latency per 144 MFMAs)
-                if (t9 == 3 || t9 == 6) acc += pend;
-                if (t9 % 3 == 2) { if (t9 == 8) acc += tmp; else pend = tmp; }
+            if (ILV && t9 + 1 < 9) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    STX_SCHED_GROUP(0x008, 2);
+                    STX_SCHED_GROUP(0x100, 1);
+                }
             }
             if (with_epi) {
                 // rows epi0 + t9 (and the last slice takes what is left of its half): 16 rows over 18 taps
                 const int r = epi0 + t9;
-                if (r < 16) emit_row(done, r, dprev);
+                if (r < 16) emit_row(done0, done1, done, r, dprev);
             }
             STX_SCHED_BARRIER();
         }
     };
-    // one input plane p (resident in `pbuf`): kd = 2 -> aOld (output p-1, finished here), kd = 1 -> aMid (output p),
-    // kd = 0 -> aNew (output p+1, starts here)
-    auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, float* nbuf, bool stage, f32x16& aOld, f32x16& aMid,
-                    f32x16& aNew) {
-        aNew = zero16();
+    // one input plane p (resident in `pbuf`): kd = 2 -> output p-1 (finished here), kd = 1 -> output p, kd = 0 -> output p+1
+    // (starts here).  BS = 0: one accumulator per output: aOld / aMid / aNew = pC / pE / pF (pA, pB, pD unused).
+    // BS = 1: one accumulator per (output, input plane): output p-1 = pA (plane p-2) + pB (plane p-1) + pC (this plane),
+    // output p = pD (plane p-1) + pE (this plane), output p+1 = pF (this plane); pC, pE, pF start from zero here.
+    auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, float* nbuf, bool stage, f32x16& pA, f32x16& pB,
+                    f32x16& pC, f32x16& pD, f32x16& pE, f32x16& pF) {
+        pF = zero16();
+        if (BS) { pC = zero16(); pE = zero16(); }
         const bool live = p >= 0 && p < a.Di;                        // planes outside the volume are zero padding
         const bool vOld = p - 1 >= d_lo && p - 1 < d_hi, vMid = p >= d_lo && p < d_hi, vNew = p + 1 >= d_lo && p + 1 < d_hi;
-        if (live && vOld) tap_plane(pbuf, 2, aOld, false, aOld, 0, 0);
+        if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, 0);
         // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
         // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
         if (stage) store_plane(nbuf);
         // output p-1 is complete: its 16 rows leave in the shadow of the next 18 taps (or on their own at the edges)
-        if (live && vMid) tap_plane(pbuf, 1, aMid, vOld, aOld, p - 1, 0);
+        if (live && vMid) tap_plane(pbuf, 1, pE, vOld, pA, pB, pC, p - 1, 0);
         else if (vOld) {
             // no MFMAs to hide behind: plain epilogue of rows 0..8
 #pragma unroll
-            for (int r = 0; r < 9; ++r) emit_row(aOld, r, p - 1);
+            for (int r = 0; r < 9; ++r) emit_row(pA, pB, pC, r, p - 1);
         }
-        if (live && vNew) tap_plane(pbuf, 0, aNew, vOld, aOld, p - 1, 9);
+        if (live && vNew) tap_plane(pbuf, 0, pF, vOld, pA, pB, pC, p - 1, 9);
         else if (vOld) {
 #pragma unroll
-            for (int r = 9; r < 16; ++r) emit_row(aOld, r, p - 1);
+            for (int r = 9; r < 16; ++r) emit_row(pA, pB, pC, r, p - 1);
         }
     };
 
     __syncthreads();                                                 // weights are in LDS
-    f32x16 acc0 = zero16(), acc1 = zero16(), acc2 = zero16();
+    f32x16 r0 = zero16(), r1 = zero16(), r2 = zero16(), r3 = zero16(), r4 = zero16(), r5 = zero16();
     while (u < u_end) {
         int d_lo, d_hi;
         {
@@ -837,17 +849,27 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         store_plane(planes);
         __syncthreads();
         int par = 0;
-        auto advance = [&](int p, f32x16& aOld, f32x16& aMid, f32x16& aNew) {
+        auto advance = [&](int p, f32x16& pA, f32x16& pB, f32x16& pC, f32x16& pD, f32x16& pE, f32x16& pF) {
             const bool stage = p + 1 <= d_hi && ma.ablate != 1;
             if (stage) load_plane(p + 1);                            // in flight during this plane's first 9 taps
-            step(p, d_lo, d_hi, planes + par * MW2_SLOT, planes + (par ^ 1) * MW2_SLOT, stage, aOld, aMid, aNew);
+            step(p, d_lo, d_hi, planes + par * MW2_SLOT, planes + (par ^ 1) * MW2_SLOT, stage, pA, pB, pC, pD, pE, pF);
             __syncthreads();                                         // plane p+1 is resident, plane p's buffer is free
             par ^= 1;
         };
-        for (int p = d_lo - 1; p <= d_hi; p += 3) {
-            advance(p, acc0, acc1, acc2);
-            if (p + 1 <= d_hi) advance(p + 1, acc1, acc2, acc0);
-            if (p + 2 <= d_hi) advance(p + 2, acc2, acc0, acc1);
+        if (BS) {
+            // after a step: output p becomes "old" (A <- D, B <- E), output p+1 "mid" (D <- F); the three freed sets are
+            // handed out so that the renaming is two 3-cycles (A D F) (B E C): three unrolled steps, as without BS
+            for (int p = d_lo - 1; p <= d_hi; p += 3) {
+                advance(p, r0, r1, r2, r3, r4, r5);
+                if (p + 1 <= d_hi) advance(p + 1, r3, r4, r1, r5, r2, r0);
+                if (p + 2 <= d_hi) advance(p + 2, r5, r2, r4, r0, r1, r3);
+            }
+        } else {
+            for (int p = d_lo - 1; p <= d_hi; p += 3) {
+                advance(p, r3, r4, r0, r5, r1, r2);                  // (aOld, aMid, aNew) = (r0, r1, r2) rotate
+                if (p + 1 <= d_hi) advance(p + 1, r3, r4, r1, r5, r2, r0);
+                if (p + 2 <= d_hi) advance(p + 2, r3, r4, r2, r5, r0, r1);
+            }
         }
     }
     if (a.stats) {
@@ -1105,9 +1127,57 @@ struct WgradArgs {
     int Dc, Hc, Wc, CC;
     int nHt, nWt, ntiles;
     int ablate;          // profiling only (STX_WGRAD_ABLATE): 1 = no tile staging, 2 = no MFMA loop
+    int v2;              // 1: straight-line MFMA loop per tap count (see wgrad_pairs), 0: first version (A/B: STX_WGRAD_V2)
 };
 
-template <int KS, int S, int TH, int TW, int NW, bool PIPE>
+// MFMA loop of the weight gradient over one staged tile for a wave that owns NA taps (3 or 4 of the 27 with eight waves):
+// the first version asked `t * NW + wave < T` in front of every MFMA (exec-mask juggling and a branch per tap, basic
+// blocks of one MFMA that nothing can be scheduled into); here the tap count is a compile-time constant chosen ONCE per
+// wave, each voxel pair is a straight line of NA MFMAs, and the NA + 1 LDS reads of the next pair are dealt one per MFMA
+// into their shadow instead of being issued as a burst in front of them.
+template <int NA, int TH, int TW, int S, int EWS>
+__device__ __forceinline__ void wgrad_pairs(const float* ftile, const float* ctile, const int (&toff)[NA], int i, int half,
+                                            f32x16 (&acc)[NA]) {
+    constexpr int PR = TW / 2;                                      // voxel pairs per tile row (even: 8 or 16)
+    constexpr int FSTR = S * EWS * 32, CSTR = TW * 32;              // floats between tile rows (fine / coarse)
+    float av[2][NA], bv[2];
+    // operand addresses: one base register per tap and row (+ immediate offsets for the pairs of the row: 256 B apart)
+    const float* f0 = ftile + half * 32 + i;
+    const float* c0 = ctile + half * 32 + i;
+    const float* fcur = f0;
+    const float* ccur = c0;
+    auto load_pair = [&](const float* fb, const float* cb_, int off, int buf) {
+        bv[buf] = cb_[off];
+#pragma unroll
+        for (int t = 0; t < NA; ++t) av[buf][t] = fb[toff[t] + off];
+    };
+    load_pair(fcur, ccur, 0, 0);
+#pragma unroll 1
+    for (int lh = 0; lh < TH; ++lh) {
+        const float* fnext = (lh + 1 < TH) ? fcur + FSTR : f0;       // (the last prefetch wraps: uniform pipeline depth)
+        const float* cnext = (lh + 1 < TH) ? ccur + CSTR : c0;
+#pragma unroll
+        for (int pp = 0; pp < PR; ++pp) {
+            const int cb = pp & 1;
+            if (pp + 1 < PR) load_pair(fcur, ccur, (pp + 1) * 64, cb ^ 1);
+            else load_pair(fnext, cnext, 0, cb ^ 1);
+#pragma unroll
+            for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][t], bv[cb], acc[t], 0, 0, 0);
+            STX_SCHED_GROUP(0x008, 1);
+            STX_SCHED_GROUP(0x100, 2);
+#pragma unroll
+            for (int t = 1; t < NA; ++t) {
+                STX_SCHED_GROUP(0x008, 1);
+                STX_SCHED_GROUP(0x100, 1);
+            }
+            STX_SCHED_BARRIER();
+        }
+        fcur = fnext;
+        ccur = cnext;
+    }
+}
+
+template <int KS, int S, int TH, int TW, int NW, bool PIPE, bool V2 = false>
 __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int PAD = KS / 2;
@@ -1200,6 +1270,37 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 const float bv = ctile[v * 32 + i];
                 const float av = ftile[(lh * EWS + lw) * 32 + i];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+            }
+        } else if (V2) {
+            if constexpr (V2 && NTAP >= 2 && NTAP * NW - T < NW) {
+            // straight-line loop: waves [0, T - (NTAP-1)*NW) own NTAP taps, the others NTAP - 1 (wave-uniform choice)
+            const int nfull = T - (NTAP - 1) * NW;
+            if (__builtin_amdgcn_readfirstlane(wave) < nfull) {
+                int toff[NTAP];
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    const int tap = t * NW + wave;
+                    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                    toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
+                                       : ((kd * EH + kh) * EWS + kw) * 32;
+                }
+                wgrad_pairs<NTAP, TH, TW, S, EWS>(ftile, ctile, toff, i, half, acc);
+            } else {
+                constexpr int N1 = NTAP >= 2 ? NTAP - 1 : 1;
+                int toff[N1];
+                f32x16 acc1[N1];
+#pragma unroll
+                for (int t = 0; t < N1; ++t) {
+                    const int tap = t * NW + wave;
+                    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                    toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
+                                       : ((kd * EH + kh) * EWS + kw) * 32;
+                    acc1[t] = acc[t];
+                }
+                wgrad_pairs<N1, TH, TW, S, EWS>(ftile, ctile, toff, i, half, acc1);
+#pragma unroll
+                for (int t = 0; t < N1; ++t) acc[t] = acc1[t];
+            }
             }
         } else {
             // address of operand A = (voxel part) + (tap part): tap offsets live in NTAP registers, the
@@ -1482,10 +1583,13 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         if ((long long)m2.ncols * a.Do < (1ll << 31)) {
             const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
             const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
-            // STX_MARCH_BS=0: one sequential accumulation chain per output (first version of the kernel; A/B)
-            static const int bs_env = getenv("STX_MARCH_BS") ? atoi(getenv("STX_MARCH_BS")) : 1;
-            hipFuncSetAttribute((const void*)conv3d_marchw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            hipFuncSetAttribute((const void*)conv3d_marchw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            // STX_MARCH_BS (read per call, A/B): 1 (default) = one accumulator per (output, input plane), summed in the
+            // epilogue; 0 = one sequential accumulation chain per output (first version of the kernel)
+            const int bs_env = getenv("STX_MARCH_BS") ? atoi(getenv("STX_MARCH_BS")) : 1;
+            const int ilv_env = getenv("STX_MARCH_ILV") ? atoi(getenv("STX_MARCH_ILV")) : 0;
+            void (*mk)(MarchArgs) = bs_env ? (ilv_env ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<1, 0>)
+                                           : (ilv_env ? conv3d_marchw_kernel<0, 1> : conv3d_marchw_kernel<0, 0>);
+            hipFuncSetAttribute((const void*)mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
             const int nk = Cin / 32, nn = stx_cdiv(Cout, 32);
             for (int ns = 0; ns < nn; ++ns)
@@ -1497,8 +1601,7 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
-                    if (bs_env) hipLaunchKernelGGL(conv3d_marchw_kernel<true>, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
-                    else hipLaunchKernelGGL(conv3d_marchw_kernel<false>, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
+                    hipLaunchKernelGGL(mk, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
                 }
             return stx_check_launch("conv3d_fwd(march v2)");
         }
@@ -1671,6 +1774,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     const bool pipe = wgrad_pipe(ks, stride, npairs);
     static const int ablate = getenv("STX_WGRAD_ABLATE") ? atoi(getenv("STX_WGRAD_ABLATE")) : 0;
     a.ablate = ablate;
+    a.v2 = getenv("STX_WGRAD_V2") ? atoi(getenv("STX_WGRAD_V2")) : 0;      // (read per call: A/B)
     int TH, TW;
     wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
     a.nHt = stx_cdiv(Hc, TH); a.nWt = stx_cdiv(Wc, TW);
@@ -1684,9 +1788,10 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
 #define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, PIPE_, LDS_)                                                           \
     {                                                                                                             \
         const size_t lds = (LDS_);                                                                                \
-        hipFuncSetAttribute((const void*)conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_>,                      \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-        hipLaunchKernelGGL((conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_>), grid, dim3(NW_ * 64), lds, st, a); \
+        void (*wk)(WgradArgs) = (a.v2 && KS_ == 3 && NW_ == 8) ? conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_, (KS_ == 3 && NW_ == 8)> \
+                                                               : conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_, false>; \
+        hipFuncSetAttribute((const void*)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+        hipLaunchKernelGGL(wk, grid, dim3(NW_ * 64), lds, st, a);                                                 \
     }
     if (ks == 3 && stride == 1) {
         if (TW == 16 && pipe) WG_LAUNCH(3, 1, 4, 16, 8, true, ((size_t)3 * 6 * 18 + 64) * 32 * 4)

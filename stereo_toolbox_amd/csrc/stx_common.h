@@ -12,6 +12,7 @@
 #define STX_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define stx_exp(x) expf(x)
 #define STX_SCHED_BARRIER() ((void)0)
+#define STX_SCHED_GROUP(mask, n) ((void)0)
 #define STX_OPAQUE_VGPR(x) ((void)0)
 #define STX_TIE3(a, b, c) ((void)0)
 #else
@@ -20,6 +21,9 @@
 #define stx_exp(x) __expf(x)
 // Instruction-scheduling fence (guide 5.4 rule 18 / T19): nothing moves across it.
 #define STX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// Instruction interleave inside one scheduling region (guide T19): the next `n` instructions of class `mask` (0x008 MFMA,
+// 0x100 LDS read, 0x200 LDS write, 0x020 VMEM read, 0x002 VALU) form the next group of the region's pipeline.
+#define STX_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 // Makes a VGPR value opaque to the optimiser at this point (blocks hoisting of address math that
 // would otherwise be precomputed into dozens of live registers; guide 5.7 item 3).
 #define STX_OPAQUE_VGPR(x) asm volatile("" : "+v"(x))

@@ -10,8 +10,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...aggregation import convbn_block
-from ..features2d import ResTrunk, convbn, init_reference_style, run_pair
+from ...aggregation import convbn_block, deferred_bn_counters
+from ..features2d import ResTrunk, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from ..GwcNet.gwcnet import classifier, run_classifier
 from .submodule import attention_block, convbn_3d
 
@@ -77,6 +77,8 @@ class ACVNet(nn.Module):
         self.classif1 = classifier(32)
         self.classif2 = classifier(32)
         init_reference_style(self)
+        channels_last_weights_(self.feature_extraction)
+        channels_last_weights_(self.concatconv)
         self._dil = {}
 
     def _dilations(self, device):
@@ -103,6 +105,10 @@ class ACVNet(nn.Module):
         return gl, gr, att
 
     def forward(self, left, right):
+        with deferred_bn_counters():
+            return self._forward(left, right)
+
+    def _forward(self, left, right):
         H, W = left.shape[2], left.shape[3]
         if self.freeze_attn_weights:
             with torch.no_grad():
@@ -111,7 +117,7 @@ class ACVNet(nn.Module):
             gl, gr, att = self._attention_branch(left, right)
 
         if not self.attn_weights_only:
-            cl, cr = self.concatconv(gl), self.concatconv(gr)
+            cl, cr = run_head2d(self.concatconv, gl), run_head2d(self.concatconv, gr)
             if torch.is_grad_enabled() and att.requires_grad:
                 prob = torch.softmax(att, dim=1)          # softmax over D' (acv.py:196), tiny tensor
             else:

@@ -9,8 +9,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...aggregation import conv_block, convbn_block
-from ..features2d import ResTrunk, convbn, init_reference_style, run_pair
+from ...aggregation import conv_block, convbn_block, deferred_bn_counters
+from ..features2d import ResTrunk, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from .submodule import convbn_3d
 
 
@@ -28,7 +28,7 @@ class feature_extraction(ResTrunk):
         gwc = torch.cat(self.trunk(x), dim=1)
         if not self.concat_feature:
             return {"gwc_feature": gwc}
-        return {"gwc_feature": gwc, "concat_feature": self.lastconv(gwc)}
+        return {"gwc_feature": gwc, "concat_feature": run_head2d(self.lastconv, gwc)}
 
 
 class hourglass(nn.Module):
@@ -93,10 +93,12 @@ class GwcNet(nn.Module):
         self.classif2 = classifier(32)
         self.classif3 = classifier(32)
         init_reference_style(self)
+        channels_last_weights_(self.feature_extraction)
 
     def forward(self, left, right):
-        fl, fr = run_pair(self.feature_extraction, left, right, self.training)
-        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+        with deferred_bn_counters():
+            fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+            return self.aggregate(fl, fr, left.shape[2], left.shape[3])
 
     def aggregate(self, fl, fr, H, W):
         """Everything behind the 2-D feature CNN (reference gwcnet.py:175-224): the hand-written part of the model.

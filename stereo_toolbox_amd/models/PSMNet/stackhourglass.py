@@ -6,8 +6,8 @@ Mirror of reference models/PSMNet/stackhourglass.py: PSMNet(maxdisp=192).forward
 import torch.nn as nn
 
 from ... import ops
-from ...aggregation import conv_block, convbn_block
-from ..features2d import init_reference_style, run_pair
+from ...aggregation import conv_block, convbn_block, deferred_bn_counters
+from ..features2d import channels_last_weights_, init_reference_style, run_pair
 from .submodule import convbn_3d, feature_extraction
 
 
@@ -64,10 +64,12 @@ class PSMNet(nn.Module):
         self.classif2 = _classifier()
         self.classif3 = _classifier()
         init_reference_style(self)
+        channels_last_weights_(self.feature_extraction)
 
     def forward(self, left, right):
-        fl, fr = run_pair(self.feature_extraction, left, right, self.training)
-        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+        with deferred_bn_counters():
+            fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+            return self.aggregate(fl, fr, left.shape[2], left.shape[3])
 
     def aggregate(self, fl, fr, H, W):
         """Hot path: 32-channel features at 1/4 resolution -> disparity at (H, W)."""

@@ -5,7 +5,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ..features2d import BasicBlock, ResTrunk, convbn  # noqa: F401
+from ..features2d import BasicBlock, ResTrunk, convbn, run_head2d  # noqa: F401
 
 
 def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
@@ -43,4 +43,4 @@ class feature_extraction(ResTrunk):
         br = [F.interpolate(getattr(self, f"branch{i}")(skip), size, mode="bilinear", align_corners=False)
               for i in (1, 2, 3, 4)]
         feat = torch.cat((raw, skip, br[3], br[2], br[1], br[0]), 1)
-        return self.lastconv(feat)
+        return run_head2d(self.lastconv, feat)

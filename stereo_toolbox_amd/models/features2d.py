@@ -1,16 +1,97 @@
 """2-D feature CNNs feeding the cost-volume builders.
 
-These are ON the critical path but NOT hand-written: they stay stock
-PyTorch-ROCm (MIOpen) modules.  Only their *structure* is dictated here -- by state-dict
-compatibility with the reference checkpoints (reference models/GwcNet/gwcnet.py:12-65,
-models/PSMNet/submodule.py:57-132, models/ACVNet/acv.py:15-54): module names, shapes and the
-Sequential indices must match so `load_checkpoint_flexible` loads published weights.
+These are ON the critical path but their CONVOLUTIONS are not hand-written: they stay stock
+PyTorch-ROCm (MIOpen) kernels.  Only their *structure* is dictated here -- by state-dict compatibility with the
+reference checkpoints (reference models/GwcNet/gwcnet.py:12-65, models/PSMNet/submodule.py:57-132,
+models/ACVNet/acv.py:15-54): module names, shapes and the Sequential indices must match so
+`load_checkpoint_flexible` loads published weights.
+
+Round 3: the glue AROUND the convolutions.  A rocprofv3 split of the extractor's train step (profiles/r03_feat2d_*.txt:
+27.7 ms fwd+bwd for both 576x960 views) showed 45 % of it outside the convolutions: MIOpen BatchNorm 4.7 ms, NCHW<->NHWC
+transposes around MIOpen's NHWC-only implicit-GEMM backward kernels 3.5 ms, stock elementwise adds / ReLU / counters
+3.5 ms.  In train mode on a ROCm device the extractor therefore runs channels-last end to end (no transposes; the conv
+weights are kept in channels_last memory format so that no per-call weight re-layout happens either) and every
+`BatchNorm2d (+ReLU) (+residual add / + BatchNorm2d(downsample))` is ONE fused pass on the in-house channels-last BN
+kernels of the 3-D path (stx_bn_stats -> stx_bn_finalize -> stx_bn_apply; backward stx_bn_bwd_reduce2 / _apply2),
+through the same autograd function (ops.BnActFn).  The nn.BatchNorm2d / nn.ReLU modules stay as parameter containers.
+Eval mode and CPU tensors keep the stock modules.  STX_FEAT2D_FUSED=0 switches the fused glue off (A/B).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
+from ..aggregation import _bn_state
+
+
+def channels_last_weights_(module):
+    """Store every Conv2d weight of `module` in channels_last memory format (values, shapes and state-dict keys are
+    unchanged; `load_state_dict` / `copy_` preserve the format).  With channels-last activations MIOpen's NHWC kernels
+    then take the weights as they are -- a contiguous weight would be re-laid-out by a small kernel in every forward,
+    backward-data and backward-weight call (4 launches per convolution and step)."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d) and m.weight.dim() == 4:
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return module
+
+
+def fused_glue(x, *bns):
+    """Whether the BatchNorm2d / ReLU / add glue runs on the in-house kernels for this call: fp32 on a ROCm device (or
+    the emulator in tests), every BatchNorm involved in train mode."""
+    if os.environ.get("STX_FEAT2D_FUSED", "1") == "0":
+        return False
+    if x.dtype != torch.float32 or not (x.is_cuda or ops._EMULATED):
+        return False
+    return all(isinstance(b, nn.modules.batchnorm._BatchNorm) and b.training for b in bns)
+
+
+def _nhwc(t):
+    """NCHW-logical tensor -> dense [B, H, W, C] (a view when `t` is channels_last already)."""
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_bn_act(x, conv, bn, relu=False, residual=None, second=None):
+    """act(BN(conv(x)) [+ residual | + BN2(z2)]) for a train-mode BatchNorm2d: MIOpen convolution (channels-last), one
+    statistics pass, one fused normalise / add / ReLU pass.  x / residual: NCHW-logical; second = (z2, bn2) with z2 the raw
+    output of the other branch's convolution.  Returns an NCHW-logical channels_last tensor."""
+    z = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    zl = _nhwc(z)
+    st = _bn_state(bn, ops.bn_stats(zl.detach()), zl.numel() // zl.shape[-1])
+    if second is not None:
+        z2l = _nhwc(second[0])
+        bn2 = second[1]
+        st2 = _bn_state(bn2, ops.bn_stats(z2l.detach()), z2l.numel() // z2l.shape[-1])
+        y = ops.BnActFn.apply(zl, bn.weight, bn.bias, z2l, bn2.weight, bn2.bias, None, relu, st, st2)
+    else:
+        y = ops.BnActFn.apply(zl, bn.weight, bn.bias, None, None, None, None if residual is None else _nhwc(residual),
+                              relu, st, None)
+    return y.permute(0, 3, 1, 2)
+
+
+def convbn_relu_chain(seq, x):
+    """nn.Sequential of [convbn, ReLU]* optionally ending in a bare Conv2d (firstconv, lastconv, concatconv), fused."""
+    i, n = 0, len(seq)
+    while i < n:
+        m = seq[i]
+        if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d):
+            relu = i + 1 < n and isinstance(seq[i + 1], nn.ReLU)
+            x = conv_bn_act(x, m[0], m[1], relu=relu)
+            i += 2 if relu else 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+def run_head2d(seq, x):
+    """`convbn + ReLU + Conv2d(1x1)` heads (GwcNet lastconv, ACVNet concatconv, PSMNet lastconv)."""
+    if fused_glue(x, seq[0][1]):
+        return convbn_relu_chain(seq, x)
+    return seq(x)
 
 
 def convbn(cin, cout, k, stride, pad, dilation):
@@ -30,6 +111,14 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        bns = [self.conv1[0][1], self.conv2[1]] + ([self.downsample[1]] if self.downsample is not None else [])
+        if fused_glue(x, *bns):
+            y = conv_bn_act(x, self.conv1[0][0], self.conv1[0][1], relu=True)
+            if self.downsample is None:
+                return conv_bn_act(y, self.conv2[0], self.conv2[1], residual=x)
+            d = self.downsample[0]
+            zd = F.conv2d(x, d.weight, d.bias, d.stride, d.padding, d.dilation, d.groups)
+            return conv_bn_act(y, self.conv2[0], self.conv2[1], second=(zd, self.downsample[1]))
         y = self.conv2(self.conv1(x))
         if self.downsample is not None:
             x = self.downsample(x)
@@ -60,7 +149,11 @@ class ResTrunk(nn.Module):
         return nn.Sequential(*layers)
 
     def trunk(self, x):
-        x = self.layer1(self.firstconv(x))
+        if fused_glue(x, self.firstconv[0][1]):
+            x = convbn_relu_chain(self.firstconv, x.contiguous(memory_format=torch.channels_last))
+        else:
+            x = self.firstconv(x)
+        x = self.layer1(x)
         l2 = self.layer2(x)
         l3 = self.layer3(l2)
         l4 = self.layer4(l3)

@@ -14,6 +14,7 @@ import torch
 from ._capi import StxError, get_lib
 
 _P = ctypes.c_void_p
+_EMULATED = False      # tests only (tests/emu_util.emu_product_path): CPU tensors are served by the host-emulator build
 
 
 # --------------------------------------------------------------------------------------- plumbing
@@ -366,6 +367,20 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     _call("stx_bn_finalize", _p(partials), partials.shape[0], C, float(count), _p(gamma), _p(beta),
           _p(running_mean), _p(running_var), float(momentum), float(eps), *[_p(o) for o in outs])
     return outs   # scale, shift, mean, invstd
+
+
+def bn_stats(z):
+    """Per-workgroup (sum, sum of squares) rows of a dense channels-last activation [..., C] -> [rows, 2, C]: the batch
+    statistics input of bn_finalize for producers without a fused epilogue (the 2-D feature CNN's MIOpen convolutions)."""
+    _chk(z, "z")
+    C = z.shape[-1]
+    nvox = z.numel() // C
+    rows = get_lib().raw("stx_bn_stats_rows")(nvox, C)
+    if rows <= 0:
+        raise StxError(f"bn_stats: C={C} unsupported")
+    part = torch.empty(rows, 2, C, dtype=torch.float32, device=z.device)
+    _call("stx_bn_stats", _p(z), _p(part), nvox, C)
+    return part
 
 
 def _sync_bn_partials(partials, count, group, world):

@@ -84,3 +84,20 @@ def state_dict_digest(sd):
         c = zlib.crc32(name.encode(), c)
         c = zlib.crc32(sd[name].detach().cpu().contiguous().numpy().tobytes(), c)
     return c
+
+
+def use_tuning_db():
+    """Point MIOpen's user find-db / perf-db at the copy shipped in-tree (stereo_toolbox_amd/tuning/miopen: the solver
+    search results of the 2-D feature CNN's convolutions at the benchmarked shapes, recorded on an MI355X with this
+    image's MIOpen), unless MIOPEN_USER_DB_PATH is already set.  With `torch.backends.cudnn.benchmark = True` every
+    process otherwise repeats the exhaustive search (~2.5 GPU-minutes per rank for the GwcNet_GC train step) before its
+    first step; results for shapes the db lacks are searched as usual and appended.  Tuning cache only: it selects among
+    MIOpen's own kernels, the timed region and the numerics contract are unchanged.  Call before the first convolution."""
+    import os
+    if os.environ.get("MIOPEN_USER_DB_PATH"):
+        return os.environ["MIOPEN_USER_DB_PATH"]
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "miopen")
+    if os.path.isdir(d) and os.access(d, os.W_OK):
+        os.environ["MIOPEN_USER_DB_PATH"] = d
+        return d
+    return None

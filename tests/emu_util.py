@@ -47,7 +47,8 @@ class emu_product_path:
     def __enter__(self):
         from stereo_toolbox_amd import ops
         self.ops = ops
-        self.saved = (ops.get_lib, ops._chk, ops._stream)
+        self.saved = (ops.get_lib, ops._chk, ops._stream, ops._EMULATED)
+        ops._EMULATED = True
         lib = emu_lib()
         ops.get_lib = lambda: lib
 
@@ -61,5 +62,5 @@ class emu_product_path:
         return self
 
     def __exit__(self, *exc):
-        self.ops.get_lib, self.ops._chk, self.ops._stream = self.saved
+        self.ops.get_lib, self.ops._chk, self.ops._stream, self.ops._EMULATED = self.saved
         return False

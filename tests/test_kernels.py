@@ -787,3 +787,60 @@ def test_bn_train_fwd_bwd(be, case):
         assert torch.equal(dz1b.cpu(), dz1.cpu())
         if two:
             assert torch.equal(dz2b.cpu(), dz2.cpu())
+
+
+# ------------------------------------------------------------------------------ 2-D feature CNN glue
+@pytest.mark.parametrize("case", [(1000, 32), (37, 64), (5000, 128), (3, 16), (70000, 32)])
+def test_bn_stats(be, case):
+    """stx_bn_stats: per-workgroup (sum, sum of squares) rows of a channels-last activation -> the column sums are the
+    batch statistics torch's BatchNorm2d computes (models/GwcNet/gwcnet.py:12-65 `convbn`)."""
+    nvox, C = case
+    torch.manual_seed(31)
+    z = torch.randn(nvox, C) * 2 + 0.5
+    rows = be.raw("stx_bn_stats_rows")(nvox, C)
+    assert rows >= 1
+    part = be.empty(rows, 2, C)
+    be.call("stx_bn_stats", ptr(be.dev(z)), ptr(part), nvox, C)
+    p = part.cpu().double()
+    _close(p[:, 0].sum(0).float(), z.double().sum(0).float(), rtol=1e-5, atol=1e-3)
+    _close(p[:, 1].sum(0).float(), (z.double() ** 2).sum(0).float(), rtol=1e-5, atol=1e-3)
+
+
+def test_conv3d_march_blocked_sums(be, monkeypatch):
+    """Blocked fp32 accumulation in the weights-in-LDS march kernel (STX_MARCH_BS=1, the default): one accumulator per
+    (output, input plane) -- three 288-term chunks instead of one 864-term chain.  Same convolution; the result must be
+    CLOSER to an fp64 evaluation than the sequential chain's (STX_MARCH_BS=0)."""
+    torch.manual_seed(5)
+    for B, Cin, Cout, D, H, W in ((1, 32, 32, 7, 9, 37), (1, 64, 32, 4, 8, 33), (2, 32, 64, 5, 6, 40), (1, 32, 32, 2, 3, 20)):
+        x = torch.randn(B, Cin, D, H, W)
+        w = torch.randn(Cout, Cin, 3, 3, 3) * 0.1
+        ref64 = F.conv3d(x.double(), w.double(), None, 1, 1)
+        monkeypatch.setenv("STX_MARCH_BS", "1")
+        got, st = run_conv(be, x, w, 3, 1, stats=True)
+        _close(got, ref64.float())
+        _close(st[:, 0].sum(0), ref64.float().sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        monkeypatch.setenv("STX_MARCH_BS", "0")
+        seq, _ = run_conv(be, x, w, 3, 1)
+        _close(seq, ref64.float())
+        e_blk = (got.double() - ref64).abs().mean().item()
+        e_seq = (seq.double() - ref64).abs().mean().item()
+        assert e_blk < 0.85 * e_seq, (e_blk, e_seq)
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2),
+                                  (1, 64, 64, 3, 4, 34, 3, 1), (1, 64, 32, 2, 9, 20, 3, 1)])
+def test_conv3d_wgrad_straight_line_loop(be, case, monkeypatch):
+    """STX_WGRAD_V2=1: weight-gradient MFMA loop with a compile-time tap count per wave (3 or 4 of the 27) and the LDS
+    operand reads dealt between the MFMAs -- same sums, in the same order, as the first version."""
+    monkeypatch.setenv("STX_WGRAD_V2", "1")
+    B, Cin, Cout, D, H, W, ks, s = case
+    torch.manual_seed(8)
+    x = torch.randn(B, Cin, D, H, W)
+    w = (torch.randn(Cout, Cin, ks, ks, ks) * 0.1).requires_grad_()
+    y = F.conv3d(x, w, None, s, ks // 2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    v2 = run_wgrad(be, x, gy, ks, s)
+    _close(v2.view_as(w), w.grad)
+    monkeypatch.setenv("STX_WGRAD_V2", "0")
+    assert torch.equal(v2, run_wgrad(be, x, gy, ks, s))        # identical accumulation order -> identical bits

@@ -80,9 +80,9 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
     fp32 error of a tensor is set by its conditioning, which the oracle-vs-fp64 distance measures.  Achieved on the GPU
     at the benchmarked shape: 1.0-1.8 x, profiles/r02_parity_report.jsonl.)"""
     if rtol is None:
-        # floor: 0.2 % of the tensor's max on the emulator (bit-exact fp32 MFMA model, CPU 2-D convs); 0.5 % on the GPU,
+        # floor: 0.2 % of the tensor's max on the emulator (bit-exact fp32 MFMA model, CPU 2-D convs); 1 % on the GPU,
         # where the stock 2-D feature CNN runs MIOpen's benchmark-selected algorithms (varying from run to run)
-        rtol = 5e-3 if next(model.parameters()).is_cuda else 2e-3
+        rtol = 1e-2 if next(model.parameters()).is_cuda else 2e-3
     worst = 0.0
     worst_ratio, worst_key = 0.0, None
     n = 0

@@ -12,6 +12,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stereo_toolbox_amd.models.GwcNet.gwcnet import feature_extraction  # noqa: E402
+from stereo_toolbox_amd.models.features2d import channels_last_weights_  # noqa: E402
+from stereo_toolbox_amd.utils import use_tuning_db  # noqa: E402
+
+use_tuning_db()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--fmt", default="both")
@@ -23,6 +27,8 @@ torch.backends.cudnn.benchmark = not a.no_benchmark
 dev = torch.device("cuda:0")
 for fmt in (("nchw", "nhwc") if a.fmt == "both" else (a.fmt,)):
     m = feature_extraction(True, 12).to(dev).train()
+    if os.environ.get("STX_FEAT2D_FUSED", "1") != "0":
+        channels_last_weights_(m)       # (what the model constructors do)
     x = [torch.randn(1, 3, 576, 960, device=dev) for _ in range(2)]
     if fmt == "nhwc":
         m = m.to(memory_format=torch.channels_last)
@@ -40,7 +46,7 @@ for fmt in (("nchw", "nhwc") if a.fmt == "both" else (a.fmt,)):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
-    print(fmt, "fwd+bwd both views: %.2f ms" % (dt * 1e3), flush=True)
+    print(fmt, "fused_glue=%s" % os.environ.get("STX_FEAT2D_FUSED", "1"), "fwd+bwd both views: %.2f ms" % (dt * 1e3), flush=True)
     if a.no_eval:
         continue
     with torch.no_grad():

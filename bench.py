@@ -62,10 +62,10 @@ class KernelTimer:
     stream every stx_* entry point is given, stereo_toolbox_amd/ops.py:_stream)."""
 
     def __init__(self):
-        self.records = []
+        self.records = {"conv": [], "volume": []}
         self.enabled = False
 
-    def _timed(self, orig, units):
+    def _timed(self, orig, units, kind):
         timer = self
 
         def wrapper(*a, **k):
@@ -77,7 +77,7 @@ class KernelTimer:
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            timer.records.append((e0, e1, u))
+            timer.records[kind].append((e0, e1, u))
             return out
         return wrapper
 
@@ -90,7 +90,7 @@ class KernelTimer:
                 return None
             B, D, H, W, Cin = x.shape
             return 2.0 * B * D * H * W * Cout * Cin * 27
-        ops.conv3d_forward = self._timed(ops.conv3d_forward, units)
+        ops.conv3d_forward = self._timed(ops.conv3d_forward, units, "conv")
 
     def install_volume(self):
         from stereo_toolbox_amd import ops
@@ -104,14 +104,15 @@ class KernelTimer:
             G = num_groups if Lg is not None else 0
             Cc = Lc.shape[1] if Lc is not None else 0
             return float(n + B * maxdisp * H * W * (G + 2 * Cc) * 4)
-        ops.cost_volume_forward = self._timed(ops.cost_volume_forward, units)
+        ops.cost_volume_forward = self._timed(ops.cost_volume_forward, units, "volume")
 
-    def summary(self):
-        if not self.records:
+    def summary(self, kind):
+        recs = self.records[kind]
+        if not recs:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        un = sum(u for _, _, u in self.records)
-        return {"launches": len(self.records), "ms_total": ms, "units_total": un}
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        un = sum(u for _, _, u in recs)
+        return {"launches": len(recs), "ms_total": ms, "units_total": un}
 
 
 def committed_pmc_traffic(fname):
@@ -150,30 +151,43 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, maxdisp):
-    """Oracle (torch-op restatement of the reference path) on the host cores: 1 warm-up + 2 timed runs of a BOUNDED
-    sample of the config's workload.  `value` extrapolates the sample to the config's shape by voxel count and says
-    so (`extrapolated`); `sample_s` are the measured times."""
+def cpu_baseline(cfg, maxdisp, full_cap_s=180.0):
+    """Oracle (torch-op restatement of the reference path) on the host cores.  First a BOUNDED sample of the config's
+    workload (1 warm-up + 1 timed run of one pair at reduced resolution); if the sample says the config's TRUE shape fits
+    into `full_cap_s` seconds, one pair at the true shape is run once and `value` is that measurement
+    (`extrapolated` false) -- otherwise `value` extrapolates the sample by pixel count and says so."""
     from oracle import torch_oracle as O
     from stereo_toolbox_amd import models
     from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
     model_name, mode, Hc, Wc, _, _ = CONFIGS[cfg]
     threads = torch.get_num_threads()
+
+    def timed(fn):
+        t0 = time.time()
+        fn()
+        return time.time() - t0
+
     if mode == "volume":
         H, W = Hc // 4, Wc // 4
         L, R = synthetic_tensor((1, 32, H, W), 1), synthetic_tensor((1, 32, H, W), 2)
 
         def run():
             O.build_concat_volume(L, R, maxdisp // 4)
-        frac, what = 1.0, f"oracle build_concat_volume (PSM semantics), features 1x32x{H}x{W}, D'={maxdisp // 4}"
-    else:
-        H, W = (192, 480) if mode == "train" else (Hc // 2, Wc // 2)
-        ctor = getattr(models, model_name)
-        sd = ctor(maxdisp).state_dict()
-        fill_state_dict(sd)
+        run()
+        times = [timed(run) for _ in range(2)]
+        dt = min(times)
+        return {"value": round(1.0 / dt, 5), "unit": "volumes/s", "cores": threads, "cpu_model": cpu_model_name(),
+                "kind": "port", "extrapolated": False, "sample_s": [round(t, 3) for t in times],
+                "sample": f"oracle build_concat_volume (PSM semantics), features 1x32x{H}x{W}, D'={maxdisp // 4}; "
+                          f"1 warm-up + 2 timed runs (best {dt:.3f} s)"}
+    ctor = getattr(models, model_name)
+    sd = ctor(maxdisp).state_dict()
+    fill_state_dict(sd)
+    fwd = O.acvnet_forward if model_name == "ACVNet" else (lambda s, l, r, d, **k: O.gwcnet_forward(s, l, r, d, True, **k))
+
+    def make(H, W):
         left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
         gt = synthetic_tensor((1, H, W), 3, lo=0.0, hi=190.0)
-        fwd = O.acvnet_forward if model_name == "ACVNet" else (lambda s, l, r, d, **k: O.gwcnet_forward(s, l, r, d, True, **k))
 
         def run():
             if mode == "train":
@@ -182,21 +196,23 @@ def cpu_baseline(cfg, maxdisp):
             else:
                 with torch.no_grad():
                     fwd(sd, left, right, maxdisp)
-        frac = (H * W) / float(Hc * Wc)
-        what = (f"oracle {model_name} {'fwd+bwd' if mode == 'train' else 'eval fwd'}, 1 pair at {H}x{W} D={maxdisp}")
-    run()                                              # warm-up (thread pool, oneDNN primitive caches)
-    times = []
-    for _ in range(2):
-        t0 = time.time()
-        run()
-        times.append(time.time() - t0)
-    dt = min(times)
-    return {"value": round(frac / dt, 5), "unit": "pairs/s" if mode != "volume" else "volumes/s", "cores": threads,
-            "cpu_model": cpu_model_name(), "kind": "port", "extrapolated": frac != 1.0,
-            "sample_s": [round(t, 2) for t in times],
-            "sample": f"{what}; 1 warm-up + 2 timed runs (best {dt:.2f} s)"
-                      + ("" if frac == 1.0 else f"; value = measured rate x pixel ratio {frac:.4f} to the {Hc}x{Wc} pair "
-                                                "(an extrapolation, not a measurement of the full shape)")}
+        return run
+    Hs, Ws = (192, 480) if mode == "train" else (Hc // 2, Wc // 2)
+    small = make(Hs, Ws)
+    small()                                            # warm-up (thread pool, oneDNN primitive caches)
+    ts = timed(small)
+    frac = (Hs * Ws) / float(Hc * Wc)
+    what = f"oracle {model_name} {'fwd+bwd' if mode == 'train' else 'eval fwd'}, 1 pair, D={maxdisp}"
+    base = {"unit": "pairs/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port"}
+    if ts / frac <= full_cap_s:
+        tf = timed(make(Hc, Wc))                       # the config's true shape, once
+        return dict(base, value=round(1.0 / tf, 5), extrapolated=False, sample_s=[round(tf, 2)],
+                    sample=f"{what} at the config's true shape {Hc}x{Wc}: one timed run ({tf:.1f} s) after a warm-up and a "
+                           f"timed run at {Hs}x{Ws} ({ts:.1f} s, which predicted {ts / frac:.0f} s by pixel count)")
+    return dict(base, value=round(frac / ts, 5), extrapolated=True, sample_s=[round(ts, 2)],
+                sample=f"{what} at {Hs}x{Ws}; 1 warm-up + 1 timed run ({ts:.2f} s); value = measured rate x pixel ratio "
+                       f"{frac:.4f} to the {Hc}x{Wc} pair (an extrapolation: the true shape was predicted to take "
+                       f"{ts / frac:.0f} s, above the {full_cap_s:.0f} s cap)")
 
 
 def parse_args(argv=None):
@@ -244,6 +260,30 @@ def self_spawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def pin_host_threads(local, world):
+    """One rank per GPU shares the node's host cores: give every rank its own contiguous block of the cores this process
+    may run on (launch threads, MIOpen's solver search, the CPU side of autograd) and cap the OpenMP / torch intra-op pool
+    at that block's size -- N ranks each spawning a pool as wide as the machine oversubscribe it N-fold.  Returns what
+    was done (reported in the JSON line); silently does nothing where the affinity API is not available."""
+    info = {"threads": None, "cores": None}
+    if world <= 1:
+        return info
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        per = max(1, len(avail) // world)
+        mine = avail[local * per:(local + 1) * per] or avail
+        os.sched_setaffinity(0, mine)
+        info["cores"] = f"{mine[0]}-{mine[-1]}"
+        n = int(os.environ.get("OMP_NUM_THREADS", "0")) or per
+        n = min(n, len(mine))
+        os.environ["OMP_NUM_THREADS"] = str(n)
+        torch.set_num_threads(n)
+        info["threads"] = n
+    except (AttributeError, OSError, ValueError):
+        pass
+    return info
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
@@ -257,6 +297,7 @@ def main(argv=None):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(torch.distributed.run --nproc-per-node {args.gpus})")
     emu = emulated()
+    pin = pin_host_threads(local, world)              # before any thread pool starts
     if emu:
         from tests.emu_util import emu_product_path
         emu_product_path().__enter__()
@@ -309,6 +350,7 @@ def main(argv=None):
         left = torch.randn(B, 3, H, W, device=dev, generator=g)
         right = torch.randn(B, 3, H, W, device=dev, generator=g)
         timer.install_conv()
+        timer.install_volume()
         if mode == "train":
             model.train()
             overlap = not args.no_overlap and not args.graph
@@ -316,12 +358,21 @@ def main(argv=None):
             opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
             gt = 190.0 * torch.rand(B, H, W, device=dev, generator=g)
 
+            sync_events = []                       # (before, after) finish(): what the gradient exchange adds to the stream
+
             def step():
                 gsync.detach_grads()
                 preds = model(left, right)
                 loss = smooth_l1_multi(preds, gt, D)
                 loss.backward()
-                gsync.finish()
+                if timer.enabled and world > 1:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    gsync.finish()
+                    e1.record()
+                    sync_events.append((e0, e1))
+                else:
+                    gsync.finish()
                 opt.step()
         else:
             model.eval()
@@ -358,35 +409,72 @@ def main(argv=None):
         dist.barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
+    per_rank = None
     if world > 1:
+        # every rank's own wall time and the time its stream spent in the gradient exchange after backward() (pack + what
+        # of the all-reduce did not hide behind the backward pass), gathered for the report; `value` uses the MAX
+        exposed = 0.0
+        if mode == "train" and not emu and sync_events:
+            exposed = sum(a.elapsed_time(b) for a, b in sync_events) / len(sync_events)
+        mine = torch.tensor([dt / args.steps * 1e3, exposed], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(x[0]), 3) for x in allr],
+                    "grad_sync_ms_on_stream": [round(float(x[1]), 3) for x in allr]}
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
-        ks = timer.summary()
-        roof = None
-        if ks and mode == "volume":
+        std_shape = (H, W, B, D) == (576, 960, 1, 192)    # the shape the committed PMC summaries were collected at
+
+        def roof_volume():
+            ks = timer.summary("volume")
+            if not ks:
+                return None
             ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e9
-            src = first_existing("r02_pmc_cost_volume_fwd_psm.txt", "r02_pmc_cost_volume_fwd.txt")
-            roof = {"bound": "hbm", "kernel": "cost_volume_fwd (PSMNet concat volume, fp32 copy/shift/mask)",
+            src = first_existing("r03_pmc_cost_volume_fwd.txt", "r02_pmc_cost_volume_fwd.txt")
+            kind = "PSMNet concat volume, fp32 copy / shift / mask" if mode == "volume" else \
+                   "fused group-wise correlation + concat volume, NDHWC"
+            return {"bound": "hbm", "kernel": f"cost_volume_fwd_mfma_kernel ({kind})",
                     "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
-                    "traffic": committed_pmc_traffic(src), "traffic_source": f"profiles/{src} (committed PMC summary of an "
-                    "earlier profiled session of this kernel; constant, not measured by this run)",
+                    "traffic": committed_pmc_traffic(src) if std_shape and mode != "volume" else None,
+                    "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the GwcNet_GC "
+                                      "576x960 build, separate passes; a committed-profile constant, not measured by this run "
+                                      "(null for other shapes)",
                     "algorithmic_bytes_per_launch": int(ks["units_total"] / ks["launches"]),
                     "launches_per_step": ks["launches"] // max(1, args.steps),
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
-        elif ks:
+
+        def roof_conv():
+            ks = timer.summary("conv")
+            if not ks:
+                return None
             ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e12
-            src = first_existing("r02_pmc_conv3d_marchw.txt", "r01_pmc_conv3d_march.txt")
-            roof = {"bound": "mfma", "kernel": "conv3d_marchw_kernel (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA, weights resident in LDS)",
+            src = first_existing("r03_pmc_conv3d_marchw.txt", "r02_pmc_conv3d_marchw.txt")
+            return {"bound": "mfma", "kernel": "conv3d_marchw_kernel (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA, weights "
+                                               "resident in LDS)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": committed_pmc_traffic(src),
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": committed_pmc_traffic(src) if std_shape else None,
                     "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
-                                      "576x960 launch; a committed-profile constant of the same kernel, not measured by this "
-                                      "run (algorithmic: 424 MB)",
+                                      "576x960 B=1 launch (algorithmic: 424 MB); a committed-profile constant of the same "
+                                      "kernel, not measured by this run (null for other shapes)",
+                    "flop_per_launch": int(ks["units_total"] / ks["launches"]),
                     "launches_per_step": ks["launches"] // max(1, args.steps),
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
+        # dominant kernel per config: the Conv3d march kernel for the train steps (MFMA-bound); the volume builder for the
+        # volume-only config and for cfg5, for which BASELINE.json asks for the HBM roofline report (the march kernel of
+        # that run is reported next to it)
+        extra = {}
+        if mode == "train":
+            roof = roof_conv()
+            extra["roofline_volume_build"] = roof_volume()
+        elif mode == "eval":
+            roof = roof_volume()
+            extra["roofline_conv3d"] = roof_conv()
+        else:
+            roof = roof_volume()
         work = {"train": f"{model_name}(maxdisp={D}) train step: fwd+bwd+allreduce+Adam",
                 "eval": f"{model_name}(maxdisp={D}) inference (eval forward, no_grad), batch-parallel",
                 "volume": f"build_concat_volume (PSMNet semantics) features {B}x32x{H // 4}x{W // 4}, D'={D // 4}, fwd only"}[mode]
@@ -416,6 +504,9 @@ def main(argv=None):
                                           else tuning_db)},
             "roofline": roof,
         }
+        out.update(extra)
+        if per_rank is not None:
+            out["per_rank"] = dict(per_rank, host_threads_per_rank=pin["threads"], host_cores_rank0=pin["cores"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, D)
         print(json.dumps(out), flush=True)

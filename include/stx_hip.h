@@ -13,7 +13,8 @@
  *   - 2-D features are NCHW [B][C][H][W]; 3-D activations are channels-last [B][D][H][W][C];
  *   - return value 0 = OK; 1 = invalid argument; 2 = launch failure; stx_last_error() gives the
  *     message of the last failure on the calling thread;
- *   - re-entrant: no global mutable state, safe from several host threads / one process per GPU.
+ *   - re-entrant: no mutable state beyond the tuning switches below, safe from several host threads / one process
+ *     per GPU.
  */
 #ifndef STX_HIP_H
 #define STX_HIP_H
@@ -23,6 +24,12 @@ extern "C" {
 
 const char* stx_last_error(void);
 const char* stx_build_info(void);
+/* Tuning / A-B switches (names = their environment variables, e.g. "STX_MARCH_BS"; list and defaults: StxTune in
+ * csrc/stx_common.h).  The environment is read ONCE, when the library is loaded; stx_set_tuning changes a switch for the
+ * calls that follow in this process (tests, tools/kernel_bench.py).  None changes a result beyond fp32 rounding.
+ * stx_get_tuning: value, or -1 for an unknown name;  stx_set_tuning: 0, or 1 for an unknown name. */
+int stx_get_tuning(const char* name);
+int stx_set_tuning(const char* name, int value);
 
 /* ---- cost-volume builders ------------------------------------------------------------------
  * build_gwc_volume / groupwise_correlation  models/GwcNet/submodule.py:44-63 (dup ACVNet/submodule.py:209-238)

@@ -185,9 +185,16 @@ def deconvbn_3d(cx, x, prefix):
     return cx.bn(y, prefix + ".1")
 
 
+def _w2d(w):
+    """2-D conv weight in plain NCHW memory order, whatever format the state-dict tensor is stored in (the product keeps
+    its Conv2d weights channels_last; the reference -- and the fixtures generated from it -- run contiguous weights, and
+    the CPU convolution picks a different kernel, with different fp32 rounding, for a channels_last weight)."""
+    return w.contiguous()
+
+
 def convbn_2d(cx, x, prefix, stride, pad, dilation):
     """GwcNet/submodule.py:11-14."""
-    y = F.conv2d(x, cx.sd[prefix + ".0.weight"], None, stride, dilation if dilation > 1 else pad, dilation)
+    y = F.conv2d(x, _w2d(cx.sd[prefix + ".0.weight"]), None, stride, dilation if dilation > 1 else pad, dilation)
     return cx.bn(y, prefix + ".1")
 
 
@@ -303,7 +310,7 @@ def features_gwc(cx, x, concat, p="feature_extraction"):
     if not concat:
         return gwc, None
     c = F.relu(convbn_2d(cx, gwc, p + ".lastconv.0", 1, 1, 1))
-    c = F.conv2d(c, cx.sd[p + ".lastconv.2.weight"])
+    c = F.conv2d(c, _w2d(cx.sd[p + ".lastconv.2.weight"]))
     return gwc, c
 
 
@@ -318,7 +325,7 @@ def features_psm(cx, x, p="feature_extraction"):
         branches.append(F.interpolate(b, size, mode="bilinear", align_corners=False))
     feat = torch.cat((l2, l4, branches[3], branches[2], branches[1], branches[0]), 1)
     f = F.relu(convbn_2d(cx, feat, p + ".lastconv.0", 1, 1, 1))
-    return F.conv2d(f, cx.sd[p + ".lastconv.2.weight"])
+    return F.conv2d(f, _w2d(cx.sd[p + ".lastconv.2.weight"]))
 
 
 # ----------------------------------------------------------------------------- whole models
@@ -413,7 +420,7 @@ def acvnet_forward(sd, left, right, maxdisp, attn_weights_only=False, freeze_att
     if not attn_weights_only:
         def concatconv(g):
             c = F.relu(convbn_2d(cx, g, "concatconv.0", 1, 1, 1))
-            return F.conv2d(c, sd["concatconv.2.weight"])
+            return F.conv2d(c, _w2d(sd["concatconv.2.weight"]))
         cvol = build_concat_volume(concatconv(gl), concatconv(gr), maxdisp // 4, mask_left=False)
         ac = F.softmax(att, dim=2) * cvol
         cost0 = dres0(cx, ac)
@@ -460,7 +467,7 @@ def _pcw_layer(cx, x, p, blocks, stride, pad, dilation, has_down):
 
 def _pcw_head2d(cx, x, p):
     """convbn(3x3) + Mish + 1x1 Conv2d (pcwnet.py:36-74)."""
-    return F.conv2d(mish(convbn_2d(cx, x, p + ".0", 1, 1, 1)), cx.sd[p + ".2.weight"])
+    return F.conv2d(mish(convbn_2d(cx, x, p + ".0", 1, 1, 1)), _w2d(cx.sd[p + ".2.weight"]))
 
 
 def features_pcw(cx, x, p="feature_extraction"):
@@ -551,7 +558,7 @@ def _pcw_refine(cx, x, disp, p="refinenet3"):
     x = _pcw_block(cx, x, p + ".conv5.0", 1, 1, 8, True)
     x = _pcw_block(cx, x, p + ".conv6.0", 1, 1, 16, True)
     x = _pcw_block(cx, x, p + ".conv7.0", 1, 1, 1, True)
-    return disp + F.conv2d(x, cx.sd[p + ".conv8.weight"], None, 1, 1)
+    return disp + F.conv2d(x, _w2d(cx.sd[p + ".conv8.weight"]), None, 1, 1)
 
 
 def pcwnet_forward(sd, left, right, maxdisp, training=False, return_ctx=False):
@@ -656,7 +663,7 @@ def igev_init_disparity(cost, maxdisp):
 # ----------------------------------------------------------------------------- CFNet
 def _cf_conv_bn_mish(cx, x, p):
     """CFNet/submodule.py:70-93 `conv2DBatchNormRelu` (1x1 conv, BN, Mish): keys p.cbr_unit.{0,1}."""
-    return mish(cx.bn(F.conv2d(x, cx.sd[p + ".cbr_unit.0.weight"]), p + ".cbr_unit.1"))
+    return mish(cx.bn(F.conv2d(x, _w2d(cx.sd[p + ".cbr_unit.0.weight"])), p + ".cbr_unit.1"))
 
 
 def _cf_pyramid_pooling(cx, x, p):

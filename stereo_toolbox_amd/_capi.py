@@ -21,6 +21,8 @@ _L = ctypes.c_longlong
 
 # name -> argtypes (every entry point returns int: 0 ok, else see stx_last_error()).
 SIGNATURES = {
+    "stx_get_tuning": [ctypes.c_char_p],
+    "stx_set_tuning": [ctypes.c_char_p, _I],
     # cost_volume.hip
     "stx_cost_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_cost_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -111,6 +113,16 @@ class StxLib:
 
     def build_info(self):
         return self._dll.stx_build_info().decode()
+
+    def get_tuning(self, name):
+        return self._fns["stx_get_tuning"](name.encode())
+
+    def set_tuning(self, name, value):
+        """A/B switch of the library (see StxTune in csrc/stx_common.h); returns the previous value."""
+        old = self.get_tuning(name)
+        if old < 0 or self._fns["stx_set_tuning"](name.encode(), int(value)) != 0:
+            raise StxError(f"unknown tuning switch {name}")
+        return old
 
     def raw(self, name):
         return self._fns[name]

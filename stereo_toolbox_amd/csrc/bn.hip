@@ -351,8 +351,7 @@ extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double c
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
     stx_begin();
     STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
-    const int v1 = getenv("STX_BN_FINALIZE_V1") ? 1 : 0;   // A/B switch (read per call): first-generation kernel
-    if (C % 4 == 0 && nrows >= 256 && !v1)
+    if (C % 4 == 0 && nrows >= 256)
         hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(BN_FIN_THREADS), 0, (hipStream_t)stream, partials, nrows, C,
                            count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
     else
@@ -366,7 +365,9 @@ extern "C" int stx_bn_stats_rows(long long nvox, int C) {
     if (C < 4 || C % 4 != 0 || BN_THREADS % (C / 4) != 0 || nvox < 1) return 0;
     const long long vpb = BN_THREADS / (C / 4);
     const long long g = (nvox + 4 * vpb - 1) / (4 * vpb);          // >= 4 voxels per lane before another workgroup is added
-    return (int)(g > BN_RED_BLOCKS ? BN_RED_BLOCKS : (g < 1 ? 1 : g));
+    // at most 256 rows: the tensors of the 2-D CNN are 4-18 MB, both passes are latency-bound and the finalize pass reads
+    // every row (1024 rows: 7.6 us per layer in the rocprofv3 split of GPU call D)
+    return (int)(g > 256 ? 256 : (g < 1 ? 1 : g));
 }
 
 extern "C" int stx_bn_stats(const float* z, float* partials, long long nvox, int C, void* stream) {
@@ -401,11 +402,14 @@ extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* 
                 "bn_bwd_reduce: the relu mask needs y or the forward pass's scale / shift vectors");
     STX_REQUIRE(relu != 2 || !y, "bn_bwd_reduce: Mish (activation code 2) differentiates the pre-activation value: pass y = NULL and the scale / shift vectors");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(BN_RED_BLOCKS), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
+    // small activations (the 2-D CNN's: <= 4.5 M elements): a quarter of the workgroups, so that the column-sum pass reads
+    // 256 partial rows instead of 1024 (both passes are latency-bound there)
+    const int nblk = ((long long)nvox * C <= (9ll << 19)) ? BN_RED_BLOCKS / 4 : BN_RED_BLOCKS;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
                        z2, mean2, invstd2, scale1, shift1, scale2, shift2, partials, (size_t)nvox, C, relu);
     int rc = stx_check_launch("bn_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, BN_RED_BLOCKS, 3 * C, sums);
+    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, nblk, 3 * C, sums);
     return stx_check_launch("bn_colsum");
 }
 

@@ -397,30 +397,6 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
     if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------
-// 3x3x3 stride-1 convolution with Cin = 32, software-pipelined along D ("march" kernel).
-//
-// conv3d_igemm_kernel above stages a tile, computes, stages the next: co-resident workgroups run in
-// lock-step, so the matrix pipe idles while they all wait for their halo tiles (measured: MFMA busy
-// 60 %, rocprofv3 PMC, profiles/r01_pmc_conv_32_32_L0.txt).  Here a workgroup (8 waves) owns a column
-// of 4 x 32 output voxels and marches through a segment of output planes d.  LDS holds a ring of
-// three input planes (6 x 34 voxels x 36 dwords = 29 KB each).  While plane d is being multiplied,
-// input plane d+2 is already in flight into registers (4 float4 per lane); it is written into the
-// ring slot of plane d-1 once every wave has finished with it.  Each input voxel is staged
-// 6*34/(4*32) = 1.6 x instead of 4.25 x, and the loads are always a full plane ahead of their use.
-// Two waves share one 32-voxel row block and split GEMM-K by channel halves (2 of the 4 8-channel
-// K steps of every tap each = 216 MFMAs per plane per wave); they exchange half of their 32x32
-// accumulator through LDS and each finishes 16 of the rows (epilogue as above).
-// MW = 16 variant: the 32 voxels of a row block are 2 rows x 16 columns (workgroup column 8 x 16), for widths
-// like W' = 240 = 15 x 16 = 7.5 x 32 where 32-wide blocks waste 6 % of the MFMAs; its planes are 10 x 18 voxels.
-constexpr int MARCH_VS = 36;
-template <int MW, int NRB, int NTHR> struct MarchGeo {     // NRB row blocks (of 32 voxels) per workgroup column
-    static constexpr int R = 32 / MW;              // rows per 32-voxel row block
-    static constexpr int TH = NRB * R, EH = TH + 2, EW = MW + 2;
-    static constexpr int SLOT = EH * EW * MARCH_VS;                 // floats per ring slot
-    static constexpr int NF4 = (EH * EW * 8 + NTHR - 1) / NTHR;
-};
-
 struct MarchArgs {
     ConvArgs c;
     int ncols;           // B * nHt * nWt workgroup columns; the (column, d) plane list is split evenly over the grid
@@ -432,230 +408,13 @@ struct MarchArgs {
     const float* acc_in; // partial sums of an earlier K slice (same layout as out), or null
 };
 
-// NQ = 8-channel K steps a wave multiplies per tap: 2 = wave pairs split K as described above (4 row blocks per
-// column); 4 = every wave owns a whole row block (8 row blocks per column: 16 x 16 or 8 x 32 voxels), no
-// accumulator exchange, twice the MFMAs per plane and barrier pair.
-// NWV = waves per workgroup.  8: one workgroup per CU (LDS ring 78-87 KB + exchange buffer).  4 (whole-K waves only): a
-// column of 4 row blocks, no exchange buffer -> TWO independent workgroups per CU, one wave of each per SIMD: while one
-// workgroup sits in its per-plane barriers / epilogue stores, the other one's wave keeps the SIMD's matrix pipe busy.
-template <int NT, int MW, int NQ, int NWV = 8>
-__global__ __launch_bounds__(NWV * 64) void conv3d_march_kernel(MarchArgs ma) {
-    constexpr bool KSPLIT = (NQ == 2);
-    constexpr int MARCH_THREADS = NWV * 64;
-    using G = MarchGeo<MW, KSPLIT ? NWV / 2 : NWV, MARCH_THREADS>;
-    constexpr int MARCH_TH = G::TH, MARCH_EH = G::EH, MARCH_EW = G::EW, MARCH_SLOT = G::SLOT, MARCH_NF4 = G::NF4;
-    const ConvArgs& a = ma.c;
-    STX_DYN_SMEM(smem);
-    float* ring = reinterpret_cast<float*>(smem);                       // [3][MARCH_SLOT]
-    float* xch = ring + 3 * MARCH_SLOT;                                  // [4 rows][2][NT][8][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, half = lane >> 5;
-    const int th = KSPLIT ? (wave & 3) : wave, kh2 = KSPLIT ? (wave >> 2) : 0;     // row block, K half
-    // Work list: all (column, output plane d) pairs, column-major; workgroup k owns the k-th of gridDim.x equal
-    // contiguous pieces (256 workgroups = one per CU: no tail round, unlike whole segments per workgroup), and
-    // walks it as runs of consecutive planes of one column.
-    int b = 0, oh0 = 0, ow0 = 0, d_lo = 0, d_hi = 0;                     // current run: planes [d_lo, d_hi)
-    const long long units = (long long)ma.ncols * a.Do;                  // < 2^31 (checked by the host)
-    const long long wg = xcd_remap(blockIdx.x, gridDim.x);
-    int u = __builtin_amdgcn_readfirstlane((int)(units * wg / gridDim.x));
-    const int u_end = __builtin_amdgcn_readfirstlane((int)(units * (wg + 1) / gridDim.x));
-
-    // per-lane staging assignment: float4 number idx = tid + k*512 of a plane (voxel v = idx/8, chunk f = idx%8)
-    float4 stg[MARCH_NF4];
-    auto load_plane = [&](int pd) {
-#pragma unroll
-        for (int k = 0; k < MARCH_NF4; ++k) {
-            const int idx = tid + k * MARCH_THREADS;
-            const int v = idx >> 3, f = idx & 7;
-            const int wx = v % MARCH_EW, hy = v / MARCH_EW;
-            const int gh = oh0 - 1 + hy, gw = ow0 - 1 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < MARCH_EH * MARCH_EW && pd >= 0 && pd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * 32 + 4 * f);
-            stg[k] = val;
-        }
-    };
-    auto store_plane = [&](int pd) {
-        float* slot = ring + ((pd + 3) % 3) * MARCH_SLOT;
-#pragma unroll
-        for (int k = 0; k < MARCH_NF4; ++k) {
-            const int idx = tid + k * MARCH_THREADS;
-            const int v = idx >> 3, f = idx & 7;
-            if (v < MARCH_EH * MARCH_EW) stx_st4(slot + v * MARCH_VS + 4 * f, stg[k]);
-        }
-    };
-
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
-    const int abase = ((th * G::R + i / MW) * MARCH_EW + i % MW) * MARCH_VS + 4 * half + 16 * kh2;
-    // packed weights of my K half (q = 2*kh2, 2*kh2+1): wave-uniform base (provably: readfirstlane) +
-    // a 32-bit per-lane offset, so every tap's load is `global_load v, v_off, s[base] offset:imm`
-    // instead of 54 precomputed 64-bit address pairs.
-    const int kh2u = __builtin_amdgcn_readfirstlane(kh2);
-    const float* wq = a.wp + (size_t)(2 * kh2u) * NT * 256;
-    const unsigned wlane = (unsigned)lane * 4u;
-
-    while (u < u_end) {
-    {
-        const int col = u / a.Do;
-        d_lo = u - col * a.Do;
-        const int left = u_end - u;
-        d_hi = (a.Do - d_lo < left) ? a.Do : d_lo + left;
-        u += d_hi - d_lo;
-        const int wt = col % a.nWt, ht = (col / a.nWt) % a.nHt;
-        b = col / (a.nWt * a.nHt);
-        oh0 = ht * MARCH_TH; ow0 = wt * MW;
-        // ring slots are free: every wave passed the barrier behind the previous run's last MFMA
-        load_plane(d_lo - 1);
-        store_plane(d_lo - 1);
-        load_plane(d_lo);
-        store_plane(d_lo);
-        load_plane(d_lo + 1);
-    }
-    for (int d = d_lo; d < d_hi; ++d) {
-        if (ma.ablate != 1) store_plane(d + 1);   // slot of plane d-2: free since the barrier ending iteration d-1
-        __syncthreads();
-        if (d + 2 <= d_hi && ma.ablate != 1) load_plane(d + 2);
-
-        // Two independent accumulator chains per column block (one per K step of the tap): a single
-        // chain of dependent fp32 MFMAs does not keep the matrix pipe full.
-        f32x16 acc2[2][NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { acc2[0][nt] = zero16(); acc2[1][nt] = zero16(); }
-        // Operand ping-pong, one tap ahead.  sched_barrier pins "issue the next tap's loads, THEN the
-        // current tap's MFMAs": left alone, hipcc sinks the weight loads next to their use and every
-        // tap waits a full L2 round trip (s_waitcnt vmcnt right in front of the MFMAs: 60 % MFMA busy).
-        // The 27 taps are fully unrolled: every LDS / weight offset is an immediate, so a tap costs
-        // 2 ds_read_b128 + 2*NT global_load_dwordx4 + 8*NT MFMAs and almost no address arithmetic
-        // (a clump of scalar/vector address code between MFMA groups leaves the matrix pipe idle: an
-        // in-order wave can only hide a handful of instructions behind each 64-cycle MFMA).
-        // Scheduling fences pin "issue loads, then multiply": without them hipcc sinks each weight load
-        // to ~3 MFMAs before its first use (s_waitcnt vmcnt right behind it) and every tap stalls on L2.
-        constexpr int NBUF = KSPLIT ? 3 : 2;
-        float4 av[NBUF][NQ], bv[NBUF][NQ][NT];
-        const float* slotp[3];
-#pragma unroll
-        for (int kd = 0; kd < 3; ++kd) slotp[kd] = ring + ((d - 1 + kd + 3) % 3) * MARCH_SLOT + abase;
-        auto load_tap = [&](int tap, int buf) {
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const float* sl = slotp[kd] + (kh * MARCH_EW + kw) * MARCH_VS;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) av[buf][q] = stx_ld4(sl + 8 * q);
-            unsigned wl = wlane;
-            STX_OPAQUE_VGPR(wl);     // keep the per-tap weight addresses out of (spilled) registers
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bv[buf][q][nt] = stx_ld4((wq + (size_t)(tap * 4 * NT * 256 + (q * NT + nt) * 256)) + wl);
-        };
-        auto mma_tap = [&](int buf) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    acc2[q & 1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][q].x, bv[buf][q][nt].x, acc2[q & 1][nt], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    acc2[q & 1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][q].y, bv[buf][q][nt].y, acc2[q & 1][nt], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    acc2[q & 1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][q].z, bv[buf][q][nt].z, acc2[q & 1][nt], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    acc2[q & 1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][q].w, bv[buf][q][nt].w, acc2[q & 1][nt], 0, 0, 0);
-            }
-        };
-        // K split: prefetch distance = 2 taps (3 rotating register buffers): the loads of tap t+2 are issued,
-        // fenced, before the 8*NT MFMAs of tap t, so they have >= 16*NT MFMAs (1-2k cycles) to land.
-        // Whole-K waves multiply 16 MFMAs per tap: one tap ahead (2 buffers) gives the same cover.
-        load_tap(0, 0);
-        if (NBUF == 3) load_tap(1, 1);
-        STX_SCHED_BARRIER();
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + NBUF - 1 < 27) load_tap(tap + NBUF - 1, (tap + NBUF - 1) % NBUF);
-            STX_SCHED_BARRIER();
-            mma_tap(tap % NBUF);
-            STX_SCHED_BARRIER();
-        }
-        f32x16 acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = acc2[0][nt] + acc2[1][nt];
-        // K split: K-half 0 keeps accumulator regs 0..7 (rows 0-3, 8-11 (+4*half)), K-half 1 keeps 8..15
-        float* mine = xch + (((th * 2 + kh2) * NT) * 8) * 64;
-        float* theirs = xch + (((th * 2 + (kh2 ^ 1)) * NT) * 8) * 64;
-        if (KSPLIT) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) mine[(nt * 8 + r) * 64 + lane] = acc[nt][kh2 ? r : 8 + r];
-        }
-        __syncthreads();                    // every wave is done reading ring slot (d-1)%3 (and xch is complete)
-        const size_t plane0 = ((size_t)b * a.Do + d) * a.Ho;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + i;
-            const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
-            const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < (KSPLIT ? 8 : 16); ++r) {
-                const int rr = (KSPLIT && kh2) ? 8 + r : r;
-                const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;          // voxel of the row block
-                const int oh = oh0 + th * G::R + row / MW, ow = ow0 + row % MW;
-                if (oh < a.Ho && ow < a.Wo && n < a.Cout && (ma.ablate != 2 || d == d_lo)) {
-                    const size_t idx = ((plane0 + oh) * a.Wo + ow) * a.Cout + n;
-                    float v = acc[nt][rr];
-                    if (KSPLIT) v += theirs[(nt * 8 + r) * 64 + lane];
-                    s1[nt] += v;
-                    s2[nt] = fmaf(v, v, s2[nt]);
-                    v = fmaf(v, sc, bs);
-                    if (a.residual) v += a.residual[idx];
-                    v = stx_act(v, a.relu);
-                    a.out[idx] = v;
-                }
-            }
-        }
-    }
-    }   // runs
-    if (a.stats) {
-        // 8 waves: reduce through the (now idle) ring
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            s1[nt] += __shfl_xor(s1[nt], 32);
-            s2[nt] += __shfl_xor(s2[nt], 32);
-        }
-        __syncthreads();
-        if (lane < 32) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                ring[((wave * NT + nt) * 32 + lane) * 2 + 0] = s1[nt];
-                ring[((wave * NT + nt) * 32 + lane) * 2 + 1] = s2[nt];
-            }
-        }
-        __syncthreads();
-        if (tid < NT * 32 && tid < a.Cout) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < NWV; ++w) {
-                t1 += ring[((w * NT) * 32 + tid) * 2 + 0];
-                t2 += ring[((w * NT) * 32 + tid) * 2 + 1];
-            }
-            const size_t slab = (size_t)blockIdx.x;
-            a.stats[slab * 2 * a.Cout + tid] = t1;
-            a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// 3x3x3 stride-1 convolution 32 -> 32, second-generation march kernel: the WEIGHTS live in LDS and the planes are
+// 3x3x3 stride-1 convolution in 32 x 32 channel slices ("march" kernel): the WEIGHTS live in LDS and the planes are
 // input-stationary.
 //
-// conv3d_march_kernel above streams the packed weights from L2 for every tap of every plane (each wave fetches 4 KB
-// per 16 MFMAs: ~31 B/clk/CU of L2 traffic, and its two barriers + accumulator exchange per plane leave the matrix pipe
-// idle: 0.60-0.63 of the fp32-MFMA peak).  Here a workgroup is 4 waves, ONE per SIMD, and
+// (The first generation of this kernel -- rounds 1-2, removed in round 3 -- streamed the packed weights from L2 for every
+// tap of every plane and needed two barriers + an accumulator exchange per plane: 0.60-0.63 of the fp32-MFMA peak.)
+// A workgroup is 4 waves, ONE per SIMD, and
 //   * the 27 x 32 x 32 packed weights (110 592 B, MFMA B-operand order) are loaded into LDS once per workgroup; both
 //     operands of every MFMA then come from LDS (8 ds_read_b128 per 16 MFMAs per wave = 12 % of the LDS bandwidth);
 //   * LDS holds two input planes (double buffer, 10 x 18 voxels x 36 dwords = 25 920 B each: a column of 8 x 16 output
@@ -930,10 +689,12 @@ constexpr DcEntries dc_entries(int cset) {
 }
 
 // One K chunk of the transposed convolution for a wave: the work list above as straight-line code, the weight operands
-// of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The loop nest in the
-// kernel below has run-time bounds; hipcc keeps it rolled and waits for each tap's loads right before its first MFMA:
-// an L2 round trip per 16 MFMAs -- GPU call O: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes.)
-template <int CSET, int NT, int CK, bool APRE>
+// of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The first version walked
+// the classes and taps in a loop nest with run-time bounds; hipcc kept it rolled and waited for each tap's loads right
+// before its first MFMA, an L2 round trip per 16 MFMAs: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes, GPU
+// call O of round 2.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower:
+// calls Q-T of round 2, call G of round 3.)
+template <int CSET, int NT, int CK>
 __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
     constexpr DcEntries E = dc_entries(CSET);
     constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8;
@@ -951,15 +712,11 @@ __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const floa
         for (int q = 0; q < QS; ++q) av[buf][q] = stx_ld4(atile + toff + q * 8);
     };
     load_b(0, 0);
-    if (APRE) load_a(0, 0);
 #pragma unroll
     for (int t = 0; t < E.n; ++t) {
-        if (t + 1 < E.n) {
-            load_b(t + 1, (t + 1) & 1);
-            if (APRE) load_a(t + 1, (t + 1) & 1);              // (APRE: the LDS operands one entry ahead as well)
-        }
+        if (t + 1 < E.n) load_b(t + 1, (t + 1) & 1);
         STX_SCHED_BARRIER();
-        if (!APRE) load_a(t, t & 1);
+        load_a(t, t & 1);
 #pragma unroll
         for (int q = 0; q < QS; ++q) {
             const float4 a4 = av[t & 1][q];
@@ -976,9 +733,7 @@ __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const floa
     }
 }
 
-// PIPE: 0 = rolled tap loops (first generation), 1 = straight-line tap list with the weights one entry ahead,
-// 2 = LDS operands one entry ahead as well
-template <int NT, int CK, int PIPE>
+template <int NT, int CK>
 __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_kernel(ConvArgs a) {
     constexpr int TH = 2;
     constexpr int ED = 2, EH = TH + 1, EW = 33;
@@ -1016,41 +771,8 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
         }
         __syncthreads();
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        if (PIPE) {
-            if (cset == 0) deconv_chunk_taps<0, NT, CK, PIPE == 2>(tile + abase, wq, NQ, acc);
-            else deconv_chunk_taps<1, NT, CK, PIPE == 2>(tile + abase, wq, NQ, acc);
-            continue;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int cls = cls_tab[cset][c];
-            const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-            for (int sd = 0; sd <= pd; ++sd)
-                for (int sh = 0; sh <= ph; ++sh)
-                    for (int sw = 0; sw <= pw; ++sw) {
-                        // parity 0: (k=1, delta=0); parity 1: s=0 -> (k=0, delta=1), s=1 -> (k=2, delta=0)
-                        const int kd = pd ? (sd ? 2 : 0) : 1, dd = pd ? (sd ? 0 : 1) : 0;
-                        const int kh = ph ? (sh ? 2 : 0) : 1, dh = ph ? (sh ? 0 : 1) : 0;
-                        const int kw = pw ? (sw ? 2 : 0) : 1, dw = pw ? (sw ? 0 : 1) : 0;
-                        const int tap = (kd * 3 + kh) * 3 + kw;
-                        const int toff = ((dd * EH + dh) * EW + dw) * VS;
-                        const float* wtap = wq + (size_t)tap * NQ * NT * 256;
-#pragma unroll
-                        for (int q = 0; q < CK / 8; ++q) {
-                            const float4 av = stx_ld4(tile + abase + toff + q * 8);
-                            float4 bv[NT];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) bv[nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) {
-                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[nt].x, acc[c][nt], 0, 0, 0);
-                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[nt].y, acc[c][nt], 0, 0, 0);
-                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[nt].z, acc[c][nt], 0, 0, 0);
-                                acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[nt].w, acc[c][nt], 0, 0, 0);
-                            }
-                        }
-                    }
-        }
+        if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
+        else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
     }
 
     float s1[NT], s2[NT];
@@ -1127,57 +849,9 @@ struct WgradArgs {
     int Dc, Hc, Wc, CC;
     int nHt, nWt, ntiles;
     int ablate;          // profiling only (STX_WGRAD_ABLATE): 1 = no tile staging, 2 = no MFMA loop
-    int v2;              // 1: straight-line MFMA loop per tap count (see wgrad_pairs), 0: first version (A/B: STX_WGRAD_V2)
 };
 
-// MFMA loop of the weight gradient over one staged tile for a wave that owns NA taps (3 or 4 of the 27 with eight waves):
-// the first version asked `t * NW + wave < T` in front of every MFMA (exec-mask juggling and a branch per tap, basic
-// blocks of one MFMA that nothing can be scheduled into); here the tap count is a compile-time constant chosen ONCE per
-// wave, each voxel pair is a straight line of NA MFMAs, and the NA + 1 LDS reads of the next pair are dealt one per MFMA
-// into their shadow instead of being issued as a burst in front of them.
-template <int NA, int TH, int TW, int S, int EWS>
-__device__ __forceinline__ void wgrad_pairs(const float* ftile, const float* ctile, const int (&toff)[NA], int i, int half,
-                                            f32x16 (&acc)[NA]) {
-    constexpr int PR = TW / 2;                                      // voxel pairs per tile row (even: 8 or 16)
-    constexpr int FSTR = S * EWS * 32, CSTR = TW * 32;              // floats between tile rows (fine / coarse)
-    float av[2][NA], bv[2];
-    // operand addresses: one base register per tap and row (+ immediate offsets for the pairs of the row: 256 B apart)
-    const float* f0 = ftile + half * 32 + i;
-    const float* c0 = ctile + half * 32 + i;
-    const float* fcur = f0;
-    const float* ccur = c0;
-    auto load_pair = [&](const float* fb, const float* cb_, int off, int buf) {
-        bv[buf] = cb_[off];
-#pragma unroll
-        for (int t = 0; t < NA; ++t) av[buf][t] = fb[toff[t] + off];
-    };
-    load_pair(fcur, ccur, 0, 0);
-#pragma unroll 1
-    for (int lh = 0; lh < TH; ++lh) {
-        const float* fnext = (lh + 1 < TH) ? fcur + FSTR : f0;       // (the last prefetch wraps: uniform pipeline depth)
-        const float* cnext = (lh + 1 < TH) ? ccur + CSTR : c0;
-#pragma unroll
-        for (int pp = 0; pp < PR; ++pp) {
-            const int cb = pp & 1;
-            if (pp + 1 < PR) load_pair(fcur, ccur, (pp + 1) * 64, cb ^ 1);
-            else load_pair(fnext, cnext, 0, cb ^ 1);
-#pragma unroll
-            for (int t = 0; t < NA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][t], bv[cb], acc[t], 0, 0, 0);
-            STX_SCHED_GROUP(0x008, 1);
-            STX_SCHED_GROUP(0x100, 2);
-#pragma unroll
-            for (int t = 1; t < NA; ++t) {
-                STX_SCHED_GROUP(0x008, 1);
-                STX_SCHED_GROUP(0x100, 1);
-            }
-            STX_SCHED_BARRIER();
-        }
-        fcur = fnext;
-        ccur = cnext;
-    }
-}
-
-template <int KS, int S, int TH, int TW, int NW, bool PIPE, bool V2 = false>
+template <int KS, int S, int TH, int TW, int NW, bool PIPE>
 __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int PAD = KS / 2;
@@ -1271,37 +945,6 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 const float av = ftile[(lh * EWS + lw) * 32 + i];
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
             }
-        } else if (V2) {
-            if constexpr (V2 && NTAP >= 2 && NTAP * NW - T < NW) {
-            // straight-line loop: waves [0, T - (NTAP-1)*NW) own NTAP taps, the others NTAP - 1 (wave-uniform choice)
-            const int nfull = T - (NTAP - 1) * NW;
-            if (__builtin_amdgcn_readfirstlane(wave) < nfull) {
-                int toff[NTAP];
-#pragma unroll
-                for (int t = 0; t < NTAP; ++t) {
-                    const int tap = t * NW + wave;
-                    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                    toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
-                                       : ((kd * EH + kh) * EWS + kw) * 32;
-                }
-                wgrad_pairs<NTAP, TH, TW, S, EWS>(ftile, ctile, toff, i, half, acc);
-            } else {
-                constexpr int N1 = NTAP >= 2 ? NTAP - 1 : 1;
-                int toff[N1];
-                f32x16 acc1[N1];
-#pragma unroll
-                for (int t = 0; t < N1; ++t) {
-                    const int tap = t * NW + wave;
-                    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                    toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
-                                       : ((kd * EH + kh) * EWS + kw) * 32;
-                    acc1[t] = acc[t];
-                }
-                wgrad_pairs<N1, TH, TW, S, EWS>(ftile, ctile, toff, i, half, acc1);
-#pragma unroll
-                for (int t = 0; t < N1; ++t) acc[t] = acc1[t];
-            }
-            }
         } else {
             // address of operand A = (voxel part) + (tap part): tap offsets live in NTAP registers, the
             // operands of voxel pair p+1 are fetched while pair p is multiplied (pinned by the fences).
@@ -1356,36 +999,9 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dW[cc][cf][tap] = sum over chunks (and waves for KS=1) of the slab, in a fixed order.
-// A workgroup reduces 64 consecutive outputs; its 4 waves take every 4th slab row and meet in LDS.
-__global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_reduce_kernel(const float* __restrict__ slab,
-                                                                           float* __restrict__ dw, int CF, int CC,
-                                                                           int T, int nchunks, int rows_per_chunk) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + lane;                        // over [pair][tap][cf32][cc32]
-    const int ncf = CF / 32;
-    const int cc_l = idx & 31, cf_l = (idx >> 5) & 31;
-    const int tap = (idx >> 10) % T, pair = (idx >> 10) / T;
-    const int cfb = pair % ncf, ccb = pair / ncf;
-    float s = 0.f;
-    if (rows_per_chunk == T) {
-        const float* p = slab + ((size_t)pair * nchunks * T + tap) * 1024 + cf_l * 32 + cc_l;
-        for (int c = wave; c < nchunks; c += 4) s += p[(size_t)c * T * 1024];
-    } else {  // KS=1: one slab row per wave of the producer
-        const float* p = slab + ((size_t)pair * nchunks * rows_per_chunk) * 1024 + cf_l * 32 + cc_l;
-        for (int c = wave; c < nchunks * rows_per_chunk; c += 4) s += p[(size_t)c * 1024];
-    }
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0)
-        dw[((size_t)(ccb * 32 + cc_l) * CF + cfb * 32 + cf_l) * T + tap] =
-            (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-
-// Second generation of the slab reduction: 16 lanes x float4 cover the workgroup's 64 outputs, the four 16-lane groups
-// of the four waves take every 16th slab row (16 rows of 256 contiguous bytes in flight per wave instruction instead of
-// one dword per lane behind a dependent add: 29 us -> the slab's L2 read time), then one LDS round in a fixed order.
+// dW[cc][cf][tap] = sum over chunks (and waves for KS=1) of the slab, in a fixed order (deterministic): 16 lanes x float4
+// cover the workgroup's 64 outputs, the four 16-lane groups of the four waves take every 16th slab row (16 rows of 256
+// contiguous bytes in flight per wave instruction), then one LDS round.
 __global__ __launch_bounds__(CONV_THREADS) void conv3d_wgrad_reduce4_kernel(const float* __restrict__ slab,
                                                                             float* __restrict__ dw, int CF, int CC,
                                                                             int T, int nchunks, int rows_per_chunk) {
@@ -1450,28 +1066,15 @@ int launch_persistent(K kernel, size_t lds, hipStream_t st, ConvArgs a, int ntil
     if (lds > 160 * 1024) return stx_set_error(STX_ERR_ARG, "conv3d: LDS tile of %zu B exceeds 160 KiB", lds);
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const int env = getenv("STX_CONV_PIPE_WGS") ? atoi(getenv("STX_CONV_PIPE_WGS")) : 0;
     int per_cu = (int)((160 * 1024) / (lds + 512));
     per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    if (env > 0) per_cu = env;
     int grid = 256 * per_cu;
     if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(CONV_THREADS), lds, st, a, ntiles);
     return 0;
 }
 
-template <int KS, int S>
-int conv_dispatch_pipe(const ConvArgs& a, int NT, int CK, int ntiles, hipStream_t st) {
-    const size_t lds = conv_lds_bytes<KS, S>(CK, NT);
-#define CONVP_CASE(NT_, CK_)                                                                                       \
-    if (NT == NT_ && CK == CK_)                                                                                    \
-        return launch_persistent(conv3d_pgemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, lds, st, a, ntiles);
-    CONVP_CASE(1, 32) CONVP_CASE(2, 32) CONVP_CASE(4, 16)
-    CONVP_CASE(1, 8) CONVP_CASE(2, 8) CONVP_CASE(4, 8)
-#undef CONVP_CASE
-    return -1;
-}
-
+// Implicit-GEMM kernel for NT column blocks of 32 output channels and K chunks of CK input channels.
 template <int KS, int S>
 int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) {
     const size_t lds = conv_lds_bytes<KS, S>(CK, NT);
@@ -1479,7 +1082,6 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
     if (NT == NT_ && CK == CK_)                                                                                    \
         return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, grid, lds, st, a);
     CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32)
-    CONV_CASE(1, 16) CONV_CASE(2, 16) CONV_CASE(4, 16)
     CONV_CASE(1, 8) CONV_CASE(2, 8) CONV_CASE(4, 8)
 #undef CONV_CASE
     return stx_set_error(STX_ERR_ARG, "conv3d: unsupported NT=%d CK=%d", NT, CK);
@@ -1487,16 +1089,10 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
 
 }  // namespace
 
-// Cin chunk used by the kernels for a given Cin (multiple of 8).  STX_CONV_CK overrides (tuning).
-// 3x3x3: 8-channel chunks (GPU call T: the LDS tile shrinks to 26 KB and the register budget to ~100, so up to four
-// workgroups share a CU instead of two: 64->64 L1 0.486 -> 0.430 ms, 128->128 L2 0.242 -> 0.232 ms); 1x1x1 (HBM-bound,
-// no halo): 32-channel chunks.
-static int conv_pick_ck(int Cin, int ks) {
-    static const int env = getenv("STX_CONV_CK") ? atoi(getenv("STX_CONV_CK")) : 0;
-    if (env && Cin % env == 0) return env;
-    if (ks == 3) return 8;
-    return (Cin % 32 == 0) ? 32 : 8;
-}
+// Cin chunk of the implicit-GEMM kernels (Cin is a multiple of 8).  3x3x3: 8-channel chunks (GPU call T of round 2: the LDS
+// tile shrinks to 26 KB and the register budget to ~100, so up to four workgroups share a CU instead of two: 64->64 L1
+// 0.486 -> 0.430 ms, 128->128 L2 0.242 -> 0.232 ms); 1x1x1 (HBM-bound, no halo): 32-channel chunks where Cin allows.
+static int conv_pick_ck(int Cin, int ks) { return (ks == 1 && Cin % 32 == 0) ? 32 : 8; }
 // 32-wide MFMA column blocks used for N output channels (1, 2 or 4).
 static int conv_nt(int N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
@@ -1517,30 +1113,21 @@ extern "C" int stx_conv3d_pack_weight(const float* w, float* wp, int A, int Bd, 
     return stx_check_launch("conv3d_pack_weight");
 }
 
-static int march_mw(int W) {
-    static const int force32 = getenv("STX_MARCH_MW32") ? 1 : 0;
-    return (!force32 && stx_cdiv(W, 16) * 16 < stx_cdiv(W, 32) * 32) ? 16 : 32;
-}
-// Workgroups of the march kernel: one per CU (its LDS ring admits only one), fewer for tiny volumes so that a
-// workgroup still gets a few planes per 2-plane prologue.
-static int march_wgs(long long units, int per_cu) {
-    static const int env = getenv("STX_MARCH_WGS") ? atoi(getenv("STX_MARCH_WGS")) : 0;
-    long long g = env > 0 ? env : 256 * per_cu;
+// Workgroups of the march kernel: one per CU (its LDS admits only one), fewer for tiny volumes so that a workgroup still
+// gets a few planes per 2-plane prologue.
+static int march_wgs(long long units) {
+    long long g = 256;
     if (g > units / 3) g = units / 3;
     return g < 1 ? 1 : (int)g;
 }
-static bool use_march(int Cin, int Cout, int ks, int stride) {
-    static const int off = getenv("STX_NO_MARCH") ? 1 : 0;
-    return !off && ks == 3 && stride == 1 && Cin == 32 && Cout <= 64;
-}
 
-// Rows of the `stats` partial slab stx_conv3d_fwd writes per batch item (>= its workgroup count / B;
-// unused rows are zero-filled).
+// Rows of the `stats` partial slab stx_conv3d_fwd writes per batch item (>= its workgroup count / B for every kernel it
+// may choose; unused rows are zero-filled).
 extern "C" int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo) {
     stx_begin();
     const int a = stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
-    const int m = Do * stx_cdiv(Ho, 4) * stx_cdiv(Wo, 32);            // upper bounds for the march kernel
-    const int m16 = Do * stx_cdiv(Ho, 8) * stx_cdiv(Wo, 16);
+    const int m = Do * stx_cdiv(Ho, 4) * stx_cdiv(Wo, 32);
+    const int m16 = Do * stx_cdiv(Ho, 8) * stx_cdiv(Wo, 16);           // upper bound for the march kernel's workgroups
     return a > m ? (a > m16 ? a : m16) : (m > m16 ? m : m16);
 }
 extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) {
@@ -1563,32 +1150,29 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     a.Wo = (Wi + 2 * pad - ks) / stride + 1;
     a.nDt = stx_cdiv(a.Do, CONV_TD); a.nHt = stx_cdiv(a.Ho, CONV_TH); a.nWt = stx_cdiv(a.Wo, 32);
     const int NT = conv_nt(Cout);
+    hipStream_t st = (hipStream_t)stream;
     // the slab has stx_conv3d_fwd_blocks() rows per batch item; rows no workgroup writes must read 0
-    if (stats)
-        hipMemsetAsync(stats, 0, (size_t)B * stx_conv3d_fwd_blocks(a.Do, a.Ho, a.Wo) * 2 * Cout * 4, (hipStream_t)stream);
-    // Second-generation march kernel (weights resident in LDS, input-stationary planes) for 3x3x3 stride-1 layers in
-    // 32 x 32 channel slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums
-    // and applies the epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).  STX_MARCH_V2=0: first generation.
-    static const int v2_env = getenv("STX_MARCH_V2") ? atoi(getenv("STX_MARCH_V2")) : 1;
-    const int v2_6464 = getenv("STX_MARCH_6464") ? atoi(getenv("STX_MARCH_6464")) : 0;   // tuning (read per call): 64 -> 64 as 2 x 2 slices
-    if (v2_env && ks == 3 && stride == 1 &&
-        ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32) || (v2_6464 && Cin == 64 && Cout <= 64))) {
+    if (stats) hipMemsetAsync(stats, 0, (size_t)B * stx_conv3d_fwd_blocks(a.Do, a.Ho, a.Wo) * 2 * Cout * 4, st);
+    // March kernel (weights resident in LDS, input-stationary planes) for the 3x3x3 stride-1 layers in 32 x 32 channel
+    // slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums and applies the
+    // epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).
+    if (ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
         MarchArgs m2;
         m2.c = a;
         m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);
         m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
         m2.ncols = B * m2.c.nHt * m2.c.nWt;
-        static const int ablate2 = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
-        m2.ablate = ablate2;
+        m2.ablate = stx_tune(STX_TUNE_MARCH_ABLATE);
         if ((long long)m2.ncols * a.Do < (1ll << 31)) {
-            const int nb2 = march_wgs((long long)m2.ncols * a.Do, 1);
+            const int nb2 = march_wgs((long long)m2.ncols * a.Do);
             const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
-            // STX_MARCH_BS (read per call, A/B): 1 (default) = one accumulator per (output, input plane), summed in the
-            // epilogue; 0 = one sequential accumulation chain per output (first version of the kernel)
-            const int bs_env = getenv("STX_MARCH_BS") ? atoi(getenv("STX_MARCH_BS")) : 1;
-            const int ilv_env = getenv("STX_MARCH_ILV") ? atoi(getenv("STX_MARCH_ILV")) : 0;
-            void (*mk)(MarchArgs) = bs_env ? (ilv_env ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<1, 0>)
-                                           : (ilv_env ? conv3d_marchw_kernel<0, 1> : conv3d_marchw_kernel<0, 0>);
+            // STX_MARCH_BS: 1 = one accumulator per (output, input plane), summed in the epilogue; 0 = one sequential chain per
+            // output.  STX_MARCH_ILV: 1 = operand reads of the next tap dealt between the MFMAs, 0 = issued as a burst in
+            // front of them (GPU call F of round 3, 32 -> 32 L0: 0.776 -> 0.757 ms without / 0.784 -> 0.767 ms with the
+            // blocked sums)
+            const int bs = stx_tune(STX_TUNE_MARCH_BS), ilv = stx_tune(STX_TUNE_MARCH_ILV);
+            void (*mk)(MarchArgs) = bs ? (ilv ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<1, 0>)
+                                       : (ilv ? conv3d_marchw_kernel<0, 1> : conv3d_marchw_kernel<0, 0>);
             hipFuncSetAttribute((const void*)mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
             const int nk = Cin / 32, nn = stx_cdiv(Cout, 32);
@@ -1601,80 +1185,34 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
-                    hipLaunchKernelGGL(mk, dim3(nb2), dim3(256), lds2, (hipStream_t)stream, m);
+                    hipLaunchKernelGGL(mk, dim3(nb2), dim3(256), lds2, st, m);
                 }
-            return stx_check_launch("conv3d_fwd(march v2)");
+            return stx_check_launch("conv3d_fwd(march)");
         }
     }
-    if (use_march(Cin, Cout, ks, stride)) {
-        MarchArgs ma;
-        ma.c = a;
-        const int mw = march_mw(a.Wo);
-        // whole-K waves (NQ = 4) are a tuning switch: measured 1.19 ms vs 1.07 ms for the K split on 32->32 L0
-        static const int wholek_env = getenv("STX_MARCH_WHOLEK") ? 1 : 0;
-        // STX_MARCH_W4: 4-wave whole-K workgroups, two per CU (tuning switch, NT = 1 only)
-        // (measured on 32->32 L0: 0.969 -> 0.932 ms; default on, STX_MARCH_W4=0 selects the 8-wave K-split kernel)
-        static const int w4_env = getenv("STX_MARCH_W4") ? atoi(getenv("STX_MARCH_W4")) : 1;
-        const bool w4 = w4_env && NT == 1;
-        const bool ksplit = !w4 && (!wholek_env || NT == 2);      // NT = 2 without the K split does not fit 256 VGPRs
-        const int nrb = (ksplit || w4) ? 4 : 8;
-        ma.c.nHt = stx_cdiv(a.Ho, nrb * 32 / mw);
-        ma.c.nWt = stx_cdiv(a.Wo, mw);
-        ma.ncols = B * ma.c.nHt * ma.c.nWt;
-        STX_REQUIRE((long long)ma.ncols * a.Do < (1ll << 31), "conv3d_fwd: volume too large");
-        static const int ablate = getenv("STX_MARCH_ABLATE") ? atoi(getenv("STX_MARCH_ABLATE")) : 0;
-        ma.ablate = ablate;
-        const int nblk = march_wgs((long long)ma.ncols * a.Do, w4 ? 2 : 1);
-        const size_t slot = (size_t)(nrb * 32 / mw + 2) * (mw + 2) * MARCH_VS;
-        const size_t lds = ((size_t)3 * slot + (ksplit ? (size_t)4 * 2 * NT * 8 * 64 : 0)) * 4;
-        hipStream_t st = (hipStream_t)stream;
-#define MARCH_LAUNCH_W(NT_, MW_, NQ_, NWV_)                                                                             \
-    {                                                                                                                   \
-        hipFuncSetAttribute((const void*)conv3d_march_kernel<NT_, MW_, NQ_, NWV_>,                                     \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
-        hipLaunchKernelGGL((conv3d_march_kernel<NT_, MW_, NQ_, NWV_>), dim3(nblk), dim3(NWV_ * 64), lds, st, ma);      \
-    }
-#define MARCH_LAUNCH(NT_, MW_, NQ_) MARCH_LAUNCH_W(NT_, MW_, NQ_, 8)
-        if (w4 && mw == 32) MARCH_LAUNCH_W(1, 32, 4, 4)
-        else if (w4) MARCH_LAUNCH_W(1, 16, 4, 4)
-        else if (NT == 2 && mw == 32) MARCH_LAUNCH(2, 32, 2)
-        else if (NT == 2) MARCH_LAUNCH(2, 16, 2)
-        else if (ksplit && mw == 32) MARCH_LAUNCH(1, 32, 2)
-        else if (ksplit) MARCH_LAUNCH(1, 16, 2)
-        else if (mw == 32) MARCH_LAUNCH(1, 32, 4)
-        else MARCH_LAUNCH(1, 16, 4)
-#undef MARCH_LAUNCH
-#undef MARCH_LAUNCH_W
-        return stx_check_launch("conv3d_fwd(march)");
-    }
-    // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: keep it to 8-channel K chunks (79 KB).
-    int CK = (stride == 2) ? 8 : conv_pick_ck(Cin, ks);
+    // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: 8-channel K chunks (79 KB padded, 53 KB dense).
+    const int CK = (stride == 2) ? 8 : conv_pick_ck(Cin, ks);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
-    hipStream_t st = (hipStream_t)stream;
     int rc;
-    // Persistent software-pipelined kernel.  Its staging registers cost the second resident workgroup (254 VGPRs), so it
-    // wins only where the first-generation kernel overlaps poorly: measured (576x960 shapes, same session) 128->128 L2
-    // 0.283 -> 0.245 ms, stride-2 64->128 0.176 -> 0.154 ms, but 64->64 L1 0.470 -> 0.537 ms, 64->32 L0 2.13 -> 2.21 ms,
-    // stride-2 32->64 0.327 -> 0.353 ms.  Policy: 128 output channels only; STX_CONV_PIPE = 0 never / 2 always (tuning).
-    static const int pipe_env = getenv("STX_CONV_PIPE") ? atoi(getenv("STX_CONV_PIPE")) : 1;
-    if ((pipe_env == 2 || (pipe_env == 1 && NT == 4)) && ks == 3 && Cin % 8 == 0) {
-        int ckp = CK;
-        if (NT == 4 && ckp == 32) ckp = 16;      // 128 output channels: 16-channel chunks keep the operand buffers in registers
+    // 128 output channels: persistent software-pipelined kernel (its staging registers cost the second resident workgroup,
+    // so it wins only there: measured at the 576x960 shapes 128->128 L2 0.283 -> 0.245 ms, stride-2 64->128 0.176 -> 0.154 ms,
+    // but 64->64 L1 0.470 -> 0.537 ms, stride-2 32->64 0.327 -> 0.353 ms: round 2, profiles/r02_conv_ab.txt)
+    if (NT == 4 && ks == 3 && CK == 8) {
         const long long nt_all = (long long)grid.x * B;
-        if (nt_all < (1ll << 31) && Cin % ckp == 0) {
+        if (nt_all < (1ll << 31)) {
             // the stats slab has stx_conv3d_fwd_blocks() rows per batch item and this kernel writes row blockIdx.x
-            rc = (stride == 1) ? conv_dispatch_pipe<3, 1>(a, NT, ckp, (int)nt_all, st)
-                               : conv_dispatch_pipe<3, 2>(a, NT, ckp, (int)nt_all, st);
-            if (rc == 0) return stx_check_launch("conv3d_fwd(pipelined)");
-            if (rc > 0) return rc;
+            const size_t lds = stride == 1 ? conv_lds_bytes<3, 1>(8, 4) : conv_lds_bytes<3, 2>(8, 4);
+            rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all)
+                             : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all);
+            if (rc) return rc;
+            return stx_check_launch("conv3d_fwd(pipelined)");
         }
     }
-    // opt-in, not yet timed on the chip (prepared after the last GPU call of round 2): stride 2 with the dense LDS tile
-    const int s2_dense = getenv("STX_CONV_S2_DENSE") ? atoi(getenv("STX_CONV_S2_DENSE")) : 0;
     if (ks == 3 && stride == 1) rc = conv_dispatch<3, 1>(a, NT, CK, grid, st);
-    else if (ks == 3 && s2_dense && NT == 2 && CK == 8) {
-        const size_t lds = (size_t)5 * 5 * 66 * 8 * 4;
-        rc = launch_with_lds(conv3d_igemm_kernel<3, 2, CONV_TD, CONV_TH, 2, 8, 0>, grid, lds, st, a);
+    else if (ks == 3 && NT == 2 && stx_tune(STX_TUNE_CONV_S2_DENSE)) {
+        // stride 2, 32 -> 64 (the first convolution of every hourglass): dense (un-padded) LDS tile, 53 KB: three workgroups
+        // per CU instead of two (GPU call A of round 3: 0.332 -> 0.312 ms)
+        rc = launch_with_lds(conv3d_igemm_kernel<3, 2, CONV_TD, CONV_TH, 2, 8, 0>, grid, (size_t)5 * 5 * 66 * 8 * 4, st, a);
     }
     else if (ks == 3) rc = conv_dispatch<3, 2>(a, NT, CK, grid, st);
     else rc = conv_dispatch<1, 1>(a, NT, CK, grid, st);
@@ -1695,49 +1233,28 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.nDt = Di; a.nHt = stx_cdiv(Hi, 2); a.nWt = stx_cdiv(Wi, 32);
-    const int NT = conv_nt(Cout);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
-    int rc;
-    // A/B switches (read per call).  STX_DECONV_PIPE: 0 rolled tap loops / 1 weights one tap ahead / 2 LDS operands too;
-    // STX_DECONV_CK: K chunk (32 or 16 channels: 64 output channels with 32-channel chunks need 372 VGPRs = one wave
-    // per SIMD)
-    const int pipe = getenv("STX_DECONV_PIPE") ? atoi(getenv("STX_DECONV_PIPE")) : 1;
-    // (GPU call S, 576x960: 128->64 0.223 ms with 372 VGPRs and 32-channel chunks -> 0.168 ms with the occupancy hint
-    //  -> 0.143 ms with 16-channel chunks (15.8 KB of LDS: four workgroups per CU); 64->32 0.327 -> 0.289 -> 0.254 ms)
-    // (call T: 8-channel chunks 0.140 / 0.251 ms, 16-channel 0.157 / 0.280, 32-channel 0.153 / 0.266 on the same box)
-    int ck = getenv("STX_DECONV_CK") ? atoi(getenv("STX_DECONV_CK")) : 8;
-    if (ck != 8 && ck != 16 && ck != 32) ck = 8;
-    const size_t lds = (size_t)2 * 3 * 33 * (ck + 4) * 4;
-#define DC_LAUNCH(NT_, CK_)                                                                        \
-    rc = pipe == 2   ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 2>, grid, lds, st, a)       \
-         : pipe == 1 ? launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 1>, grid, lds, st, a)       \
-                     : launch_with_lds(deconv3d_igemm_kernel<NT_, CK_, 0>, grid, lds, st, a)
-    if (NT == 1) { if (ck == 8) { DC_LAUNCH(1, 8); } else if (ck == 16) { DC_LAUNCH(1, 16); } else { DC_LAUNCH(1, 32); } }
-    else { if (ck == 8) { DC_LAUNCH(2, 8); } else if (ck == 16) { DC_LAUNCH(2, 16); } else { DC_LAUNCH(2, 32); } }
-#undef DC_LAUNCH
+    // 8-channel K chunks (9.5 KB of LDS: four workgroups per CU; calls S/T of round 2: 32-channel chunks 0.153 / 0.266 ms,
+    // 16-channel 0.157 / 0.280, 8-channel 0.140 / 0.251 for the two GwcNet shapes)
+    const size_t lds = (size_t)2 * 3 * 33 * (8 + 4) * 4;
+    int rc = conv_nt(Cout) == 1 ? launch_with_lds(deconv3d_igemm_kernel<1, 8>, grid, lds, st, a)
+                                : launch_with_lds(deconv3d_igemm_kernel<2, 8>, grid, lds, st, a);
     if (rc) return rc;
     return stx_check_launch("deconv3d_fwd");
 }
 
-// Workgroups along the split-K axis for the weight gradient.
-// Spatial tile of the weight-gradient kernel (coarse voxels) and whether tile staging is software-pipelined.
-// 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 when the narrower tile wastes fewer columns
-// (W' = 240 = 15 x 16 = 7.5 x 32: 6 % fewer MFMAs).  STX_WGRAD_PIPE / STX_WGRAD_TW32 are tuning switches.
-static bool wgrad_pipe(int ks, int stride, int npairs) {
-    static const int force = getenv("STX_WGRAD_PIPE") ? atoi(getenv("STX_WGRAD_PIPE")) : -1;
-    if (ks != 3) return false;
-    if (force >= 0) return force != 0;
-    return stride == 2 || npairs <= 2;    // measured: the L1/L2 stride-1 layers (few tiles per chunk) prefer the plain loop
-}
+// Weight gradient: spatial tile (coarse voxels), whether tile staging is software-pipelined, workgroups along split-K.
+// 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 voxels when the narrower tile wastes fewer columns (W' = 240 = 15 x 16 =
+// 7.5 x 32: 6 % fewer MFMAs); the pipelined staging pays for stride 2 and for the one- or two-pair L0 layers (measured: the
+// L1 / L2 stride-1 layers, few tiles per chunk, prefer the plain loop).
+static bool wgrad_pipe(int ks, int stride, int npairs) { return ks == 3 && (stride == 2 || npairs <= 2); }
 static void wgrad_tile(int ks, int stride, int Wc, bool pipe, int* TH, int* TW) {
-    static const int force32 = getenv("STX_WGRAD_TW32") ? 1 : 0;
     *TH = pipe ? 4 : 2; *TW = (stride == 2) ? 16 : 32;
-    if (ks == 3 && stride == 1 && !force32 && stx_cdiv(Wc, 16) * 16 < stx_cdiv(Wc, 32) * 32) { *TH = 4; *TW = 16; }
+    if (ks == 3 && stride == 1 && stx_cdiv(Wc, 16) * 16 < stx_cdiv(Wc, 32) * 32) { *TH = 4; *TW = 16; }
 }
 static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
-    static const int budget = getenv("STX_WGRAD_CHUNKS") ? atoi(getenv("STX_WGRAD_CHUNKS")) : 0;
-    int c = (budget > 0 ? (budget > 512 ? 512 : budget) : (pipe ? 256 : 512)) / npairs;   // workgroups in total
+    int c = (pipe ? 256 : 512) / npairs;                            // workgroups in total
     if (c < 1) c = 1;
     if (c > ntiles) c = ntiles;
     return c;
@@ -1748,15 +1265,11 @@ extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, in
     const int npairs = (CF / 32) * (CC / 32);
     if (npairs < 1 || B < 1 || Dc < 1 || Hc < 1 || Wc < 1) return 0;   // stx_conv3d_wgrad rejects these shapes
     const int rows = (ks == 1) ? 8 : 27;
-    // sized for the largest chunk count any tile/pipeline choice can produce (they are tuning switches)
-    int cmax = 1;
-    for (int pipe = 0; pipe < 2; ++pipe)
-        for (int th = 2; th <= 4; th += 2)
-            for (int tw = 16; tw <= 32; tw += 16) {
-                const int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, th) * stx_cdiv(Wc, tw), npairs, pipe);
-                if (c > cmax) cmax = c;
-            }
-    return (long long)npairs * cmax * rows * 1024;
+    const bool pipe = wgrad_pipe(ks, stride, npairs);
+    int TH, TW;
+    wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
+    const int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW), npairs, pipe);
+    return (long long)npairs * c * rows * 1024;
 }
 
 extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float* workspace, int B, int Df, int Hf,
@@ -1772,9 +1285,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     a.B = B; a.Df = Df; a.Hf = Hf; a.Wf = Wf; a.CF = CF; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.CC = CC;
     const int npairs = (CF / 32) * (CC / 32);
     const bool pipe = wgrad_pipe(ks, stride, npairs);
-    static const int ablate = getenv("STX_WGRAD_ABLATE") ? atoi(getenv("STX_WGRAD_ABLATE")) : 0;
-    a.ablate = ablate;
-    a.v2 = getenv("STX_WGRAD_V2") ? atoi(getenv("STX_WGRAD_V2")) : 0;      // (read per call: A/B)
+    a.ablate = stx_tune(STX_TUNE_WGRAD_ABLATE);
     int TH, TW;
     wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
     a.nHt = stx_cdiv(Hc, TH); a.nWt = stx_cdiv(Wc, TW);
@@ -1783,13 +1294,11 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     dim3 grid(nchunks, npairs);
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
-    static const int nw_env = getenv("STX_WGRAD_WAVES") ? atoi(getenv("STX_WGRAD_WAVES")) : 0;
-    const int NW = (nw_env == 4 || nw_env == 8) ? nw_env : 8;   // 8 waves: 4 taps (64 acc regs) per wave, measured +22 % over 4 waves
+    // 3x3x3: eight waves, 3-4 taps (48-64 accumulator registers) each: measured +22 % over four waves with 7
 #define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, PIPE_, LDS_)                                                           \
     {                                                                                                             \
         const size_t lds = (LDS_);                                                                                \
-        void (*wk)(WgradArgs) = (a.v2 && KS_ == 3 && NW_ == 8) ? conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_, (KS_ == 3 && NW_ == 8)> \
-                                                               : conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_, false>; \
+        void (*wk)(WgradArgs) = conv3d_wgrad_kernel<KS_, S_, TH_, TW_, NW_, PIPE_>;                               \
         hipFuncSetAttribute((const void*)wk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
         hipLaunchKernelGGL(wk, grid, dim3(NW_ * 64), lds, st, a);                                                 \
     }
@@ -1797,12 +1306,10 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
         if (TW == 16 && pipe) WG_LAUNCH(3, 1, 4, 16, 8, true, ((size_t)3 * 6 * 18 + 64) * 32 * 4)
         else if (TW == 16) WG_LAUNCH(3, 1, 4, 16, 8, false, ((size_t)3 * 6 * 18 + 64) * 32 * 4)
         else if (pipe) WG_LAUNCH(3, 1, 4, 32, 8, true, ((size_t)3 * 6 * 34 + 128) * 32 * 4)
-        else if (NW == 8) WG_LAUNCH(3, 1, 2, 32, 8, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
-        else WG_LAUNCH(3, 1, 2, 32, 4, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
+        else WG_LAUNCH(3, 1, 2, 32, 8, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
     } else if (ks == 3) {
         if (pipe) WG_LAUNCH(3, 2, 4, 16, 8, true, ((size_t)3 * 9 * 34 + 64) * 32 * 4)
-        else if (NW == 8) WG_LAUNCH(3, 2, 2, 16, 8, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
-        else WG_LAUNCH(3, 2, 2, 16, 4, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+        else WG_LAUNCH(3, 2, 2, 16, 8, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
     } else {
         WG_LAUNCH(1, 1, 2, 32, 4, false, ((size_t)2 * 32 + 64) * 32 * 4)
     }
@@ -1810,12 +1317,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     int rc = stx_check_launch("conv3d_wgrad");
     if (rc) return rc;
     const int total = npairs * T * 1024;
-    const int red_v1 = getenv("STX_WGRAD_REDUCE_V1") ? 1 : 0;   // A/B switch (read per call): first-generation slab reduction
-    if (red_v1)
-        hipLaunchKernelGGL(conv3d_wgrad_reduce_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st,
-                           workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);   // KS=1 producer uses 4 waves
-    else
-        hipLaunchKernelGGL(conv3d_wgrad_reduce4_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st,
-                           workspace, dw, CF, CC, T, nchunks, ks == 1 ? 4 : 27);
+    hipLaunchKernelGGL(conv3d_wgrad_reduce4_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st, workspace, dw, CF, CC, T,
+                       nchunks, ks == 1 ? 4 : 27);                   // (KS = 1: one slab row per wave of the 4-wave producer)
     return stx_check_launch("conv3d_wgrad_reduce");
 }

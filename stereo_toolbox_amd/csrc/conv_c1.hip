@@ -438,8 +438,7 @@ extern "C" int stx_conv3d_c1_fwd(const float* x, const float* w, const float* re
     stx_begin();
     STX_REQUIRE(x && w && out && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_c1_fwd: bad shape");
     STX_REQUIRE(Cin % C1_CK == 0, "conv3d_c1_fwd: Cin=%d must be a multiple of %d", Cin, C1_CK);
-    static const int no_mfma = getenv("STX_C1_FWD_VALU") ? 1 : 0;
-    if (Cin == 32 && !no_mfma) {
+    if (Cin == 32) {                                   // (other widths: the streaming VALU kernel below)
         const int nHt = stx_cdiv(H, C1F_TH), nWt = stx_cdiv(W, C1F_TW);
         const long long ncols = (long long)B * nHt * nWt, units = ncols * D;
         STX_REQUIRE(units < (1ll << 31), "conv3d_c1_fwd: volume too large");
@@ -473,8 +472,7 @@ extern "C" int stx_conv3d_c1_wgrad(const float* x, const float* gy, float* dw, f
     stx_begin();
     STX_REQUIRE(x && gy && dw && workspace && B > 0, "conv3d_c1_wgrad: null operand");
     STX_REQUIRE(Cin % C1_CK == 0 && Cin <= 4 * C1_CK, "conv3d_c1_wgrad: Cin=%d must be 16..64 in steps of 16", Cin);
-    static const int no_mfma = getenv("STX_C1_WGRAD_VALU") ? 1 : 0;
-    if (Cin % 32 == 0 && !no_mfma) {
+    if (Cin % 32 == 0) {                               // (16- and 48-channel inputs: the VALU kernel below)
         const int nDt = stx_cdiv(D, C1M_TD), nHt = stx_cdiv(H, C1M_TH), nWt = stx_cdiv(W, C1M_TW);
         const long long nt = (long long)B * nDt * nHt * nWt;
         STX_REQUIRE(nt < (1ll << 31), "conv3d_c1_wgrad: volume too large");

@@ -124,6 +124,9 @@ __device__ __forceinline__ f32x4 cvb_zero4() {
 // CPG channels per group; QPW group quads per compute wave (4 QPW >= G / 4); NS chunks of the volume gradient in flight in
 // the loader waves' registers; GT / CCT: G and Cc as compile-time constants (0 / -1: taken from the arguments) -- with them
 // every LDS offset of the inner loops is an instruction immediate.
+// (Eight compute waves -- three waves per SIMD, the ten group quads of the GwcNet volume in 2 rounds per chunk instead of 3 --
+//  measured the same 0.225 ms as four: GPU call G of round 3.  Neither the compute waves nor, with the team schedule, the
+//  memory traffic alone set this kernel's time.)
 template <int CPG, int QPW, int NS, int GT, int CCT>
 __global__ __launch_bounds__((CVB2_NCW + CVB2_NLW) * 64) void cost_volume_bwd_mfma_kernel(CvbArgs a) {
     constexpr int NCW = CVB2_NCW;
@@ -459,7 +462,7 @@ int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
     auto kern = cost_volume_bwd_mfma_kernel<CPG, QPW, NS, GT, CCT>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256;
-    if (const char* e = getenv("STX_CVB_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force short / long runs
+    if (stx_tune(STX_TUNE_CVB_GRID) > 0) grid = stx_tune(STX_TUNE_CVB_GRID);           // tests: force short / long runs
     if (grid > a.macros) grid = a.macros;
     if (a.team) grid = 256;                                 // 8 XCDs x 32 members
     hipLaunchKernelGGL(kern, dim3(grid), dim3((CVB2_NCW + CVB2_NLW) * 64), lds, st, a);
@@ -471,8 +474,7 @@ int cvb_launch(const CvbArgs& a, size_t lds, hipStream_t st) {
 // Returns -1 when the configuration is not served by this kernel (caller falls back to cost_volume.hip).
 int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc, float* gLg, float* gRg,
                     float* gLc, float* gRc, int B, int H, int W, int D, int mask_left, void* stream) {
-    const int off = getenv("STX_CVB_OLD") ? 1 : 0;          // (read per call: tests switch generations)
-    if (off || !G) return -1;
+    if (stx_tune(STX_TUNE_CVB_OLD) || !G) return -1;
     const int cpg = Cg / G;
     if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || (G & 3) || (Cc & 3) || G > 40) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4;
@@ -492,20 +494,17 @@ int stx_cv_bwd_mfma(const float* gvol, const float* Lg, const float* Rg, int Cg,
     // team schedule (see above): one row team per XCD
     // (GPU call O, 576x960: run schedule 0.201 ms, team schedule 0.207-0.222 ms depending on the prefetch depth, first
     // generation 0.303 ms: the team schedule halves the HBM reads but its lock-step costs more than that saves -> opt-in)
-    const int team_env = getenv("STX_CVB_TEAM") ? atoi(getenv("STX_CVB_TEAM")) : 0;
+    const int team_env = stx_tune(STX_TUNE_CVB_TEAM);
     a.nteams = 8;
-    a.team = (team_env && 2 * a.nt > 16 && 2 * a.nt <= 32 && nch == 6 && B * H >= a.nteams && !getenv("STX_CVB_GRID")) ? 1 : 0;
+    a.team = (team_env && 2 * a.nt > 16 && 2 * a.nt <= 32 && nch == 6 && B * H >= a.nteams && stx_tune(STX_TUNE_CVB_GRID) <= 0) ? 1 : 0;
     const size_t lds = ((size_t)2 * (CVB2_DC * cvb_pitch(G) + G) + (size_t)CVB2_RING * (Cg + 4)) * 4;
     if (lds > 160 * 1024) return -1;
     hipStream_t st = (hipStream_t)stream;
     const int GQ = G / 4;
-    if (getenv("STX_CVB_TRACE"))
-        fprintf(stderr, "[stx] cost_volume_bwd(mfma): cpg %d G %d Cc %d D %d chunks %d macros %d lds %zu team %d\n", cpg, G, Cc,
-                D, nch, a.macros, lds, a.team);
     // GwcNet / ACVNet volumes (320 channels in 40 groups, 12 or 0 concat channels): constants folded, STX_CVB_NSET chunks
     // in flight per loader lane (A/B switch)
-    const int nset = getenv("STX_CVB_NSET") ? atoi(getenv("STX_CVB_NSET")) : 3;
-    if (cpg == 8 && G == 40 && (Cc == 12 || Cc == 0) && !getenv("STX_CVB_GENERIC_G")) {
+    const int nset = stx_tune(STX_TUNE_CVB_NSET);
+    if (cpg == 8 && G == 40 && (Cc == 12 || Cc == 0)) {
         if (Cc == 12) {
             if (nset == 2) return cvb_launch<8, 3, 2, 40, 12>(a, lds, st);
             if (nset == 4) return cvb_launch<8, 3, 4, 40, 12>(a, lds, st);

@@ -333,7 +333,7 @@ int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
     auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND, SCALE>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int grid = 256 * wgs_per_cu;
-    if (const char* e = getenv("STX_CV_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;   // tests: force multi-unit runs
+    if (stx_tune(STX_TUNE_CV_GRID) > 0) grid = stx_tune(STX_TUNE_CV_GRID);            // tests: force multi-unit runs
     if (grid > a.macros) grid = a.macros;
     hipLaunchKernelGGL(kern, dim3(grid), dim3((NCW + NSW) * 64), lds, st, a);
     return stx_check_launch("cost_volume_fwd(mfma)");
@@ -344,8 +344,7 @@ int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
 // Returns -1 when the configuration is not served by this kernel (caller falls back to cost_volume.hip).
 int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float* Lc, const float* Rc, int Cc,
                     const float* scale, float* vol, int B, int H, int W, int D, int mask_left, void* stream) {
-    static const int off = getenv("STX_CV_OLD") ? 1 : 0;
-    if (off) return -1;
+    if (stx_tune(STX_TUNE_CV_OLD)) return -1;
     const int cpg = G ? Cg / G : 8;
     if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
@@ -368,31 +367,20 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     a.magic_q = (unsigned)(0x100000000ULL / (unsigned)Q + 1);
     a.magic_tc = (unsigned)(0x100000000ULL / (unsigned)TC + 1);
     // non-temporal stores keep the streamed volume from evicting the (small, re-read) feature rows from L2:
-    // measured 0.173 -> 0.141 ms on the GwcNet_GC build; STX_CV_NT=0 switches them off (tuning)
-    static const int nt_env = getenv("STX_CV_NT") ? atoi(getenv("STX_CV_NT")) : 1;
-    a.nontemporal = nt_env;
-    // workgroups per CU: what the LDS images admit, at most 2 (tuning switch STX_CV_WGS); the wave layouts below are
-    // sized for <= 16 waves per workgroup
-    static const int wgs_env = getenv("STX_CV_WGS") ? atoi(getenv("STX_CV_WGS")) : 0;
+    // measured 0.173 -> 0.141 ms on the GwcNet_GC build
+    a.nontemporal = 1;
+    // workgroups per CU: what the LDS images admit, at most 2; the wave layouts below are sized for <= 16 waves per workgroup
     int wgs = (int)((160 * 1024) / (lds + 1024));
     wgs = wgs < 1 ? 1 : (wgs > 2 ? 2 : wgs);
-    if (wgs_env > 0) wgs = wgs_env;
-    const int qpw_env = getenv("STX_CV_QPW") ? atoi(getenv("STX_CV_QPW")) : 0;
-    static const int nsw_env = getenv("STX_CV_NSW") ? atoi(getenv("STX_CV_NSW")) : 0;
     hipStream_t st = (hipStream_t)stream;
-    // wave layouts <channels per group, quads per compute wave, compute waves, store waves, ring bound>; STX_CV_QPW = 2
-    // selects the fat-wave layouts, STX_CV_NSW = 4 fewer store waves (tuning switches)
+    // wave layouts <channels per group, quads per compute wave, compute waves, store waves, ring bound> (measured in round 2:
+    // fewer store waves are much slower -- 4 instead of 6: 0.21 vs 0.104 ms; two quads per compute wave: no gain)
 #define CVM_LAYOUT(CPG_, ND_)                                                                        \
     {                                                                                                \
         if (GQ == 0 && scale) return cvm_launch<CPG_, 1, 4, 8, ND_, true>(a, wgs, lds, st);          \
-        if (GQ == 0) return nsw_env == 4 ? cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st)           \
-                                         : cvm_launch<CPG_, 1, 4, 8, ND_>(a, wgs, lds, st);          \
-        if (GQ <= 4 && qpw_env != 2) return cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st);         \
-        if (GQ <= 10 && qpw_env != 2)                                                                \
-            return nsw_env == 4 ? cvm_launch<CPG_, 1, 10, 4, ND_>(a, wgs, lds, st)                   \
-                                : cvm_launch<CPG_, 1, 10, 6, ND_>(a, wgs, lds, st);                  \
-        if (GQ <= 10) return nsw_env == 4 ? cvm_launch<CPG_, 2, 5, 4, ND_>(a, wgs, lds, st)          \
-                                          : cvm_launch<CPG_, 2, 5, 8, ND_>(a, wgs, lds, st);         \
+        if (GQ == 0) return cvm_launch<CPG_, 1, 4, 8, ND_>(a, wgs, lds, st);                         \
+        if (GQ <= 4) return cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st);                         \
+        if (GQ <= 10) return cvm_launch<CPG_, 1, 10, 6, ND_>(a, wgs, lds, st);                       \
         if (GQ <= 16) return cvm_launch<CPG_, 2, 8, 8, ND_>(a, wgs, lds, st);                        \
         return -1;                                                                                   \
     }

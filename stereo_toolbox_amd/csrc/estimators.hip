@@ -239,9 +239,8 @@ __global__ __launch_bounds__(ES_THREADS) void modal_bwd_kernel(const float* __re
 
 static int modal_launch(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream,
                         const char* what) {
-    static const int in_place = getenv("STX_MODAL_INPLACE") ? atoi(getenv("STX_MODAL_INPLACE")) : 0;   // A/B switch
     hipStream_t st = (hipStream_t)stream;
-    if (D <= ES_LDS_MAX_D && !in_place) {
+    if (D <= ES_LDS_MAX_D) {
         const dim3 grid(stx_cdiv(HW, ES_WAVE), B);
         const size_t lds = (size_t)D * ES_WAVE * sizeof(float);
         if (kind == 0) {

@@ -288,55 +288,6 @@ __global__ __launch_bounds__(HD_THREADS) void head_fwd_lds_kernel(
 }
 
 template <bool AC>
-__global__ __launch_bounds__(HD_THREADS) void head_bwd_pix_lds_kernel(
-    const float* __restrict__ gout, const float* __restrict__ cost, const float* __restrict__ disp,
-    const float* __restrict__ stats, float* __restrict__ gpix, int Dc, int Hc, int Wc, int D, int H, int W) {
-    STX_DYN_SMEM(smem);
-    float* cs = reinterpret_cast<float*>(smem);
-    HdStep* tw = reinterpret_cast<HdStep*>(cs + (size_t)Dc * HD_THREADS);
-    const int tid = threadIdx.x;
-    const int w_raw = blockIdx.x * HD_THREADS + tid;
-    const int w = w_raw < W ? w_raw : W - 1;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const float rd = hd_scale<AC>(Dc, D), rh = hd_scale<AC>(Hc, H), rw = hd_scale<AC>(Wc, W);
-    const Lerp lh = hd_src<AC>(h, rh, Hc), lw = hd_src<AC>(w, rw, Wc);
-    const int plane = Hc * Wc;
-    hd_build_table<AC>(tw, Dc, D, rd, tid);
-    (void)hd_stage_samples(cs, cost + (size_t)b * Dc * plane, plane, Dc, Wc, lh, lw, tid);
-    __syncthreads();
-    const size_t o = ((size_t)b * H + h) * W + w;
-    const float dv = disp[o], m = stats[2 * o], gs = gout[o] / stats[2 * o + 1];      // g / sum
-    float* gp = gpix + ((size_t)b * Dc * H + h) * W + w;                              // + k * H * W
-    const size_t pstride = (size_t)H * W;
-    const bool live = w_raw < W;
-    float a0 = 0.f, a1 = 0.f;                                                         // gradients of samples k and k + 1
-    for (int k = 0, k0 = __builtin_amdgcn_readfirstlane(tw[0].k); k < k0; ++k)        // (planes below the first interval: none in practice)
-        if (live) gp[k * pstride] = 0.f;
-    hd_walk(cs, tw, Dc, D, tid,
-            [&](float fd, float w0, float w1, float c0, float c1) {
-                const float e = stx_exp(w0 * c0 + w1 * c1 - m);
-                const float gl = gs * e * (fd - dv);                                  // g * p_d * (d - disp)
-                a0 = fmaf(w0, gl, a0);
-                a1 = fmaf(w1, gl, a1);
-            },
-            [&](int k, int kn) {
-                if (k + 1 >= Dc) { a0 += a1; a1 = 0.f; }                              // the clamped upper neighbour is plane k itself
-                if (live) gp[k * pstride] = a0;
-                const int stop = kn < 0 ? Dc : kn;                                    // planes k+1 .. stop-1 are left for good
-                if (k + 1 < stop) {
-                    if (live) gp[(k + 1) * pstride] = a1;
-                    for (int z = k + 2; z < stop; ++z)
-                        if (live) gp[z * pstride] = 0.f;
-                    a1 = 0.f;
-                }
-                a0 = a1;
-                a1 = 0.f;
-            },
-            [&](int& nk) { STX_TIE3(a0, a1, nk); });
-}
-
-// weight with which output index `dst` reads source cell `cell` under the lerp
-template <bool AC>
 __device__ __forceinline__ float hd_weight(int dst, float scale, int n, int cell) {
     const Lerp l = hd_src<AC>(dst, scale, n);
     return (l.i0 == cell ? 1.f - l.t : 0.f) + (l.i1 == cell ? l.t : 0.f);
@@ -513,10 +464,7 @@ __global__ __launch_bounds__(HD_THREADS) void softmax_d_kernel(const float* __re
 // Default 2 (GPU call P, 576x960 D=192, kernel trace): forward 95.4 -> 76.7 us with the LDS kernel, but the backward
 // per-pixel pass is SLOWER with it (93.1 -> 102.7 us: 50 KB of LDS per workgroup leave 3 waves per SIMD where the first
 // version runs 8, and its walk is issue-bound either way); gather 132.3 -> 62.9 us (third generation).
-static int hd_v1_mask() { const char* e = getenv("STX_HEAD_V1"); return e ? atoi(e) : 2; }   // (read per call: tests switch generations)
-static bool hd_use_lds(size_t lds, int bit) {
-    return !(hd_v1_mask() & bit) && lds <= 80 * 1024;
-}
+static bool hd_use_lds(size_t lds) { return lds <= 80 * 1024; }    // (the first-generation kernels serve larger D)
 
 template <bool AC>
 static int head_fwd_launch(const float* cost, float* disp, float* stats, int B, int Dc, int Hc, int Wc, int D, int H,
@@ -524,7 +472,7 @@ static int head_fwd_launch(const float* cost, float* disp, float* stats, int B, 
     STX_REQUIRE(cost && disp && B > 0 && Dc > 0 && Hc > 0 && Wc > 0 && D > 0 && H > 0 && W > 0, "head_fwd: bad shape");
     dim3 grid(stx_cdiv(W, HD_THREADS), H, B);
     const size_t lds = hd_lds_bytes(Dc, D);
-    if (hd_use_lds(lds, 1)) {
+    if (hd_use_lds(lds)) {
         if (lds > 64 * 1024)
             hipFuncSetAttribute((const void*)head_fwd_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(head_fwd_lds_kernel<AC>, grid, dim3(HD_THREADS), lds, (hipStream_t)stream, cost, disp, stats,
@@ -557,17 +505,10 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
                            float* workspace, int B, int Dc, int Hc, int Wc, int D, int H, int W, void* stream) {
     STX_REQUIRE(gout && cost && disp && stats && gcost && workspace && B > 0, "head_bwd: null operand");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = hd_lds_bytes(Dc, D);
-    if (hd_use_lds(lds, 2)) {
-        if (lds > 64 * 1024)
-            hipFuncSetAttribute((const void*)head_bwd_pix_lds_kernel<AC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-        hipLaunchKernelGGL(head_bwd_pix_lds_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), lds, st, gout,
-                           cost, disp, stats, workspace, Dc, Hc, Wc, D, H, W);
-    } else {
-        hipLaunchKernelGGL(head_bwd_pix_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
-                           disp, stats, workspace, Dc, Hc, Wc, D, H, W);
-    }
+    // (an LDS-staged version of this pass, like the forward kernel's, measured slower: 93.1 -> 102.7 us, 50 KB of LDS per
+    //  workgroup leave 3 waves per SIMD where this one runs 8 -- round 2, call P)
+    hipLaunchKernelGGL(head_bwd_pix_kernel<AC>, dim3(stx_cdiv(W, HD_THREADS), H, B), dim3(HD_THREADS), 0, st, gout, cost,
+                       disp, stats, workspace, Dc, Hc, Wc, D, H, W);
     int rc = stx_check_launch("head_bwd(pixels)");
     if (rc) return rc;
     // footprint of a cost cell in output pixels: 2/scale (+ slack for the border clamps)
@@ -579,7 +520,7 @@ static int head_bwd_launch(const float* gout, const float* cost, const float* di
         fh = 2 * stx_cdiv(H, Hc) + 3;
         fw = 2 * stx_cdiv(W, Wc) + 3;
     }
-    if (fh <= HD_GF && fw <= 13 && W % 4 == 0 && W >= 16 && !(hd_v1_mask() & 4))
+    if (fh <= HD_GF && fw <= 13 && W % 4 == 0 && W >= 16)
         hipLaunchKernelGGL(head_bwd_gather4_kernel<AC>, dim3(stx_cdiv(Wc, HD_THREADS), Dc * Hc, B), dim3(HD_THREADS), 0, st,
                            workspace, gcost, Dc, Hc, Wc, H, W, fh);
     else

@@ -330,7 +330,7 @@ extern "C" int stx_sampled_volume_bwd(const float* gvol, const float* Lg, const 
     // two workgroups per CU); STX_SV_BWD_V1 = global atomics only (first version, A/B)
     const int cpg = a.cpg ? a.cpg : 4;
     int nsplit = 0;
-    if (!getenv("STX_SV_BWD_V1"))
+    if (!stx_tune(STX_TUNE_SV_BWD_V1))
         for (int n = 1; n <= 4 && !nsplit; n *= 2) {
             const size_t win = ((size_t)stx_cdiv(G, n) * cpg + Cc) * SV_XW * 4;
             if (lds_tile + win <= (n < 4 ? 80 : 160) * 1024 && (long long)B * n <= 65535) nsplit = n;

@@ -94,6 +94,26 @@ static inline void stx_begin() { (void)hipGetLastError(); }
 
 static inline int stx_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Tuning / A-B switches of the library.  Each has a default (the measured-best path), is read from its environment
+// variable ONCE, when the library is loaded, and can be changed at run time through the C-ABI (stx_set_tuning: tests and
+// tools/kernel_bench.py flip them inside one process).  None changes results beyond fp32 rounding.
+enum StxTune {
+    STX_TUNE_MARCH_BS,       // STX_MARCH_BS       1  march kernel: one accumulator per (output, input plane), summed in the epilogue
+    STX_TUNE_MARCH_ILV,      // STX_MARCH_ILV      1  march kernel: operand reads of the next tap dealt between the MFMAs
+    STX_TUNE_MARCH_ABLATE,   // STX_MARCH_ABLATE   0  profiling: 1 = no plane staging, 2 = no epilogue stores
+    STX_TUNE_WGRAD_ABLATE,   // STX_WGRAD_ABLATE   0  profiling: 1 = no tile staging, 2 = no MFMA loop
+    STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)
+    STX_TUNE_CV_OLD,         // STX_CV_OLD         0  cost volume forward: first-generation builders (fallback path) for every shape
+    STX_TUNE_CV_GRID,        // STX_CV_GRID        0  cost volume forward: workgroups (tests: multi-unit runs)
+    STX_TUNE_CVB_OLD,        // STX_CVB_OLD        0  cost volume backward: first-generation kernels for every shape
+    STX_TUNE_CVB_TEAM,       // STX_CVB_TEAM       0  cost volume backward: row-team schedule (one HBM pass, lock-step)
+    STX_TUNE_CVB_GRID,       // STX_CVB_GRID       0  cost volume backward: workgroups (tests)
+    STX_TUNE_CVB_NSET,       // STX_CVB_NSET       3  cost volume backward: chunks in flight per loader lane (2..4)
+    STX_TUNE_SV_BWD_V1,      // STX_SV_BWD_V1      0  CFNet cascade-volume backward: global atomics only
+    STX_TUNE_COUNT
+};
+int stx_tune(StxTune id);
+
 // Activation code of the conv / BN-apply epilogues (the C-ABI's `relu` argument): 0 none, 1 ReLU, 2 Mish.
 // Mish (reference models/PCWNet/submodule.py:11-18): x * tanh(softplus(x)) with tanh(log(1 + e^x)) = n / (n + 2),
 // n = e^x (e^x + 2) -- one exp and one division, no cancellation (n >= 0); above torch's softplus threshold of 20 the

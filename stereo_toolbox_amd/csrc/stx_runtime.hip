@@ -28,3 +28,35 @@ extern "C" const char* stx_build_info(void) {
     return "stx-gfx950 (hipcc --offload-arch=gfx950)";
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------- tuning switches
+#include <stdlib.h>
+#include <string.h>
+namespace {
+struct TuneEntry { const char* name; int value; };
+TuneEntry g_tune[STX_TUNE_COUNT] = {
+    {"STX_MARCH_BS", 1}, {"STX_MARCH_ILV", 1}, {"STX_MARCH_ABLATE", 0}, {"STX_WGRAD_ABLATE", 0}, {"STX_CONV_S2_DENSE", 1},
+    {"STX_CV_OLD", 0}, {"STX_CV_GRID", 0}, {"STX_CVB_OLD", 0}, {"STX_CVB_TEAM", 0}, {"STX_CVB_GRID", 0}, {"STX_CVB_NSET", 3},
+    {"STX_SV_BWD_V1", 0},
+};
+struct TuneInit {                       // environment read once, when the library is loaded
+    TuneInit() {
+        for (int i = 0; i < STX_TUNE_COUNT; ++i)
+            if (const char* e = getenv(g_tune[i].name)) g_tune[i].value = atoi(e);
+    }
+} g_tune_init;
+}  // namespace
+
+int stx_tune(StxTune id) { return g_tune[id].value; }
+
+extern "C" int stx_get_tuning(const char* name) {
+    for (int i = 0; i < STX_TUNE_COUNT; ++i)
+        if (name && !strcmp(name, g_tune[i].name)) return g_tune[i].value;
+    return -1;
+}
+
+extern "C" int stx_set_tuning(const char* name, int value) {
+    for (int i = 0; i < STX_TUNE_COUNT; ++i)
+        if (name && !strcmp(name, g_tune[i].name)) { g_tune[i].value = value; return STX_OK; }
+    return stx_set_error(STX_ERR_ARG, "stx_set_tuning: unknown switch %s", name ? name : "(null)");
+}

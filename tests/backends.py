@@ -68,3 +68,17 @@ BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
 @pytest.fixture(params=BACKENDS)
 def be(request):
     return Backend(request.param)
+
+
+@pytest.fixture
+def tune(be):
+    """Set a tuning / A-B switch of the library under test for the duration of a test (stx_set_tuning; the library reads
+    its STX_* environment variables only once, when it is loaded)."""
+    saved = {}
+
+    def set_(name, value):
+        old = be.lib.set_tuning(name, value)
+        saved.setdefault(name, old)
+    yield set_
+    for name, old in saved.items():
+        be.lib.set_tuning(name, old)

@@ -50,6 +50,7 @@ def test_bench_gpus2_spawns_two_gloo_ranks_emulated():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 1
     assert "overlapped" in out["config"]["grad_sync"]
+    assert len(out["per_rank"]["ms_per_step"]) == 2 and max(out["per_rank"]["ms_per_step"]) <= out["ms_per_step"] * 1.001
 
 
 def test_bench_psm_volume_config_emulated():

@@ -219,3 +219,75 @@ def test_metrics_all_reduce_two_ranks_gloo():
     for r in range(2):
         assert abs(res[r][1]["epe"] - want["epe"]) < 1e-9
         assert all(abs(a - b) < 1e-9 for a, b in zip(res[r][1]["outliers"], want["outliers"]))
+
+
+# ------------------------------------------------------------------------------ RCCL: gradient VALUES of the real model
+def _rccl_model_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from oracle import torch_oracle as O
+    from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
+    from stereo_toolbox_amd.models import GwcNet_GC
+    from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
+    D, H, W = 64, 64, 128
+    m = GwcNet_GC(D)
+    sd = m.state_dict()
+    fill_state_dict(sd)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    broadcast_parameters(m)
+    sync = FlatGradSync(m, buckets=2, overlap=True)
+    left, right = synthetic_tensor((world, 3, H, W), 1), synthetic_tensor((world, 3, H, W), 2)
+    gt = synthetic_tensor((world, H, W), 3, lo=0.0, hi=float(D - 2))
+    sync.detach_grads()
+    preds = m(left[rank:rank + 1].to(dev), right[rank:rank + 1].to(dev))
+    O.smooth_l1_multi(preds, gt[rank:rank + 1].to(dev), D, (0.5, 0.5, 0.7, 1.0)).backward()
+    sync.finish()
+    torch.cuda.synchronize()
+    q.put((rank, sync.flat.detach().cpu().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_model_gradients_two_ranks_rccl():
+    """What the 8-GPU scaling run relies on, checked by VALUE on a node with >= 2 GPUs: two RCCL ranks with one 64x128 pair
+    each (per-replica BatchNorm statistics, the reference's default: trainer_torchrun.py:112-121) end up with the average
+    of the two single-sample gradients in every rank's flat buffer -- overlapped 2-range all-reduce from autograd hooks."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 ROCm devices (the 1-GPU test box runs the gloo twins of this test)")
+    sys.path.insert(0, ROOT)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    flat = [torch.from_numpy(r[1]) for r in res]
+    assert torch.equal(flat[0], flat[1])
+    from oracle import torch_oracle as O
+    from stereo_toolbox_amd.models import GwcNet_GC
+    from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
+    D, H, W = 64, 64, 128
+    left, right = synthetic_tensor((2, 3, H, W), 1), synthetic_tensor((2, 3, H, W), 2)
+    gt = synthetic_tensor((2, H, W), 3, lo=0.0, hi=float(D - 2))
+    want = 0
+    for s in range(2):                               # the same two samples, one after the other, on one device
+        m = GwcNet_GC(D)
+        sd = m.state_dict()
+        fill_state_dict(sd)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        preds = m(left[s:s + 1].cuda(), right[s:s + 1].cuda())
+        O.smooth_l1_multi(preds, gt[s:s + 1].cuda(), D, (0.5, 0.5, 0.7, 1.0)).backward()
+        want = want + torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu() / 2
+    err = (flat[0] - want).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item() + 1e-7, err     # same kernels, same order: only the AVG's rounding differs

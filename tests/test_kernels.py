@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import torch_oracle as O
-from tests.backends import be, ndhwc, ncdhw, ptr  # noqa: F401
+from tests.backends import be, ndhwc, ncdhw, ptr, tune  # noqa: F401
 
 
 def _close(got, ref, rtol=1e-4, atol=1e-5):
@@ -61,15 +61,12 @@ def _cv_inputs(case):
     return Lg, Rg, Lc, Rc, torch.cat(parts, 1)
 
 
-@pytest.mark.parametrize("variant", ["few_workgroups", "fat_waves"])
-def test_cost_volume_fwd_launch_variants(be, variant, monkeypatch):
-    """Launch variants of the MFMA builder (environment switches read per call).  The default grid gives small test
-    volumes one unit per workgroup; `few_workgroups` forces runs of several units per workgroup (register rotation of
-    the right-feature tiles along a row, row / chunk changes inside a run, double-buffered LDS image); `fat_waves`
-    two channel quads per compute wave.  All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
-    monkeypatch.setenv("STX_CV_GRID", "2" if variant == "few_workgroups" else "3")
-    if variant == "fat_waves":
-        monkeypatch.setenv("STX_CV_QPW", "2")
+@pytest.mark.parametrize("grid", [2, 3])
+def test_cost_volume_fwd_launch_variants(be, grid, tune):
+    """The default grid gives small test volumes one unit per workgroup; STX_CV_GRID forces runs of several units per
+    workgroup (register rotation of the right-feature tiles along a row, row / chunk changes inside a run, double-buffered
+    LDS image).  All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
+    tune("STX_CV_GRID", grid)
     for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
         B, Cg, G, Cc, H, W, D, ml = case
         Lg, Rg, Lc, Rc, ref = _cv_inputs(case)
@@ -79,20 +76,20 @@ def test_cost_volume_fwd_launch_variants(be, variant, monkeypatch):
         _check_volume(vol, ref, G)
 
 
-@pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "two_chunks_in_flight", "three_chunks_in_flight",
+@pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "two_chunks_in_flight", "four_chunks_in_flight",
                                      "first_generation"])
-def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
-    """Backward launch variants (environment switches read per call).  Small test volumes otherwise give the matrix-core
-    kernel one macro-unit per workgroup; `one_workgroup` / `three_workgroups` force runs over many macro-units: the
-    feature ring sliding along an image row, ring refills at row and side changes, the register double buffer of the
-    volume gradient crossing macro-unit boundaries.  `first_generation` keeps the VALU kernels covered."""
+def test_cost_volume_bwd_launch_variants(be, variant, tune):
+    """Backward launch variants.  Small test volumes otherwise give the matrix-core kernel one macro-unit per workgroup;
+    `one_workgroup` / `three_workgroups` force runs over many macro-units: the feature ring sliding along an image row,
+    ring refills at row and side changes, the register double buffer of the volume gradient crossing macro-unit
+    boundaries.  `first_generation` keeps the any-shape fallback kernels covered."""
     if variant == "first_generation":
-        monkeypatch.setenv("STX_CVB_OLD", "1")
-    elif variant.endswith("in_flight"):      # register sets of the loader waves (default 4 for the 40-group volumes)
-        monkeypatch.setenv("STX_CVB_NSET", "2" if variant.startswith("two") else "3")
-        monkeypatch.setenv("STX_CVB_GRID", "2")
+        tune("STX_CVB_OLD", 1)
+    elif variant.endswith("in_flight"):      # register sets of the loader waves (default 3 for the 40-group volumes)
+        tune("STX_CVB_NSET", 2 if variant.startswith("two") else 4)
+        tune("STX_CVB_GRID", 2)
     else:
-        monkeypatch.setenv("STX_CVB_GRID", "1" if variant == "one_workgroup" else "3")
+        tune("STX_CVB_GRID", 1 if variant == "one_workgroup" else 3)
     for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
         if case[2] == 0:
             continue
@@ -101,19 +98,27 @@ def test_cost_volume_bwd_launch_variants(be, variant, monkeypatch):
 
 @pytest.mark.parametrize("case", [(1, 320, 40, 12, 10, 130, 48, 1),     # GwcNet_GC channels, 6 chunks, 9 tiles, rows 8/9 = second round
                                   (2, 64, 8, 4, 5, 140, 43, 0)])         # D' = 43 (ragged last chunk), batch 2, left half unmasked
-def test_cost_volume_bwd_team_schedule(be, case, monkeypatch):
+def test_cost_volume_bwd_team_schedule(be, case, tune):
     """The matrix-core backward's row-team schedule (one team of (tile, side) members per XCD, progressive feature ring):
     taken for 9-16 tiles per row and 40 < D' <= 48, i.e. the benchmark shape -- these are its smallest eligible volumes.
     Checked against the same launch on the run schedule (STX_CVB_TEAM=0) by way of the common reference."""
-    monkeypatch.setenv("STX_CVB_TRACE", "1")
-    monkeypatch.setenv("STX_CVB_TEAM", "1")          # opt-in since GPU call O (the run schedule measured faster)
+    tune("STX_CVB_TEAM", 1)                          # opt-in since GPU call O of round 2 (the run schedule measured faster)
     _cv_fwd_bwd(be, case, fwd=False)
-    monkeypatch.setenv("STX_CVB_TEAM", "0")
+    tune("STX_CVB_TEAM", 0)
     _cv_fwd_bwd(be, case, fwd=False)
 
 
 @pytest.mark.parametrize("case", CV_CASES)
 def test_cost_volume_fwd_bwd(be, case):
+    _cv_fwd_bwd(be, case)
+
+
+@pytest.mark.parametrize("case", [c for c in CV_CASES if not (c[2] and c[1] // c[2] == 12)])
+def test_cost_volume_first_generation_fallback(be, case, tune):
+    """The any-shape fallback kernels of cost_volume.hip (the matrix-core builders serve every model configuration; D' > 96
+    or voxels of more than 64 channels end up here), forced for the regular cases."""
+    tune("STX_CV_OLD", 1)
+    tune("STX_CVB_OLD", 1)
     _cv_fwd_bwd(be, case)
 
 
@@ -192,17 +197,15 @@ def test_head_fwd_bwd(be, case):
     _close(gc, cost.grad, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("gen", ["lds", "v1"])
 @pytest.mark.parametrize("ac", [0, 1])
 @pytest.mark.parametrize("case", [(1, 4, 5, 7, 16, 20, 28, 5.0), (2, 12, 6, 9, 48, 24, 36, 3.0), (1, 5, 4, 6, 17, 13, 22, 4.0),
                                   (1, 1, 3, 1, 4, 9, 5, 2.0), (1, 3, 2, 75, 12, 3, 300, 40.0), (1, 9, 3, 4, 5, 4, 6, 3.0),
-                                  (1, 6, 3, 5, 24, 12, 20, 3000.0)])
-def test_head2_fwd_bwd(be, case, ac, gen, monkeypatch):
-    """Entry points with an explicit interpolation rule: align_corners=True is the PCWNet / CFNet head.  Both kernel
-    generations (LDS-staged tables / first version); W = 300 spans two workgroups with a ragged tail, D < Dc leaves
-    coarse planes without an output disparity, gain 3000 has cost steps far beyond the exp range (the LDS kernel's
-    bound-shifted sum underflows and it must redo the walk with the exact maximum)."""
-    monkeypatch.setenv("STX_HEAD_V1", "7" if gen == "v1" else "0")      # (the product default mixes generations: see head.hip)
+                                  (1, 6, 3, 5, 24, 12, 20, 3000.0), (1, 84, 2, 3, 336, 8, 12, 3.0)])
+def test_head2_fwd_bwd(be, case, ac):
+    """Entry points with an explicit interpolation rule: align_corners=True is the PCWNet / CFNet head.  W = 300 spans two
+    workgroups with a ragged tail, D < Dc leaves coarse planes without an output disparity, gain 3000 has cost steps far
+    beyond the exp range (the LDS kernel's bound-shifted sum underflows and it must redo the walk with the exact maximum),
+    D' = 84 exceeds the LDS-staged forward kernel's table (the first-generation kernel serves it)."""
     B, Dc, Hc, Wc, D, H, W, gain = case
     torch.manual_seed(3)
     cost = (torch.randn(B, 1, Dc, Hc, Wc) * gain).requires_grad_()
@@ -212,7 +215,7 @@ def test_head2_fwd_bwd(be, case, ac, gen, monkeypatch):
     be.call("stx_head_fwd2", ptr(dcost), ptr(disp), ptr(stats), B, Dc, Hc, Wc, D, H, W, ac)
     # 1e-4 at realistic logit ranges; with logit steps of 40+ the device's fast exp (exp2(x * log2 e): the argument's
     # rounding error grows with |x|) moves near-one-hot expectations by up to 6e-4 px on gfx950 -- still inside the 1e-3 bar
-    assert (disp.cpu() - ref.detach()).abs().max().item() < (1e-4 if gain <= 5 else 1e-3)
+    assert (disp.cpu() - ref.detach()).abs().max().item() < (1e-4 * max(1.0, D / 96.0) if gain <= 5 else 1e-3)   # (fp32 ulp grows with D)
     g = torch.randn(B, H, W)
     ref.backward(g)
     gc = be.empty(B, 1, Dc, Hc, Wc)
@@ -324,7 +327,7 @@ CONV_CASES = [
     (1, 40, 32, 2, 2, 20, 3, 1),     # ACVNet dres1_att_ (Cin=40 -> 8-channel K chunks)
     (1, 32, 1, 2, 4, 35, 3, 1),      # classifier tail Conv3d(32->1)
     (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
-    (1, 64, 64, 3, 5, 37, 3, 1),     # hourglass conv2 (STX_MARCH_6464=1: 2 x 2 channel slices on the march kernel)
+    (1, 64, 64, 3, 5, 37, 3, 1),     # hourglass conv2
     (1, 64, 128, 4, 4, 24, 3, 2),
     (2, 32, 64, 7, 6, 40, 3, 1),     # march kernel, 2 column blocks (NT=2), ragged H/W, several D segments
     (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 5 16-wide tiles (8 x 16 columns)
@@ -352,10 +355,11 @@ def test_conv3d_fwd(be, case):
     _close(got3, F.mish(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res), rtol=1e-4, atol=1e-5)
 
 
-def test_conv3d_stride2_dense_lds_tile(be, monkeypatch):
-    """Opt-in stride-2 variant with the un-padded LDS tile (STX_CONV_S2_DENSE=1, 32 -> 64 channels: the first convolution
-    of every hourglass): same results as the default layout, ragged H / W / D included."""
-    monkeypatch.setenv("STX_CONV_S2_DENSE", "1")
+@pytest.mark.parametrize("dense", [1, 0])
+def test_conv3d_stride2_lds_tile_layouts(be, dense, tune):
+    """Stride-2 32 -> 64 convolution (the first convolution of every hourglass) with the un-padded LDS tile (default,
+    STX_CONV_S2_DENSE=1) and with the padded one: same results, ragged H / W / D included."""
+    tune("STX_CONV_S2_DENSE", dense)
     torch.manual_seed(15)
     for B, D, H, W in ((1, 5, 6, 45), (2, 4, 4, 70)):
         x = torch.randn(B, 32, D, H, W)
@@ -576,7 +580,7 @@ def test_ac_volume_backward(be):
 @pytest.mark.parametrize("variant", ["lds_window", "global_atomics"])
 @pytest.mark.parametrize("case", [(1, 40, 4, 12, 5, 70, 6), (2, 20, 4, 6, 3, 33, 4), (1, 8, 8, 0, 2, 64, 3), (1, 0, 0, 8, 2, 20, 5),
                                   (1, 8, 4, 4, 2, 200, 3), (1, 40, 8, 12, 1, 66, 2)])
-def test_sampled_volume_fwd_bwd(be, case, variant, monkeypatch):
+def test_sampled_volume_fwd_bwd(be, case, variant, tune):
     """stx_sampled_volume_fwd / _bwd against the oracle's restatement of SpatialTransformer + groupwise_correlation_4D +
     cost_volume_generator + cat (CFNet/submodule.py:306-350, 163-169, cfnet.py:470-497, 560-566): CFNet's two stage
     configurations (40 groups x 4 channels + 12 concat; 20 x 4 + 6), 8 channels per group, concat only; W = 70 / 33 leave
@@ -584,10 +588,7 @@ def test_sampled_volume_fwd_bwd(be, case, variant, monkeypatch):
     Backward in both forms: right-feature gradients through the workgroup's LDS window (W = 200 with hypotheses up to 150
     columns puts many gather columns left of the 96-column window -> its global-atomic fallback; 320 + 12 channels split
     the groups over two workgroups) and with global atomics only (STX_SV_BWD_V1)."""
-    if variant == "global_atomics":
-        monkeypatch.setenv("STX_SV_BWD_V1", "1")
-    else:
-        monkeypatch.delenv("STX_SV_BWD_V1", raising=False)
+    tune("STX_SV_BWD_V1", 1 if variant == "global_atomics" else 0)
     B, G, cpg, Cc, H, W, S = case
     torch.manual_seed(11)
     Cg = G * cpg
@@ -806,7 +807,7 @@ def test_bn_stats(be, case):
     _close(p[:, 1].sum(0).float(), (z.double() ** 2).sum(0).float(), rtol=1e-5, atol=1e-3)
 
 
-def test_conv3d_march_blocked_sums(be, monkeypatch):
+def test_conv3d_march_blocked_sums(be, tune):
     """Blocked fp32 accumulation in the weights-in-LDS march kernel (STX_MARCH_BS=1, the default): one accumulator per
     (output, input plane) -- three 288-term chunks instead of one 864-term chain.  Same convolution; the result must be
     CLOSER to an fp64 evaluation than the sequential chain's (STX_MARCH_BS=0)."""
@@ -815,32 +816,13 @@ def test_conv3d_march_blocked_sums(be, monkeypatch):
         x = torch.randn(B, Cin, D, H, W)
         w = torch.randn(Cout, Cin, 3, 3, 3) * 0.1
         ref64 = F.conv3d(x.double(), w.double(), None, 1, 1)
-        monkeypatch.setenv("STX_MARCH_BS", "1")
+        tune("STX_MARCH_BS", 1)
         got, st = run_conv(be, x, w, 3, 1, stats=True)
         _close(got, ref64.float())
         _close(st[:, 0].sum(0), ref64.float().sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
-        monkeypatch.setenv("STX_MARCH_BS", "0")
+        tune("STX_MARCH_BS", 0)
         seq, _ = run_conv(be, x, w, 3, 1)
         _close(seq, ref64.float())
         e_blk = (got.double() - ref64).abs().mean().item()
         e_seq = (seq.double() - ref64).abs().mean().item()
         assert e_blk < 0.85 * e_seq, (e_blk, e_seq)
-
-
-@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2),
-                                  (1, 64, 64, 3, 4, 34, 3, 1), (1, 64, 32, 2, 9, 20, 3, 1)])
-def test_conv3d_wgrad_straight_line_loop(be, case, monkeypatch):
-    """STX_WGRAD_V2=1: weight-gradient MFMA loop with a compile-time tap count per wave (3 or 4 of the 27) and the LDS
-    operand reads dealt between the MFMAs -- same sums, in the same order, as the first version."""
-    monkeypatch.setenv("STX_WGRAD_V2", "1")
-    B, Cin, Cout, D, H, W, ks, s = case
-    torch.manual_seed(8)
-    x = torch.randn(B, Cin, D, H, W)
-    w = (torch.randn(Cout, Cin, ks, ks, ks) * 0.1).requires_grad_()
-    y = F.conv3d(x, w, None, s, ks // 2)
-    gy = torch.randn_like(y)
-    y.backward(gy)
-    v2 = run_wgrad(be, x, gy, ks, s)
-    _close(v2.view_as(w), w.grad)
-    monkeypatch.setenv("STX_WGRAD_V2", "0")
-    assert torch.equal(v2, run_wgrad(be, x, gy, ks, s))        # identical accumulation order -> identical bits

@@ -308,14 +308,18 @@ def _gold(name):
 @pytest.mark.parametrize("tag", ["gwc_gc_576x960", "gwc_gc_384x1248", "acv_576x960"])
 def test_full_size_eval_parity(tag, parity_log):
     """BASELINE.json configs[2]/[3]/[4] shapes, eval forward at the padded full resolution (SceneFlow 540x960 ->
-    576x960, KITTI 375x1242 -> 384x1248), D=192.  Two yard-sticks, both reported:
-      * the REFERENCE itself (tests/golden/fullsize_eval.npz: its fp64 output sampled every 4th pixel, and the max-abs
-        distance of its own fp32 run from fp64 over all pixels), and
-      * the CPU oracle run on this box over ALL pixels.
-    Bar: 1e-3 max-abs (north_star).  If -- and only if -- a correct fp32 implementation cannot meet it at this size
-    (the reference's own fp32 run is further than 0.5e-3 from fp64), the product must instead be no further from fp64
-    than 2x the reference's fp32 run; the branch taken is part of the report."""
+    576x960, KITTI 375x1242 -> 384x1248), D=192, all pixels.  Bar (north_star): 1e-3 max-abs, flat:
+      (1) the WHOLE model against the reference's own fp64 evaluation (tests/golden/fullsize_eval.npz, every 4th pixel);
+      (2) GwcNet_GC: the HAND-WRITTEN path (volume build -> 3-D aggregation -> regression, `model.aggregate`) against the
+          CPU oracle run on this box, both fed the oracle's features -- the reference path and the product on identical
+          inputs (row A of tools/parity_isolation.py);
+      (3) the whole model against the fp32 CPU oracle: 1e-3 where the stock 2-D CNN's rounding leaves room for it, never
+          above 1e-3 + the distance the MIOpen features ALONE move the oracle's own 3-D path (row B, measured here; GPU
+          calls A/F: 7.4e-4 .. 8.9e-4 px for a feature perturbation of 7e-7 relative rms -- the random-weight D=192
+          network amplifies one-ulp input noise to that level, so (3) cannot be flat for ANY fp32 implementation that does
+          not reproduce MKL-DNN's rounding; the reference's own fp32 run is 6.7e-4 .. 7.2e-4 px from its fp64 run)."""
     from stereo_toolbox_amd.models import ACVNet, GwcNet_GC
+    from stereo_toolbox_amd.models.features2d import run_pair
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
     gold = _gold("fullsize_eval.npz")
@@ -324,9 +328,25 @@ def test_full_size_eval_parity(tag, parity_log):
     m, sd = _filled(ACVNet if acv else GwcNet_GC, 192)
     m = m.cuda().eval()
     left, right = synthetic_tensor((1, 3, H, W), 1), synthetic_tensor((1, 3, H, W), 2)
+    rec = {}
     with torch.no_grad():
         got = m(left.cuda(), right.cuda()).cpu()
-        ref = O.acvnet_forward(sd, left, right, 192) if acv else O.gwcnet_forward(sd, left, right, 192, True)
+        if acv:
+            ref = O.acvnet_forward(sd, left, right, 192)
+        else:
+            cx = O.Ctx(sd, False)
+            ogl, ocl = O.features_gwc(cx, left, True)
+            ogr, ocr = O.features_gwc(cx, right, True)
+            ref = O.gwcnet_aggregate(cx, ogl, ogr, ocl, ocr, 192, H, W)
+            dev = torch.device("cuda:0")
+            got_a = m.aggregate({"gwc_feature": ogl.to(dev), "concat_feature": ocl.to(dev)},
+                                {"gwc_feature": ogr.to(dev), "concat_feature": ocr.to(dev)}, H, W).cpu()
+            fl, fr = run_pair(m.feature_extraction, left.to(dev), right.to(dev), False)
+            ref_b = O.gwcnet_aggregate(cx, fl["gwc_feature"].cpu().contiguous(), fr["gwc_feature"].cpu().contiguous(),
+                                       fl["concat_feature"].cpu().contiguous(), fr["concat_feature"].cpu().contiguous(),
+                                       192, H, W)
+            rec["hand_written_path_vs_oracle_same_features_all_px"] = (got_a - ref).abs().max().item()
+            rec["oracle_3d_on_miopen_features_vs_oracle_all_px"] = (ref_b - ref).abs().max().item()
     assert got.shape == (1, H, W)
     assert ref.std() > 1.0
     s = int(gold["stride"])
@@ -336,14 +356,17 @@ def test_full_size_eval_parity(tag, parity_log):
     e_ref32 = float(gold[tag + "_e32"])                                    # reference fp32 vs fp64 (all pixels)
     e_full = (got - ref).abs().max().item()                                # product vs oracle, all pixels
     e_mean = (got - ref).abs().mean().item()
-    flat = e_full < 1e-3 and e_prod64 < 1e-3
     parity_log(f"full_size_eval[{tag}]", max_abs_vs_oracle_all_px=e_full, mean_abs_vs_oracle=e_mean,
                max_abs_vs_reference_fp64_sampled=e_prod64, oracle_vs_reference_fp64_sampled=e_orc64,
-               reference_fp32_vs_fp64_all_px=e_ref32, branch="flat 1e-3" if flat else "fp64-calibrated (2x reference fp32 error)")
+               reference_fp32_vs_fp64_all_px=e_ref32, **rec)
     assert e_orc64 < max(1e-3, 2 * e_ref32), "oracle on this box disagrees with the reference fixture"
-    if not flat:
-        assert e_ref32 > 0.5e-3, (e_full, e_prod64, e_ref32)               # the escape exists only where fp32 itself is at the bar
-        assert e_prod64 < 2 * e_ref32 and e_full < 2e-3, (e_full, e_prod64, e_ref32)
+    assert e_prod64 < 1e-3, e_prod64                                        # (1)
+    if not acv:
+        assert rec["hand_written_path_vs_oracle_same_features_all_px"] < 1e-3, rec   # (2)
+        assert e_full < 1e-3 + rec["oracle_3d_on_miopen_features_vs_oracle_all_px"], (e_full, rec)   # (3)
+        assert e_full < 1.6e-3, e_full
+    else:
+        assert e_full < 1e-3, e_full
     assert e_mean < 3e-4
 
 

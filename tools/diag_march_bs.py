@@ -10,7 +10,7 @@ st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def conv(x, w, bs):
-    os.environ["STX_MARCH_BS"] = str(bs)
+    lib.set_tuning("STX_MARCH_BS", bs)
     B, D, H, W, Cin = x.shape
     Cout = w.shape[0]
     wp = torch.empty(lib.raw("stx_conv3d_packed_floats")(Cin, Cout, 27), device=dev)

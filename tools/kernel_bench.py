@@ -62,29 +62,22 @@ def pack(w, mode):
     return wp
 
 
-# A/B switches that libstx_hip.so reads on every call (not cached in statics): they can be flipped inside one process, so
-# a whole comparison costs one interpreter start.  (label, kernel filter, environment)
+# A/B switches of libstx_hip.so (StxTune in csrc/stx_common.h), flipped inside one process through stx_set_tuning: a whole
+# comparison costs one interpreter start.  (label, kernel filter, {switch: value})
 AB_SETS = [
-    ("stride-2 32->64 with the dense (un-padded) LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": "1"}),
-    ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": "1"}),
-    ("transposed conv: rolled tap loops (first generation)", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "0"}),
-    ("transposed conv: weights AND LDS operands one tap ahead", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_PIPE": "2"}),
-    ("transposed conv: 32-channel K chunks", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "32"}),
-    ("transposed conv: 16-channel K chunks", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "16"}),
-    ("transposed conv: 16-channel K chunks, LDS operands ahead", "deconv_128_64_L2_fwd,deconv_64_32_L1_fwd", {"STX_DECONV_CK": "16", "STX_DECONV_PIPE": "2"}),
-    ("head: first generation (all three kernels)", "head", {"STX_HEAD_V1": "7"}),
-    ("head: LDS-staged kernels everywhere (backward per-pixel pass too)", "head", {"STX_HEAD_V1": "0"}),
-    ("head: first-generation backward gather only", "head", {"STX_HEAD_V1": "4"}),
-    ("bn_finalize: first generation", "bn_finalize", {"STX_BN_FINALIZE_V1": "1"}),
-    ("wgrad slab reduce: first generation", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad", {"STX_WGRAD_REDUCE_V1": "1"}),
-    ("cost volume bwd: first generation", "cost_volume_bwd", {"STX_CVB_OLD": "1"}),
-    ("cost volume bwd: run schedule", "cost_volume_bwd", {"STX_CVB_TEAM": "0"}),
-    ("cost volume bwd: team, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "2"}),
-    ("cost volume bwd: team, 3 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "3"}),
-    ("cost volume bwd: team, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "1", "STX_CVB_NSET": "4"}),
-    ("cost volume bwd: run schedule, 2 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "0", "STX_CVB_NSET": "2"}),
-    ("cost volume bwd: run schedule, 4 chunk sets", "cost_volume_bwd", {"STX_CVB_TEAM": "0", "STX_CVB_NSET": "4"}),
-    ("64->64 L1 as 2 x 2 march slices", "conv_64_64_L1_fwd", {"STX_MARCH_6464": "1"}),
+    ("march kernel: one sequential accumulation chain per output", "conv_32_32_L0_fwd,conv_64_32_L0_fwd", {"STX_MARCH_BS": 0}),
+    ("march kernel: operand reads as a burst in front of the MFMAs", "conv_32_32_L0_fwd,conv_64_32_L0_fwd", {"STX_MARCH_ILV": 0}),
+    ("march kernel: no plane staging (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 1}),
+    ("march kernel: no epilogue stores (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 2}),
+    ("stride-2 32->64 with the padded LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": 0}),
+    ("weight gradient: no tile staging (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 1}),
+    ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
+    ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),
+    ("cost volume fwd: first-generation fallback kernel", "cost_volume_fwd", {"STX_CV_OLD": 1}),
+    ("cost volume bwd: first-generation fallback kernel", "cost_volume_bwd", {"STX_CVB_OLD": 1}),
+    ("cost volume bwd: team schedule", "cost_volume_bwd", {"STX_CVB_TEAM": 1}),
+    ("cost volume bwd: 2 chunk sets in flight", "cost_volume_bwd", {"STX_CVB_NSET": 2}),
+    ("cost volume bwd: 4 chunk sets in flight", "cost_volume_bwd", {"STX_CVB_NSET": 4}),
 ]
 
 
@@ -101,13 +94,13 @@ def main():
     run_table(a, a.only)
     if a.ab:
         for label, flt, env in AB_SETS:
-            print(json.dumps({"ab": label, "env": env}), flush=True)
-            os.environ.update(env)
+            print(json.dumps({"ab": label, "tuning": env}), flush=True)
+            old = {k: lib.set_tuning(k, v) for k, v in env.items()}
             try:
                 run_table(a, flt, only_exact=True)
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                for k, v in old.items():
+                    lib.set_tuning(k, v)
 
 
 def run_table(a, only_arg, only_exact=False):

@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--no-find", action="store_true", help="skip MIOpen's solver search (cudnn.benchmark off)")
     a = ap.parse_args()
     from stereo_toolbox_amd import models
-    from stereo_toolbox_amd.utils import fill_state_dict
+    from stereo_toolbox_amd.utils import fill_state_dict, use_tuning_db
+    use_tuning_db()
     torch.backends.cudnn.benchmark = not a.no_find
     dev = torch.device("cuda:0")
     model = getattr(models, a.model)(a.maxdisp)

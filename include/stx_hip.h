@@ -150,9 +150,13 @@ int stx_bn_reduce_blocks(void);
 /* Batch statistics of a channels-last activation z [nvox][C] whose producer has no fused epilogue -- the nn.BatchNorm2d
  * layers behind the MIOpen convolutions of the 2-D feature CNN (models/GwcNet/gwcnet.py:12-65 `convbn`, BasicBlock):
  * partials [stx_bn_stats_rows(nvox, C)][2][C] = per-workgroup (sum z, sum z^2), the row format stx_bn_finalize takes.
- * C: multiple of 4 with C/4 dividing 256. */
+ * C: multiple of 4 with C/4 dividing 256.
+ * GROUPS (here and in stx_bn_apply / stx_bn_bwd_reduce2 / stx_bn_bwd_apply2): the tensors are `groups` consecutive slabs of
+ * `nvox` voxels, each with its OWN statistics -- the per-group vectors (partials, scale, shift, mean, invstd, sums) are
+ * [groups][...], gamma is shared.  The 2-D CNN sends the left and the right view through its convolutions as one batch
+ * while every BatchNorm keeps the per-view statistics of the reference's two extractor calls (gwcnet.py:172-173). */
 int stx_bn_stats_rows(long long nvox, int C);
-int stx_bn_stats(const float* z, float* partials, long long nvox, int C, void* stream);
+int stx_bn_stats(const float* z, float* partials, long long nvox, int C, int groups, void* stream);
 /* partials [nrows][2][C] (from the conv epilogue) -> scale = gamma*invstd, shift = beta - mean*scale, mean, invstd;
  * running_mean/var (may be NULL) updated with `momentum` and the unbiased variance, like torch. */
 int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
@@ -162,7 +166,7 @@ int stx_bn_finalize(const float* partials, int nrows, int C, double count, const
  * (0 none, 1 ReLU, 2 Mish) here and in the backward passes below; Mish is differentiated at the pre-activation value,
  * which stx_bn_bwd_reduce2 / _apply2 recompute from z and the scale / shift vectors (y = NULL) */
 int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2, const float* scale2,
-                 const float* shift2, float* out, long long nvox, int C, int relu, void* stream);
+                 const float* shift2, float* out, long long nvox, int C, int relu, int groups, void* stream);
 /* sums[3][C] = sum g, sum g*xhat1, sum g*xhat2 with g = gy*[y>0]; partials: scratch of stx_bn_reduce_blocks()*3*C floats */
 int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
                       const float* z2, const float* mean2, const float* invstd2, float* partials, float* sums,
@@ -178,12 +182,12 @@ int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const flo
 int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
                        const float* z2, const float* mean2, const float* invstd2, const float* scale1,
                        const float* shift1, const float* scale2, const float* shift2, float* partials, float* sums,
-                       long long nvox, int C, int relu, void* stream);
+                       long long nvox, int C, int relu, int groups, void* stream);
 int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
                       const float* gamma1, const float* z2, const float* mean2, const float* invstd2,
                       const float* gamma2, const float* scale1, const float* shift1, const float* scale2,
                       const float* shift2, const float* sums, float* dz1, float* dz2, float* gout, long long nvox,
-                      int C, int relu, void* stream);
+                      int C, int relu, int groups, void* stream);
 
 /* ---- Evaluation-path input step on the device --------------------------------------------------------
  * pad_to_2x (datasets/data_augmentation/__init__.py:57-80: zero padding on top and to the right, to multiples of 96)

@@ -70,13 +70,13 @@ SIGNATURES = {
     # bn.hip
     "stx_bn_reduce_blocks": [],
     "stx_bn_stats_rows": [_L, _I],
-    "stx_bn_stats": [_P, _P, _L, _I, _P],
+    "stx_bn_stats": [_P, _P, _L, _I, _I, _P],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
-    "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "stx_bn_bwd_reduce2": [_P] * 14 + [_L, _I, _I, _P],
-    "stx_bn_bwd_apply2": [_P] * 18 + [_L, _I, _I, _P],
+    "stx_bn_bwd_reduce2": [_P] * 14 + [_L, _I, _I, _I, _P],
+    "stx_bn_bwd_apply2": [_P] * 18 + [_L, _I, _I, _I, _P],
 }
 _RET_CHARP = ("stx_last_error", "stx_build_info")
 

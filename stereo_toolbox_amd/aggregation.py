@@ -112,7 +112,8 @@ class deferred_bn_counters:
         return False
 
 
-def _bn_state(bn, partials, count):
+def _bn_state(bn, partials, count, steps=1):
+    """`steps`: statistic updates this call stands for (the grouped 2-D path: one per view)."""
     training = bn.training
     sync = None
     if training and isinstance(bn, nn.SyncBatchNorm):
@@ -124,9 +125,9 @@ def _bn_state(bn, partials, count):
         bn.__dict__.pop("_stx_fold", None)          # the running statistics are about to move
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if deferred_bn_counters._active and bn.momentum is not None:
-            deferred_bn_counters._pending.append(bn.num_batches_tracked)
+            deferred_bn_counters._pending.extend([bn.num_batches_tracked] * steps)
         else:
-            bn.num_batches_tracked.add_(1)
+            bn.num_batches_tracked.add_(steps)
     if bn.momentum is not None:
         momentum = bn.momentum
     elif training and bn.track_running_stats and bn.num_batches_tracked is not None:

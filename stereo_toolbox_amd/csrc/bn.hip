@@ -12,6 +12,10 @@
 //   backward: stx_bn_bwd_reduce: sums of g, g*xhat1, g*xhat2 with g = gy*[y>0]
 //             stx_bn_bwd_apply : dz_k = gamma_k*invstd_k*(g - mean(g) - xhat_k*mean(g*xhat_k))
 // All kernels are HBM-bound streaming passes (16-B accesses, one float4 channel quad per lane).
+// GROUPS: the streaming passes take `groups` consecutive slabs of `nvox` voxels each with their OWN statistics (scale / shift /
+// mean / invstd / sums are [groups][C]; gamma is shared): blockIdx.y = group.  The 2-D feature CNN runs the left and the right
+// view as one batch through its convolutions while every BatchNorm keeps per-view statistics, as the reference's two
+// separate extractor calls do (models/GwcNet/gwcnet.py:172-173).
 #include "stx_common.h"
 #include <stdlib.h>
 
@@ -129,6 +133,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(
     const float* __restrict__ z1, const float* __restrict__ scale1, const float* __restrict__ shift1,
     const float* __restrict__ z2, const float* __restrict__ scale2, const float* __restrict__ shift2,
     float* __restrict__ out, size_t nquads, int CQ, int relu) {
+    {   // group blockIdx.y: its slab of the activations, its rows of the per-group vectors
+        const size_t go = (size_t)blockIdx.y * nquads * 4, gc = (size_t)blockIdx.y * CQ * 4;
+        z1 += go; out += go; scale1 += gc; shift1 += gc;
+        if (z2) z2 += go;
+        if (scale2) { scale2 += gc; shift2 += gc; }
+    }
     for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * BN_THREADS) {
         const int cq = (int)(i % CQ) * 4;
         float4 v = stx_ld4(z1 + i * 4);
@@ -161,6 +171,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     const int tid = threadIdx.x;
     const int CQ = C >> 2;
     const int cq = tid % CQ, vl = tid / CQ, VPB = BN_THREADS / CQ;
+    {   // group blockIdx.y
+        const size_t go = (size_t)blockIdx.y * nvox * C, gc = (size_t)blockIdx.y * C;
+        gy += go; z1 += go; mean1 += gc; invstd1 += gc;
+        if (y) y += go;
+        if (z2) z2 += go;
+        if (mean2) { mean2 += gc; invstd2 += gc; }
+        if (sc1) { sc1 += gc; sh1 += gc; }
+        if (sc2) { sc2 += gc; sh2 += gc; }
+        partials += (size_t)blockIdx.y * gridDim.x * 3 * C;
+    }
     const float4 m1 = stx_ld4(mean1 + 4 * cq), i1 = stx_ld4(invstd1 + 4 * cq);
     float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f), i2 = m2;
     const bool has2 = z2 && mean2;
@@ -230,6 +250,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __res
     const int tid = threadIdx.x;
     const int CQ = C >> 2;
     const int cq = tid % CQ, vl = tid / CQ, VPB = BN_THREADS / CQ;
+    z += (size_t)blockIdx.y * nvox * C;                             // group blockIdx.y
+    partials += (size_t)blockIdx.y * gridDim.x * 2 * C;
     float s[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = 0.f;
@@ -267,6 +289,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_colsum_kernel(const float* __re
                                                                float* __restrict__ sums) {
     __shared__ double red[BN_THREADS];
     const int m = blockIdx.x, tid = threadIdx.x;
+    partials += (size_t)blockIdx.y * nrows * M;                      // group blockIdx.y
+    sums += (size_t)blockIdx.y * M;
     double s = 0.0;
     for (int r = tid; r < nrows; r += BN_THREADS) s += (double)partials[(size_t)r * M + m];
     s = bn_block_sum(s, red, tid);
@@ -281,6 +305,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ sc2, const float* __restrict__ sh2, const float* __restrict__ sums, float* __restrict__ dz1,
     float* __restrict__ dz2, float* __restrict__ gout, size_t nquads, int C, int relu, float inv_n) {
     const int CQ = C >> 2;
+    {   // group blockIdx.y (gamma is shared between the groups)
+        const size_t go = (size_t)blockIdx.y * nquads * 4, gc = (size_t)blockIdx.y * C;
+        gy += go; z1 += go; dz1 += go; mean1 += gc; invstd1 += gc; sums += 3 * gc;
+        if (y) y += go;
+        if (z2) z2 += go;
+        if (dz2) dz2 += go;
+        if (gout) gout += go;
+        if (mean2) { mean2 += gc; invstd2 += gc; }
+        if (sc1) { sc1 += gc; sh1 += gc; }
+        if (sc2) { sc2 += gc; sh2 += gc; }
+    }
     const bool has2 = z2 && mean2 && dz2;
     const bool remask = relu && !y;                 // (see bn_bwd_reduce_kernel)
     for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * BN_THREADS) {
@@ -370,23 +405,24 @@ extern "C" int stx_bn_stats_rows(long long nvox, int C) {
     return (int)(g > 256 ? 256 : (g < 1 ? 1 : g));
 }
 
-extern "C" int stx_bn_stats(const float* z, float* partials, long long nvox, int C, void* stream) {
+extern "C" int stx_bn_stats(const float* z, float* partials, long long nvox, int C, int groups, void* stream) {
     stx_begin();
-    STX_REQUIRE(z && partials && nvox > 0, "bn_stats: null operand");
+    STX_REQUIRE(z && partials && nvox > 0 && groups >= 1 && groups <= 65535, "bn_stats: bad args");
     STX_REQUIRE(C >= 4 && C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_stats: C=%d unsupported (multiple of 4 dividing 1024)", C);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(stx_bn_stats_rows(nvox, C)), dim3(BN_THREADS), 0, (hipStream_t)stream, z, partials,
-                       (size_t)nvox, C);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(stx_bn_stats_rows(nvox, C), groups), dim3(BN_THREADS), 0, (hipStream_t)stream, z,
+                       partials, (size_t)nvox, C);
     return stx_check_launch("bn_stats");
 }
 
 extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2,
                             const float* scale2, const float* shift2, float* out, long long nvox, int C, int relu,
-                            void* stream) {
+                            int groups, void* stream) {
     stx_begin();
     STX_REQUIRE(z1 && scale1 && shift1 && out && nvox > 0 && C > 0 && C % 4 == 0, "bn_apply: bad args (C=%d)", C);
     STX_REQUIRE(!scale2 || (z2 && shift2), "bn_apply: second affine needs z2 and shift2");
+    STX_REQUIRE(groups >= 1 && groups <= 65535, "bn_apply: groups=%d", groups);
     const size_t nquads = (size_t)nvox * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, z1, scale1,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(nquads), groups), dim3(BN_THREADS), 0, (hipStream_t)stream, z1, scale1,
                        shift1, z2, scale2, shift2, out, nquads, C / 4, relu);
     return stx_check_launch("bn_apply");
 }
@@ -394,9 +430,10 @@ extern "C" int stx_bn_apply(const float* z1, const float* scale1, const float* s
 extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* z1, const float* mean1,
                                   const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
                                   const float* scale1, const float* shift1, const float* scale2, const float* shift2,
-                                  float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
+                                  float* partials, float* sums, long long nvox, int C, int relu, int groups, void* stream) {
     stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && partials && sums && nvox > 0, "bn_bwd_reduce: null operand");
+    STX_REQUIRE(groups >= 1 && groups <= 65535, "bn_bwd_reduce: groups=%d", groups);
     STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
     STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2) || (scale2 && shift2))),
                 "bn_bwd_reduce: the relu mask needs y or the forward pass's scale / shift vectors");
@@ -405,11 +442,11 @@ extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* 
     // small activations (the 2-D CNN's: <= 4.5 M elements): a quarter of the workgroups, so that the column-sum pass reads
     // 256 partial rows instead of 1024 (both passes are latency-bound there)
     const int nblk = ((long long)nvox * C <= (9ll << 19)) ? BN_RED_BLOCKS / 4 : BN_RED_BLOCKS;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk, groups), dim3(BN_THREADS), 0, st, gy, y, z1, mean1, invstd1,
                        z2, mean2, invstd2, scale1, shift1, scale2, shift2, partials, (size_t)nvox, C, relu);
     int rc = stx_check_launch("bn_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, nblk, 3 * C, sums);
+    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C, groups), dim3(BN_THREADS), 0, st, partials, nblk, 3 * C, sums);
     return stx_check_launch("bn_colsum");
 }
 
@@ -417,14 +454,15 @@ extern "C" int stx_bn_bwd_apply2(const float* gy, const float* y, const float* z
                                  const float* invstd1, const float* gamma1, const float* z2, const float* mean2,
                                  const float* invstd2, const float* gamma2, const float* scale1, const float* shift1,
                                  const float* scale2, const float* shift2, const float* sums, float* dz1, float* dz2,
-                                 float* gout, long long nvox, int C, int relu, void* stream) {
+                                 float* gout, long long nvox, int C, int relu, int groups, void* stream) {
     stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && sums && dz1 && nvox > 0 && C % 4 == 0, "bn_bwd_apply: bad args");
+    STX_REQUIRE(groups >= 1 && groups <= 65535, "bn_bwd_apply: groups=%d", groups);
     STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2 && dz2) || (scale2 && shift2))),
                 "bn_bwd_apply: the relu mask needs y or the forward pass's scale / shift vectors");
     STX_REQUIRE(relu != 2 || !y, "bn_bwd_apply: Mish (activation code 2) differentiates the pre-activation value: pass y = NULL and the scale / shift vectors");
     const size_t nquads = (size_t)nvox * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads)), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_grid(nquads), groups), dim3(BN_THREADS), 0, (hipStream_t)stream, gy, y, z1,
                        mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, scale1, shift1, scale2, shift2, sums, dz1, dz2,
                        gout, nquads, C, relu, (float)(1.0 / (double)nvox));
     return stx_check_launch("bn_bwd_apply");
@@ -434,7 +472,7 @@ extern "C" int stx_bn_bwd_reduce(const float* gy, const float* y, const float* z
                                  const float* invstd1, const float* z2, const float* mean2, const float* invstd2,
                                  float* partials, float* sums, long long nvox, int C, int relu, void* stream) {
     return stx_bn_bwd_reduce2(gy, y, z1, mean1, invstd1, z2, mean2, invstd2, nullptr, nullptr, nullptr, nullptr, partials,
-                              sums, nvox, C, relu, stream);
+                              sums, nvox, C, relu, 1, stream);
 }
 
 extern "C" int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const float* mean1,
@@ -442,5 +480,5 @@ extern "C" int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1
                                 const float* invstd2, const float* gamma2, const float* sums, float* dz1, float* dz2,
                                 float* gout, long long nvox, int C, int relu, void* stream) {
     return stx_bn_bwd_apply2(gy, y, z1, mean1, invstd1, gamma1, z2, mean2, invstd2, gamma2, nullptr, nullptr, nullptr,
-                             nullptr, sums, dz1, dz2, gout, nvox, C, relu, stream);
+                             nullptr, sums, dz1, dz2, gout, nvox, C, relu, 1, stream);
 }

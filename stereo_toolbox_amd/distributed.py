@@ -40,7 +40,12 @@ class FlatGradSync:
         self.views, self.offsets = [], []
         off = 0
         for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            seg = self.flat[off:off + p.numel()]
+            # the view takes the parameter's own strides (the 2-D conv weights are stored channels_last): parameter, gradient
+            # and optimizer state then agree in layout, which the multi-tensor optimizer kernels require -- one mismatching
+            # tensor sends the whole foreach call down the one-kernel-per-tensor path
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            self.views.append(seg.as_strided(p.shape, p.stride()) if dense and not p.is_contiguous() else seg.view_as(p))
             self.offsets.append(off)
             off += p.numel()
         for p, v in zip(self.params, self.views):

@@ -18,6 +18,7 @@ from .submodule import attention_block, convbn_3d
 
 class feature_extraction(ResTrunk):
     """reference acv.py:15-54: trunk only, 320-channel gwc feature."""
+    fused_everywhere = True       # every BatchNorm2d of this extractor runs through features2d.conv_bn_act in train mode
 
     def forward(self, x):
         return {"gwc_feature": torch.cat(self.trunk(x), dim=1)}

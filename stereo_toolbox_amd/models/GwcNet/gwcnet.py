@@ -16,6 +16,7 @@ from .submodule import convbn_3d
 
 class feature_extraction(ResTrunk):
     """reference gwcnet.py:12-65."""
+    fused_everywhere = True       # every BatchNorm2d of this extractor runs through features2d.conv_bn_act in train mode
 
     def __init__(self, concat_feature=False, concat_feature_channel=12):
         super().__init__()

@@ -369,18 +369,22 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return outs   # scale, shift, mean, invstd
 
 
-def bn_stats(z):
-    """Per-workgroup (sum, sum of squares) rows of a dense channels-last activation [..., C] -> [rows, 2, C]: the batch
-    statistics input of bn_finalize for producers without a fused epilogue (the 2-D feature CNN's MIOpen convolutions)."""
+def bn_stats(z, groups=1):
+    """Per-workgroup (sum, sum of squares) rows of a dense channels-last activation [..., C] -> [rows, 2, C]
+    ([groups, rows, 2, C] for groups > 1: the leading axis of z splits into `groups` equal slabs with their own
+    statistics): the batch statistics input of bn_finalize for producers without a fused epilogue (the 2-D feature
+    CNN's MIOpen convolutions)."""
     _chk(z, "z")
     C = z.shape[-1]
-    nvox = z.numel() // C
+    nvox = z.numel() // C // groups
+    if groups < 1 or z.shape[0] % groups:
+        raise StxError(f"bn_stats: leading axis {z.shape[0]} does not split into {groups} groups")
     rows = get_lib().raw("stx_bn_stats_rows")(nvox, C)
     if rows <= 0:
         raise StxError(f"bn_stats: C={C} unsupported")
-    part = torch.empty(rows, 2, C, dtype=torch.float32, device=z.device)
-    _call("stx_bn_stats", _p(z), _p(part), nvox, C)
-    return part
+    part = torch.empty(groups, rows, 2, C, dtype=torch.float32, device=z.device)
+    _call("stx_bn_stats", _p(z), _p(part), nvox, C, groups)
+    return part if groups > 1 else part[0]
 
 
 def _sync_bn_partials(partials, count, group, world):
@@ -397,44 +401,58 @@ def _sync_bn_partials(partials, count, group, world):
     return torch.stack((hi, lo)).contiguous(), count * world
 
 
-def bn_apply(z1, scale1, shift1, z2=None, scale2=None, shift2=None, relu=False):
+def bn_apply(z1, scale1, shift1, z2=None, scale2=None, shift2=None, relu=False, groups=1):
     out = torch.empty_like(z1)
     C = z1.shape[-1]
-    _call("stx_bn_apply", _p(z1), _p(scale1), _p(shift1), _p(z2), _p(scale2), _p(shift2), _p(out), z1.numel() // C, C,
-          int(relu))
+    _call("stx_bn_apply", _p(z1), _p(scale1), _p(shift1), _p(z2), _p(scale2), _p(shift2), _p(out),
+          z1.numel() // C // groups, C, int(relu), groups)
     return out
 
 
 class BnActFn(torch.autograd.Function):
     """y = act(BN1(z1) [+ BN2(z2)] [+ residual]) with batch statistics (train) or running statistics
     (eval with grad).  `bn1`/`bn2` are dicts: gamma, beta, running_mean, running_var, momentum, eps,
-    training, partials (conv-epilogue sums) and count."""
+    training, partials (conv-epilogue sums) and count.
+    groups > 1: the leading axis of z1 (z2, residual) splits into `groups` equal slabs with their OWN batch statistics
+    (partials [groups, rows, 2, C], count = voxels per slab); the running statistics are updated slab after slab, as
+    separate forward calls would (the two views of the 2-D feature CNN, reference gwcnet.py:172-173)."""
 
     @staticmethod
-    def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2):
-        def affine(z, gamma, beta, bn):
+    def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2, groups=1):
+        G = int(groups)
+
+        def affine(gamma, beta, bn):
             if bn["training"]:
                 partials, count = bn["partials"], bn["count"]
-                if bn.get("sync"):
-                    partials, count = _sync_bn_partials(partials, count, *bn["sync"])
-                return bn_finalize(partials, count, gamma, beta, bn["running_mean"], bn["running_var"],
-                                   bn["momentum"], bn["eps"])
+                outs = []
+                for g in range(G):
+                    pg = partials[g] if G > 1 else partials
+                    cg = count
+                    if bn.get("sync"):
+                        pg, cg = _sync_bn_partials(pg, cg, *bn["sync"])
+                    outs.append(bn_finalize(pg, cg, gamma, beta, bn["running_mean"], bn["running_var"], bn["momentum"], bn["eps"]))
+                if G == 1:
+                    return outs[0]
+                return [torch.stack([o[k] for o in outs]).contiguous() for k in range(4)]      # [G, C] each
             invstd = torch.rsqrt(bn["running_var"] + bn["eps"])
             scale = gamma * invstd
-            return scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd
+            res = (scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd)
+            return res if G == 1 else [t.unsqueeze(0).expand(G, -1).contiguous() for t in res]
 
         relu = int(relu)                                  # activation code: 0 none, 1 ReLU, 2 Mish
         if relu == 2 and residual is not None:            # (before anything is launched or any running statistic moves)
             raise StxError("BnActFn: Mish with a plain residual is not wired (no model of the family uses it)")
-        sc1, sh1, m1, i1 = affine(z1, gamma1, beta1, bn1)
+        if G < 1 or z1.shape[0] % G:
+            raise StxError(f"BnActFn: leading axis {z1.shape[0]} does not split into {G} groups")
+        sc1, sh1, m1, i1 = affine(gamma1, beta1, bn1)
         two = z2 is not None
         if two:
-            sc2, sh2, m2, i2 = affine(z2, gamma2, beta2, bn2)
-            y = bn_apply(z1, sc1, sh1, z2, sc2, sh2, relu)
+            sc2, sh2, m2, i2 = affine(gamma2, beta2, bn2)
+            y = bn_apply(z1, sc1, sh1, z2, sc2, sh2, relu, G)
         else:
             sc2 = sh2 = m2 = i2 = None
-            y = bn_apply(z1, sc1, sh1, residual, None, None, relu)
-        ctx.relu, ctx.two, ctx.has_res = relu, two, residual is not None
+            y = bn_apply(z1, sc1, sh1, residual, None, None, relu, G)
+        ctx.relu, ctx.two, ctx.has_res, ctx.groups = relu, two, residual is not None, G
         ctx.train1 = bn1["training"]
         ctx.train2 = bn2["training"] if two else False
         ctx.sync = bn1.get("sync") or (bn2.get("sync") if two else None)
@@ -452,15 +470,16 @@ class BnActFn(torch.autograd.Function):
     def backward(ctx, gy):
         z1, gamma1, m1, i1, z2, gamma2, m2, i2, y, sc1, sh1, sc2, sh2 = ctx.saved_tensors
         gy = gy.contiguous()
+        G = ctx.groups
         C = z1.shape[-1]
-        nvox = z1.numel() // C
+        nvox = z1.numel() // C // G                       # voxels per group
         lib = get_lib()
         NB = lib.raw("stx_bn_reduce_blocks")()
-        part = _WS.get("bnred", NB * 3 * C, z1.device)
-        sums = torch.empty(3, C, dtype=torch.float32, device=z1.device)
+        part = _WS.get("bnred", G * NB * 3 * C, z1.device)
+        sums = torch.empty(G, 3, C, dtype=torch.float32, device=z1.device)
         _call("stx_bn_bwd_reduce2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
               _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(sc1), _p(sh1), _p(sc2), _p(sh2), _p(part),
-              _p(sums), nvox, C, int(ctx.relu))
+              _p(sums), nvox, C, int(ctx.relu), G)
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
@@ -477,11 +496,12 @@ class BnActFn(torch.autograd.Function):
             use = torch.zeros_like(sums)
         _call("stx_bn_bwd_apply2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(gamma1), _p(z2) if ctx.two else None,
               _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(gamma2) if ctx.two else None, _p(sc1), _p(sh1),
-              _p(sc2), _p(sh2), _p(use), _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu))
+              _p(sc2), _p(sh2), _p(use), _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu), G)
         if ctx.has_res and not ctx.relu:
             gres = gy
-        return (dz1, sums[1], sums[0], dz2, sums[2] if ctx.two else None, sums[0] if ctx.two else None, gres,
-                None, None, None)
+        tot = sums[0] if G == 1 else sums.sum(0)          # gamma / beta are shared between the groups
+        return (dz1, tot[1], tot[0], dz2, tot[2] if ctx.two else None, tot[0] if ctx.two else None, gres,
+                None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------- activations

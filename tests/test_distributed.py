@@ -291,3 +291,25 @@ def test_model_gradients_two_ranks_rccl():
         want = want + torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu() / 2
     err = (flat[0] - want).abs().max().item()
     assert err <= 1e-5 * want.abs().max().item() + 1e-7, err     # same kernels, same order: only the AVG's rounding differs
+
+
+def test_flat_grad_sync_keeps_parameter_layout():
+    """Gradient views of channels_last parameters (the 2-D conv weights of the models) carry the parameter's strides, so
+    that parameter / gradient / optimizer state agree in layout (multi-tensor optimizer fast path) and still alias the
+    flat buffer."""
+    sys.path.insert(0, ROOT)
+    from stereo_toolbox_amd.distributed import FlatGradSync
+    model = _net()
+    model[0].weight.data = model[0].weight.data.contiguous(memory_format=torch.channels_last)
+    sync = FlatGradSync(model)
+    assert model[0].weight.grad.stride() == model[0].weight.stride() != model[0].weight.contiguous().stride()
+    sync.detach_grads()
+    model(torch.randn(2, 3, 5, 5)).sum().backward()
+    want = [p.grad.clone() for p in model.parameters()]
+    sync.finish()
+    assert sync.views_intact()
+    for p, w in zip(model.parameters(), want):
+        assert torch.equal(p.grad, w) and p.grad.stride() == p.stride()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.step()                                       # runs on the views
+    assert sync.views_intact()

@@ -83,15 +83,15 @@ def test_run_to_run_bitwise_reproducibility(be):
     part = be.dev(torch.randn(300, 2, C).abs())
     _twice(be, lambda o: be.call("stx_bn_finalize", ptr(part), 300, C, float(nvox), ptr(sc), ptr(sh), None, None, 0.1, 1e-5,
                                  ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3])), lambda: [be.empty(C) for _ in range(4)])
-    _twice(be, lambda o: be.call("stx_bn_apply", ptr(z), ptr(sc), ptr(sh), None, None, None, ptr(o[0]), nvox, C, 1),
+    _twice(be, lambda o: be.call("stx_bn_apply", ptr(z), ptr(sc), ptr(sh), None, None, None, ptr(o[0]), nvox, C, 1, 1),
            lambda: [be.empty(nvox, C)])
     NB = be.raw("stx_bn_reduce_blocks")()
     scratch = be.empty(NB, 3, C)
     _twice(be, lambda o: be.call("stx_bn_bwd_reduce2", ptr(g), None, ptr(z), ptr(mean), ptr(inv), None, None, None, ptr(sc),
-                                 ptr(sh), None, None, ptr(scratch), ptr(o[0]), nvox, C, 1), lambda: [be.empty(3, C)])
+                                 ptr(sh), None, None, ptr(scratch), ptr(o[0]), nvox, C, 1, 1), lambda: [be.empty(3, C)])
     sums = be.dev(torch.randn(3, C))
     _twice(be, lambda o: be.call("stx_bn_bwd_apply2", ptr(g), None, ptr(z), ptr(mean), ptr(inv), ptr(sc), None, None, None,
-                                 None, ptr(sc), ptr(sh), None, None, ptr(sums), ptr(o[0]), None, None, nvox, C, 1),
+                                 None, ptr(sc), ptr(sh), None, None, ptr(sums), ptr(o[0]), None, None, nvox, C, 1, 1),
            lambda: [be.empty(nvox, C)])
     # ---- regression head
     Bh, Dc, Hc, Wc = (1, 12, 16, 40) if big else (1, 4, 5, 7)

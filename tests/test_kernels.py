@@ -658,7 +658,7 @@ def test_bn_mish_fused_fwd_bwd(be, two):
         sc2, sh2, m2, i2 = fin(z2, g2, b2)
     d1, d2 = be.dev(z1.detach()), (be.dev(z2.detach()) if two else None)
     out = be.empty(nvox, C)
-    be.call("stx_bn_apply", ptr(d1), ptr(sc1), ptr(sh1), ptr(d2), ptr(sc2), ptr(sh2), ptr(out), nvox, C, 2)
+    be.call("stx_bn_apply", ptr(d1), ptr(sc1), ptr(sh1), ptr(d2), ptr(sc2), ptr(sh2), ptr(out), nvox, C, 2, 1)
     _close(out, yr.detach(), rtol=1e-5, atol=1e-5)
     gy = torch.randn(nvox, C)
     yr.backward(gy)
@@ -666,11 +666,11 @@ def test_bn_mish_fused_fwd_bwd(be, two):
     NB = be.raw("stx_bn_reduce_blocks")()
     part, sums = be.empty(NB, 3, C), be.empty(3, C)
     be.call("stx_bn_bwd_reduce2", ptr(dgy), None, ptr(d1), ptr(m1), ptr(i1), ptr(d2), ptr(m2), ptr(i2), ptr(sc1), ptr(sh1),
-            ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2)
+            ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2, 1)
     dz1, dz2 = be.empty(nvox, C), (be.empty(nvox, C) if two else None)
     be.call("stx_bn_bwd_apply2", ptr(dgy), None, ptr(d1), ptr(m1), ptr(i1), ptr(be.dev(g1.detach())), ptr(d2), ptr(m2), ptr(i2),
             ptr(be.dev(g2.detach())) if two else None, ptr(sc1), ptr(sh1), ptr(sc2), ptr(sh2), ptr(sums), ptr(dz1), ptr(dz2), None,
-            nvox, C, 2)
+            nvox, C, 2, 1)
     _close(dz1, z1.grad, rtol=1e-4, atol=1e-5)
     _close(sums[1], g1.grad, rtol=1e-4, atol=1e-4)
     _close(sums[0], b1.grad, rtol=1e-4, atol=1e-4)
@@ -680,7 +680,7 @@ def test_bn_mish_fused_fwd_bwd(be, two):
     from stereo_toolbox_amd._capi import StxError
     with pytest.raises(StxError):          # Mish cannot be differentiated from the activated output
         be.call("stx_bn_bwd_reduce2", ptr(dgy), ptr(out), ptr(d1), ptr(m1), ptr(i1), ptr(d2), ptr(m2), ptr(i2), ptr(sc1), ptr(sh1),
-                ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2)
+                ptr(sc2), ptr(sh2), ptr(part), ptr(sums), nvox, C, 2, 1)
 
 
 @pytest.mark.parametrize("case", [(1500, 32), (300, 64), (100, 32), (257, 20)])
@@ -746,7 +746,7 @@ def test_bn_train_fwd_bwd(be, case):
     dz2_in = be.dev(z2.detach()) if z2 is not None else None
     out = be.empty(nvox, C)
     be.call("stx_bn_apply", ptr(dz1_in), ptr(sc1), ptr(sh1), ptr(dz2_in), ptr(sc2) if two else None,
-            ptr(sh2) if two else None, ptr(out), nvox, C, int(relu))
+            ptr(sh2) if two else None, ptr(out), nvox, C, int(relu), 1)
     _close(out, yr.detach(), rtol=1e-5, atol=1e-5)
     _close(drm, rm_ref, rtol=1e-5, atol=1e-6)
     _close(drv, rv_ref, rtol=1e-5, atol=1e-6)
@@ -777,14 +777,14 @@ def test_bn_train_fwd_bwd(be, case):
         part2, sums2 = be.empty(NB, 3, C), be.empty(3, C)
         be.call("stx_bn_bwd_reduce2", ptr(dgy), None, ptr(dz1_in), ptr(m1), ptr(i1), ptr(dz2_in) if two else None,
                 ptr(m2) if two else None, ptr(i2) if two else None, ptr(sc1), ptr(sh1), ptr(sc2) if two else None,
-                ptr(sh2) if two else None, ptr(part2), ptr(sums2), nvox, C, 1)
+                ptr(sh2) if two else None, ptr(part2), ptr(sums2), nvox, C, 1, 1)
         assert torch.equal(sums2.cpu(), sums.cpu())
         dz1b = be.empty(nvox, C)
         dz2b = be.empty(nvox, C) if two else None
         be.call("stx_bn_bwd_apply2", ptr(dgy), None, ptr(dz1_in), ptr(m1), ptr(i1), ptr(be.dev(g1.detach())),
                 ptr(dz2_in) if two else None, ptr(m2) if two else None, ptr(i2) if two else None,
                 ptr(be.dev(g2.detach())) if two else None, ptr(sc1), ptr(sh1), ptr(sc2) if two else None,
-                ptr(sh2) if two else None, ptr(sums2), ptr(dz1b), ptr(dz2b), None, nvox, C, 1)
+                ptr(sh2) if two else None, ptr(sums2), ptr(dz1b), ptr(dz2b), None, nvox, C, 1, 1)
         assert torch.equal(dz1b.cpu(), dz1.cpu())
         if two:
             assert torch.equal(dz2b.cpu(), dz2.cpu())
@@ -801,7 +801,7 @@ def test_bn_stats(be, case):
     rows = be.raw("stx_bn_stats_rows")(nvox, C)
     assert rows >= 1
     part = be.empty(rows, 2, C)
-    be.call("stx_bn_stats", ptr(be.dev(z)), ptr(part), nvox, C)
+    be.call("stx_bn_stats", ptr(be.dev(z)), ptr(part), nvox, C, 1)
     p = part.cpu().double()
     _close(p[:, 0].sum(0).float(), z.double().sum(0).float(), rtol=1e-5, atol=1e-3)
     _close(p[:, 1].sum(0).float(), (z.double() ** 2).sum(0).float(), rtol=1e-5, atol=1e-3)
@@ -826,3 +826,57 @@ def test_conv3d_march_blocked_sums(be, tune):
         e_blk = (got.double() - ref64).abs().mean().item()
         e_seq = (seq.double() - ref64).abs().mean().item()
         assert e_blk < 0.85 * e_seq, (e_blk, e_seq)
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_bn_groups_match_separate_calls(be, two, monkeypatch):
+    """BatchNorm passes with groups = 2 (the two views of the 2-D CNN in one batch, per-view statistics): bit-identical to
+    two separate calls on the two halves -- forward output, running statistics (updated half after half), input
+    gradients; gamma / beta gradients are the sums over the halves."""
+    from stereo_toolbox_amd import ops
+    from tests.emu_util import emu_product_path
+    import contextlib
+    torch.manual_seed(41)
+    C, shape = 32, (4, 5, 7)                       # leading axis 4 = 2 views x batch 2
+    z1 = (torch.randn(*shape, C) * 1.5 + 0.3)
+    z2 = torch.randn(*shape, C) if two else None
+    res = None if two else torch.randn(*shape, C)
+    gy = torch.randn(*shape, C)
+
+    def run(z1_, z2_, res_, gy_, groups, rm, rv):
+        dev = be.device
+        a = z1_.detach().clone().contiguous().to(dev).requires_grad_()
+        b = z2_.detach().clone().contiguous().to(dev).requires_grad_() if z2_ is not None else None
+        r = res_.detach().clone().contiguous().to(dev).requires_grad_() if res_ is not None else None
+        g1, b1 = (torch.rand(C) + 0.5).to(dev).requires_grad_(), (torch.randn(C) * 0.1).to(dev).requires_grad_()
+        nvox = a.numel() // C // groups
+        st = {"training": True, "partials": ops.bn_stats(a.detach(), groups), "count": nvox, "running_mean": rm[0],
+              "running_var": rv[0], "momentum": 0.1, "eps": 1e-5, "sync": None}
+        st2 = None
+        if b is not None:
+            st2 = dict(st, partials=ops.bn_stats(b.detach(), groups), running_mean=rm[1], running_var=rv[1])
+        y = ops.BnActFn.apply(a, g1, b1, b, g1 if b is not None else None, b1 if b is not None else None, r, 1, st, st2, groups)
+        y.backward(gy_.to(dev))
+        return y.detach().cpu(), a.grad.cpu(), (b.grad.cpu() if b is not None else r.grad.cpu()), g1.grad.cpu(), b1.grad.cpu()
+
+    ctx = emu_product_path() if be.name == "emu" else contextlib.nullcontext()
+    with ctx:
+        torch.manual_seed(1)
+        rm = [torch.zeros(C, device=be.device), torch.zeros(C, device=be.device)]
+        rv = [torch.ones(C, device=be.device), torch.ones(C, device=be.device)]
+        torch.manual_seed(7)
+        yg, dag, dbg, gg, bg = run(z1, z2, res, gy, 2, rm, rv)
+        rm2 = [torch.zeros(C, device=be.device), torch.zeros(C, device=be.device)]
+        rv2 = [torch.ones(C, device=be.device), torch.ones(C, device=be.device)]
+        outs = []
+        for h in range(2):
+            sl = slice(2 * h, 2 * h + 2)
+            torch.manual_seed(7)
+            outs.append(run(z1[sl], None if z2 is None else z2[sl], None if res is None else res[sl], gy[sl], 1, rm2, rv2))
+    assert torch.equal(yg, torch.cat([o[0] for o in outs]))
+    assert torch.equal(dag, torch.cat([o[1] for o in outs]))
+    assert torch.equal(dbg, torch.cat([o[2] for o in outs]))
+    _close(gg, outs[0][3] + outs[1][3], rtol=1e-6, atol=1e-6)
+    _close(bg, outs[0][4] + outs[1][4], rtol=1e-6, atol=1e-6)
+    for a, b in zip(rm + rv, rm2 + rv2):
+        assert torch.equal(a.cpu(), b.cpu())

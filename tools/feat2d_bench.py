@@ -22,6 +22,8 @@ ap.add_argument("--fmt", default="both")
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--no-eval", action="store_true")
 ap.add_argument("--no-benchmark", action="store_true")
+ap.add_argument("--batched", action="store_true", help="both views in ONE batch-2 pass (timing experiment: what would batched "
+                "convolutions with per-view BatchNorm statistics buy?)")
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = not a.no_benchmark
 dev = torch.device("cuda:0")
@@ -33,6 +35,9 @@ for fmt in (("nchw", "nhwc") if a.fmt == "both" else (a.fmt,)):
     if fmt == "nhwc":
         m = m.to(memory_format=torch.channels_last)
         x = [t.contiguous(memory_format=torch.channels_last) for t in x]
+
+    if a.batched:
+        x = [torch.cat(x, 0).contiguous(memory_format=torch.channels_last if fmt == "nhwc" else torch.contiguous_format)]
 
     def step():
         outs = [m(t) for t in x]
@@ -46,7 +51,7 @@ for fmt in (("nchw", "nhwc") if a.fmt == "both" else (a.fmt,)):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
-    print(fmt, "fused_glue=%s" % os.environ.get("STX_FEAT2D_FUSED", "1"), "fwd+bwd both views: %.2f ms" % (dt * 1e3), flush=True)
+    print(fmt, "batched" if a.batched else "per-view", "fused_glue=%s" % os.environ.get("STX_FEAT2D_FUSED", "1"), "fwd+bwd both views: %.2f ms" % (dt * 1e3), flush=True)
     if a.no_eval:
         continue
     with torch.no_grad():

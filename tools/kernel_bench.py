@@ -214,7 +214,7 @@ def run_table(a, only_arg, only_exact=False):
         z = torch.randn(nvox, C, device=dev)
         y = torch.empty_like(z)
         sc, sh = torch.rand(C, device=dev), torch.rand(C, device=dev)
-        ms = timeit(lambda: lib.call("stx_bn_apply", P(z), P(sc), P(sh), None, None, None, P(y), nvox, C, 1, stream()), it)
+        ms = timeit(lambda: lib.call("stx_bn_apply", P(z), P(sc), P(sh), None, None, None, P(y), nvox, C, 1, 1, stream()), it)
         report("bn_apply_L0", ms, nbytes=z.numel() * 8)
         nrows = lib.raw("stx_conv3d_fwd_blocks")(D, Hh, Ww) * B
         fpart = torch.randn(nrows, 2, C, device=dev)

@@ -162,6 +162,13 @@ int stx_bn_stats(const float* z, float* partials, long long nvox, int C, int gro
 int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                     float* mean, float* invstd, void* stream);
+/* The same for `groups` slabs of a batch with their own statistics in ONE launch: partials [groups][nrows][2][C],
+ * count = voxels per slab, out [4][groups][C] = scale, shift, mean, invstd.  The running statistics are updated slab
+ * after slab, in order -- bit-identical to `groups` calls of stx_bn_finalize (the two views of the 2-D feature CNN:
+ * reference models/GwcNet/gwcnet.py:172-173 runs the extractor once per view). */
+int stx_bn_finalize_groups(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* out, int groups,
+                           void* stream);
 /* out = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + z2 when scale2 == NULL]) over [nvox][C]; `relu` = activation code
  * (0 none, 1 ReLU, 2 Mish) here and in the backward passes below; Mish is differentiated at the pre-activation value,
  * which stx_bn_bwd_reduce2 / _apply2 recompute from z and the scale / shift vectors (y = NULL) */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "stx_bn_stats_rows": [_L, _I],
     "stx_bn_stats": [_P, _P, _L, _I, _I, _P],
     "stx_bn_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    "stx_bn_finalize_groups": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _F, _F, _P, _I, _P],
     "stx_bn_apply": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P],
     "stx_bn_bwd_reduce": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "stx_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

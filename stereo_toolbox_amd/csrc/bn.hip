@@ -41,9 +41,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
     const float* __restrict__ partials, int nrows, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-    float* __restrict__ invstd_out) {
+    float* __restrict__ invstd_out, int groups) {
     __shared__ double red[BN_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
+    // groups: slab after slab (own statistics each; the running statistics move once per slab, in order, like separate calls)
+    for (int g = 0; g < groups; ++g, partials += (size_t)nrows * 2 * C, scale += C, shift += C, mean_out += C, invstd_out += C) {
     double s1 = 0.0, s2 = 0.0;
     for (int r = tid; r < nrows; r += BN_THREADS) {
         s1 += (double)partials[(size_t)r * 2 * C + c];
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
     }
+    }
 }
 
 // Same result for C % 4 == 0 and many partial rows (the L0 layers emit ~13 000 of them): one workgroup per channel QUAD,
@@ -89,9 +92,11 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize4_kernel(
     const float* __restrict__ partials, int nrows, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
-    float* __restrict__ invstd_out) {
+    float* __restrict__ invstd_out, int groups) {
     __shared__ double red[BN_FIN_THREADS / 64][8];
     const int c0 = blockIdx.x * 4, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int g = 0; g < groups; ++g, partials += (size_t)nrows * 2 * C, scale += C, shift += C, mean_out += C, invstd_out += C) {
+    if (g) __syncthreads();                                          // `red` of the previous slab has been read
     double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     const float* p = partials + c0;
 #pragma unroll 4
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(BN_FIN_THREADS) void bn_finalize4_kernel(
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
         }
+    }
     }
 }
 
@@ -381,18 +387,35 @@ int bn_grid(size_t nquads) {
 extern "C" int stx_bn_reduce_blocks(void) {
     stx_begin(); return BN_RED_BLOCKS; }
 
+static int bn_finalize_launch(const float* partials, int nrows, int C, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                              float* mean, float* invstd, int groups, void* stream) {
+    if (C % 4 == 0 && nrows >= 256)
+        hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(BN_FIN_THREADS), 0, (hipStream_t)stream, partials, nrows, C,
+                           count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, groups);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
+                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd, groups);
+    return stx_check_launch("bn_finalize");
+}
+
 extern "C" int stx_bn_finalize(const float* partials, int nrows, int C, double count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* mean, float* invstd, void* stream) {
     stx_begin();
     STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && scale && shift && mean && invstd, "bn_finalize: bad args");
-    if (C % 4 == 0 && nrows >= 256)
-        hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(BN_FIN_THREADS), 0, (hipStream_t)stream, partials, nrows, C,
-                           count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
-    else
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, partials, nrows, C, count,
-                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean, invstd);
-    return stx_check_launch("bn_finalize");
+    return bn_finalize_launch(partials, nrows, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                              mean, invstd, 1, stream);
+}
+
+extern "C" int stx_bn_finalize_groups(const float* partials, int nrows, int C, double count, const float* gamma,
+                                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                      float* out, int groups, void* stream) {
+    stx_begin();
+    STX_REQUIRE(partials && nrows > 0 && C > 0 && count > 0 && out && groups >= 1, "bn_finalize_groups: bad args");
+    const size_t gc = (size_t)groups * C;
+    return bn_finalize_launch(partials, nrows, C, count, gamma, beta, running_mean, running_var, momentum, eps, out, out + gc,
+                              out + 2 * gc, out + 3 * gc, groups, stream);
 }
 
 extern "C" int stx_bn_stats_rows(long long nvox, int C) {

@@ -29,6 +29,7 @@
 // statistics (finalised by stx_bn_finalize; deterministic, no atomics).
 #include "stx_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -65,6 +66,46 @@ __device__ __forceinline__ f32x16 zero16() {
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     return z;
 }
+
+// Staging map of a halo tile of ED x EH x EW voxels x NF4 float4 for the 256 threads of a workgroup: element
+// e = tid + 256 k -> (voxel, float4 of the K chunk).  The loads go through a buffer descriptor whose base is the tile's
+// ORIGIN voxel (wave-uniform; for tiles on the low edges it lies in front of the volume) and whose range ends with the
+// batch item's volume: the per-lane byte offsets relative to the origin are computed once per kernel, a tile costs three
+// range tests and a select per element (voxels outside the volume get the out-of-range offset and read zeros through the
+// bounds check), a K chunk costs nothing (its channel offset rides in the instruction's scalar offset).  The first version
+// of these kernels rebuilt a 64-bit address behind four bounds tests and a branch for every element of every chunk.
+template <int ED, int EH, int EW, int NF4>
+struct HaloMap {
+    static constexpr int NE = ED * EH * EW * NF4;
+    static constexpr int NST = (NE + CONV_THREADS - 1) / CONV_THREADS;
+    unsigned rel[NST];     // byte offset relative to the tile origin
+    int crd[NST];          // dz << 20 | hy << 10 | wx; -1 behind the last element
+    __device__ __forceinline__ void init(int tid, int Hi, int Wi, int Cin) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * CONV_THREADS;
+            const int v = e / NF4, f = e - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            crd[k] = e < NE ? (dz << 20 | hy << 10 | wx) : -1;
+            rel[k] = (unsigned)((((dz * Hi + hy) * Wi + wx) * Cin + 4 * f) * 4);
+        }
+    }
+    __device__ __forceinline__ void offsets(int d0, int h0, int w0, int Di, int Hi, int Wi, unsigned (&vo)[NST]) const {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int gd = d0 + (crd[k] >> 20), gh = h0 + ((crd[k] >> 10) & 1023), gw = w0 + (crd[k] & 1023);
+            const bool ok = crd[k] >= 0 && gd >= 0 && gd < Di && gh >= 0 && gh < Hi && gw >= 0 && gw < Wi;
+            vo[k] = ok ? rel[k] : STX_BUF_OOB;
+        }
+    }
+    static __device__ __forceinline__ stx_bufrsrc rsrc(const float* x, int b, int d0, int h0, int w0, int Di, int Hi, int Wi,
+                                                       int Cin) {
+        const long long org = ((long long)d0 * Hi + h0) * Wi + w0, vol = (long long)Di * Hi * Wi;
+        return stx_make_rsrc(x + ((long long)b * vol + org) * Cin, (unsigned)((vol - org) * Cin * 4));
+    }
+};
+// (host side: the descriptor range of a batch item plus the low-edge overhang of one plane must stay below 2 GiB)
+static bool halo_range_ok(int Di, int Hi, int Wi, int Cin) { return (long long)(Di + 2) * Hi * Wi * Cin * 4 < (1ll << 31); }
 
 // Fused epilogue for one 32x32 accumulator block. `vox` = linear output voxel index of row 0 of
 // the block (rows are consecutive voxels when `rstride`==1), nrows_valid = rows that exist.
@@ -160,17 +201,32 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void con
         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16();
     }
 
+    using HM = HaloMap<ED, EH, EW, NF4>;
+    constexpr int NST = HM::NST, SG = (NST > 8) ? (NST + 1) / 2 : NST;    // float4 in flight per thread (two rounds for the stride-2 tile)
+    unsigned vo[NST];
+    {
+        HM hm;
+        hm.init(tid, a.Hi, a.Wi, a.Cin);
+        hm.offsets(id0, ih0, iw0, a.Di, a.Hi, a.Wi, vo);
+    }
+    const stx_bufrsrc xrs = HM::rsrc(a.x, b, id0, ih0, iw0, a.Di, a.Hi, a.Wi, a.Cin);
+
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        __syncthreads();
-        for (int idx = tid; idx < ED * EH * EW * NF4; idx += CONV_THREADS) {
-            const int v = idx / NF4, f = idx - v * NF4;
-            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
-            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
-            stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val);
+#pragma unroll
+        for (int k0 = 0; k0 < NST; k0 += SG) {
+            float4 val[SG];
+#pragma unroll
+            for (int j = 0; j < SG; ++j)
+                if (k0 + j < NST) val[j] = stx_buf_ld4(xrs, vo[k0 + j], (unsigned)c0 * 4u);
+            if (k0 == 0) __syncthreads();            // (the loads are in flight while the last readers of the tile finish)
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+                const int e = tid + (k0 + j) * CONV_THREADS;
+                const int v = e / NF4, f = e - v * NF4;
+                const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+                const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+                if (k0 + j < NST && e < HM::NE) stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val[j]);
+            }
         }
         __syncthreads();
         // Both operands are register double-buffered one tap ahead (A from the LDS tile, B = packed
@@ -290,21 +346,18 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
         const int wt = r % a.nWt, ht = (r / a.nWt) % a.nHt, dt = r / (a.nWt * a.nHt);
         od0 = dt * TD; oh0 = ht * TH; ow0 = wt * 32;
     };
+    using HM = HaloMap<ED, EH, EW, NF4>;
+    HM hm;
+    hm.init(tid, a.Hi, a.Wi, a.Cin);
     auto load_item = [&](int t, int c0) {
         int b, od0, oh0, ow0;
         tile_origin(t, b, od0, oh0, ow0);
         const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        unsigned vo[NST];
+        hm.offsets(id0, ih0, iw0, a.Di, a.Hi, a.Wi, vo);
+        const stx_bufrsrc xrs = HM::rsrc(a.x, b, id0, ih0, iw0, a.Di, a.Hi, a.Wi, a.Cin);
 #pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            const int e = tid + k * CONV_THREADS;
-            const int v = e / NF4, f = e - v * NF4;
-            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < NE && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
-            stg[k] = val;
-        }
+        for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, vo[k], (unsigned)c0 * 4u);
     };
     auto store_item = [&]() {
 #pragma unroll
@@ -443,10 +496,21 @@ constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed we
 //  two of the three rotations; the host emulator and a stand-alone test of the same instruction pattern
 //  (tools/ubench/mfma_tail_read.hip) are correct.  Not pursued: every accumulator read of this kernel is at least 16 MFMAs
 //  behind the chain that wrote it.)
-// ILV: the eight ds_read_b128 of the NEXT tap are dealt one per two MFMAs of the current tap (sched_group_barrier) instead of
-// being issued as one 8 KB burst in front of them (a wave alone on its SIMD pays for its own read burst: MI355X guide,
-// "two waves per SIMD", item 7).
-template <int BS, int ILV = 0>
+// The eight ds_read_b128 of the NEXT tap are dealt one per two MFMAs of the current tap (sched_group_barrier) instead of being
+// issued as one 8 KB burst in front of them (a wave alone on its SIMD pays for its own read burst: MI355X guide, "two waves
+// per SIMD", item 7; GPU call F of round 3: 0.776 -> 0.757 ms).
+// EPI: a wave that is alone on its SIMD also pays for every instruction it issues that is not an MFMA: GPU call H2 of
+// round 3 measured 0.766 ms with and 0.681 ms without the epilogue, and the listing showed why -- per output row three
+// 64-bit multiply-adds for the address, an exec-mask save / restore, four to six branches (bounds, partial sums, residual,
+// activation code) that cut the MFMA stream into basic blocks the scheduler cannot fill, and an s_waitcnt vmcnt(0) behind each
+// conditional load.  EPI = 0 (no partial sums of an earlier K slice, no residual, activation none / ReLU: every
+// training-mode launch and most inference ones) is straight-line code: the row's voxel goes through a buffer descriptor of the
+// output PLANE (wave-uniform base in SGPRs, one per-lane byte offset per column of the work list, a wave-uniform row offset in
+// soffset), rows outside the volume get the out-of-range offset (the store is dropped by the bounds check) and contribute
+// zeros to the BN sums.  EPI = 1 is the general epilogue.  The plane staging loads go through a descriptor of the input
+// plane the same way for both (offsets precomputed per column; halo voxels outside the volume and planes outside [0, Di)
+// read zeros through the bounds check: no address clamps, no branches).
+template <int BS, int EPI = 1>
 __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const ConvArgs& a = ma.c;
     STX_DYN_SMEM(smem);
@@ -455,6 +519,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
     const int th = wave;                                             // row block of this wave
+    auto n_lane = [&]() { return i; };                               // output channel of this lane
 
     // weights -> LDS (once): slice [tap][wq_off .. +4][wnt_off] of the packed tensor
     for (int e = tid; e < MW2_WFLOATS / 4; e += 256) {
@@ -471,18 +536,35 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     const int u_end = __builtin_amdgcn_readfirstlane((int)(units * (wg + 1) / gridDim.x));
 
     float4 stg[MW2_NF4];
-    auto load_plane = [&](int pd) {
+    // per column of the work list: byte offsets of this thread's staging float4s inside an input plane (out-of-range marker
+    // for halo voxels outside the volume), of this lane's first output voxel inside an output plane, validity bits of its rows
+    unsigned svoff[MW2_NF4], ovoff = 0, ovalid = 0;
+    const unsigned xplane_bytes = (unsigned)a.Hi * (unsigned)a.Wi * (unsigned)ma.xs * 4u;
+    const unsigned oplane_bytes = (unsigned)a.Ho * (unsigned)a.Wo * (unsigned)ma.os * 4u;
+    auto column_offsets = [&]() {
 #pragma unroll
         for (int k = 0; k < MW2_NF4; ++k) {
             const int idx = tid + k * 256;
             const int v = idx >> 3, f = idx & 7;
             const int wx = v % MW2_EW, hy = v / MW2_EW;
             const int gh = oh0 - 1 + hy, gw = ow0 - 1 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < MW2_EH * MW2_EW && pd >= 0 && pd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + pd) * a.Hi + gh) * a.Wi + gw) * ma.xs + ma.xo + 4 * f);
-            stg[k] = val;
+            const bool ok = v < MW2_EH * MW2_EW && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi;
+            svoff[k] = ok ? (unsigned)(((gh * a.Wi + gw) * ma.xs + ma.xo + 4 * f) * 4) : STX_BUF_OOB;
         }
+        const int ohb = oh0 + th * MW2_R, owb = ow0 + 4 * half;
+        ovoff = (unsigned)((((ohb * a.Wo + owb) * ma.os) + ma.oo + n_lane()) * 4);
+        ovalid = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
+            if (ohb + dh < a.Ho && owb + c < a.Wo && n_lane() < ma.ncout) ovalid |= 1u << r;
+        }
+    };
+    auto load_plane = [&](int pd, bool on) {
+        const bool in = on && pd >= 0 && pd < a.Di;                  // (wave-uniform) planes outside the volume read zeros
+        const stx_bufrsrc rs = stx_make_rsrc(a.x + ((size_t)b * a.Di + (in ? pd : 0)) * a.Hi * a.Wi * ma.xs, in ? xplane_bytes : 0u);
+#pragma unroll
+        for (int k = 0; k < MW2_NF4; ++k) stg[k] = stx_buf_ld4(rs, svoff[k], 0u);
     };
     auto store_plane = [&](float* buf) {
 #pragma unroll
@@ -516,11 +598,27 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             a.out[idx] = v;
         }
     };
+    // EPI = 0: the same row as straight-line code (see the kernel comment); `vmask` = validity bits of this lane's rows in the
+    // finished plane (zero when there is none), `ors` = descriptor of that output plane
+    const bool relu_on = a.relu == 1;
+    auto emit_row_plain = [&](const f32x16& done0, const f32x16& done1, const f32x16& done, int r, unsigned vmask,
+                              const stx_bufrsrc& ors) {
+        const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
+        const bool ok = (vmask >> r) & 1u;
+        float v = BS ? (done0[r] + done1[r]) + done[r] : done[r];
+        v = ok ? v : 0.f;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+        v = fmaf(v, sc, bs);
+        const float vr = fmaxf(v, 0.f);
+        v = relu_on ? vr : v;
+        stx_buf_st1(ors, ok ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4), v);
+    };
 
     // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
     // (the finished output plane dprev) interleaved with the MFMA groups
     auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done0, const f32x16& done1,
-                         const f32x16& done, int dprev, int epi0) {
+                         const f32x16& done, int dprev, int epi0, unsigned vmask, const stx_bufrsrc& ors) {
         float4 av[2][4], bv[2][4];
         auto load_tap = [&](int t9, int buf) {
             const int kh = t9 / 3, kw = t9 % 3;
@@ -536,7 +634,6 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
             if (t9 + 1 < 9) load_tap(t9 + 1, (t9 + 1) & 1);
-            if (!ILV) STX_SCHED_BARRIER();
             const int cb = t9 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -545,18 +642,20 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, acc, 0, 0, 0);
             }
-            if (ILV && t9 + 1 < 9) {
+            // rows epi0 + t9 of the finished plane: 16 rows over the 18 taps of the kd = 1 and kd = 0 planes
+            const int r = epi0 + t9;
+            if (EPI == 0) {
+                if (epi0 >= 0 && r < 16) emit_row_plain(done0, done1, done, r, vmask, ors);
+            }
+            if (t9 + 1 < 9) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     STX_SCHED_GROUP(0x008, 2);
                     STX_SCHED_GROUP(0x100, 1);
+                    if (EPI == 0) STX_SCHED_GROUP(0x002, 2);
                 }
             }
-            if (with_epi) {
-                // rows epi0 + t9 (and the last slice takes what is left of its half): 16 rows over 18 taps
-                const int r = epi0 + t9;
-                if (r < 16) emit_row(done0, done1, done, r, dprev);
-            }
+            if (EPI != 0 && with_epi && r < 16) emit_row(done0, done1, done, r, dprev);
             STX_SCHED_BARRIER();
         }
     };
@@ -570,21 +669,31 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         if (BS) { pC = zero16(); pE = zero16(); }
         const bool live = p >= 0 && p < a.Di;                        // planes outside the volume are zero padding
         const bool vOld = p - 1 >= d_lo && p - 1 < d_hi, vMid = p >= d_lo && p < d_hi, vNew = p + 1 >= d_lo && p + 1 < d_hi;
-        if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, 0);
+        const bool st_on = vOld && ma.ablate != 2;
+        const unsigned vmask = st_on ? ovalid : 0u;
+        const stx_bufrsrc ors = stx_make_rsrc(a.out + ((size_t)b * a.Do + (st_on ? p - 1 : 0)) * a.Ho * a.Wo * ma.os,
+                                              st_on ? oplane_bytes : 0u);
+        if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, -1, 0u, ors);
         // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
         // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
         if (stage) store_plane(nbuf);
         // output p-1 is complete: its 16 rows leave in the shadow of the next 18 taps (or on their own at the edges)
-        if (live && vMid) tap_plane(pbuf, 1, pE, vOld, pA, pB, pC, p - 1, 0);
+        if (live && vMid) tap_plane(pbuf, 1, pE, vOld, pA, pB, pC, p - 1, 0, vmask, ors);
         else if (vOld) {
             // no MFMAs to hide behind: plain epilogue of rows 0..8
 #pragma unroll
-            for (int r = 0; r < 9; ++r) emit_row(pA, pB, pC, r, p - 1);
+            for (int r = 0; r < 9; ++r) {
+                if (EPI == 0) emit_row_plain(pA, pB, pC, r, vmask, ors);
+                else emit_row(pA, pB, pC, r, p - 1);
+            }
         }
-        if (live && vNew) tap_plane(pbuf, 0, pF, vOld, pA, pB, pC, p - 1, 9);
+        if (live && vNew) tap_plane(pbuf, 0, pF, vOld, pA, pB, pC, p - 1, 9, vmask, ors);
         else if (vOld) {
 #pragma unroll
-            for (int r = 9; r < 16; ++r) emit_row(pA, pB, pC, r, p - 1);
+            for (int r = 9; r < 16; ++r) {
+                if (EPI == 0) emit_row_plain(pA, pB, pC, r, vmask, ors);
+                else emit_row(pA, pB, pC, r, p - 1);
+            }
         }
     };
 
@@ -603,14 +712,15 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             oh0 = ht * MW2_TH; ow0 = wt * MW2_MW;
         }
         // input planes d_lo-1 .. d_hi feed the outputs d_lo .. d_hi-1
+        column_offsets();
         __syncthreads();                                             // the previous run is done with both buffers
-        load_plane(d_lo - 1);
+        load_plane(d_lo - 1, true);
         store_plane(planes);
         __syncthreads();
         int par = 0;
         auto advance = [&](int p, f32x16& pA, f32x16& pB, f32x16& pC, f32x16& pD, f32x16& pE, f32x16& pF) {
             const bool stage = p + 1 <= d_hi && ma.ablate != 1;
-            if (stage) load_plane(p + 1);                            // in flight during this plane's first 9 taps
+            load_plane(p + 1, stage);                                // in flight during this plane's first 9 taps
             step(p, d_lo, d_hi, planes + par * MW2_SLOT, planes + (par ^ 1) * MW2_SLOT, stage, pA, pB, pC, pD, pE, pF);
             __syncthreads();                                         // plane p+1 is resident, plane p's buffer is free
             par ^= 1;
@@ -758,16 +868,27 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
         for (int nt = 0; nt < NT; ++nt) acc[c][nt] = zero16();
     const int abase = ((th * EW) + i) * VS + 4 * half;
 
+    using HM = HaloMap<ED, EH, EW, NF4>;
+    constexpr int NST = HM::NST;
+    unsigned vo[NST];
+    {
+        HM hm;
+        hm.init(tid, a.Hi, a.Wi, a.Cin);
+        hm.offsets(md0, mh0, mw0, a.Di, a.Hi, a.Wi, vo);
+    }
+    const stx_bufrsrc xrs = HM::rsrc(a.x, b, md0, mh0, mw0, a.Di, a.Hi, a.Wi, a.Cin);
+
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        float4 val[NST];
+#pragma unroll
+        for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, vo[k], (unsigned)c0 * 4u);
         __syncthreads();
-        for (int idx = tid; idx < ED * EH * EW * NF4; idx += CONV_THREADS) {
-            const int v = idx / NF4, f = idx - v * NF4;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * CONV_THREADS;
+            const int v = e / NF4, f = e - v * NF4;
             const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-            const int gd = md0 + dz, gh = mh0 + hy, gw = mw0 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gd < a.Di && gh < a.Hi && gw < a.Wi)
-                val = stx_ld4(a.x + ((((size_t)b * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.Cin + c0 + 4 * f);
-            stx_st4(tile + ((dz * EH + hy) * EW + wx) * VS + 4 * f, val);
+            if (e < HM::NE) stx_st4(tile + ((dz * EH + hy) * EW + wx) * VS + 4 * f, val[k]);
         }
         __syncthreads();
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
@@ -866,7 +987,7 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     float* ctile = ftile + ED * EH * EWS * 32;              // [NV][32]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: scalar branches on it)
     const int i = lane & 31, half = lane >> 5;
     const int ncf = a.CF / 32;
     const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;
@@ -879,10 +1000,35 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     // of the next tile are issued right before the current tile's MFMA loop and only written to LDS
     // after it (one workgroup per CU, 2 waves per SIMD: measured, more fp32-MFMA waves per SIMD lower
     // the matrix-pipe throughput); without PIPE both halves run back to back (small 1x1 case).
-    constexpr int NFL = (ED * EH * EW * 8 + NTHR - 1) / NTHR;    // float4 per lane: fine tile
-    constexpr int NCL = (NV * 8 + NTHR - 1) / NTHR;              //                  coarse tile
+    // The loads go through buffer descriptors (one per input plane of the tile, wave-uniform: base = the tile's origin in
+    // that plane, possibly in front of the plane for tiles on the low edges) with per-lane byte offsets that are computed
+    // ONCE per kernel; voxels outside the volume get the out-of-range offset and read zeros through the bounds check, planes
+    // outside [0, Df) get an empty descriptor.  Per tile that leaves two compares and a select per float4 -- the first
+    // version recomputed a 64-bit address with four bounds tests and a branch per float4, in lock-step on all eight waves
+    // (GPU call H2 of round 3: 0.817 ms with, 0.687 ms without the staging at 32 -> 32 L0).
+    constexpr int NPL = (EH * EW * 8 + NTHR - 1) / NTHR;         // float4 per lane and fine-tile plane
+    constexpr int NFL = ED * NPL;                                //                 fine tile
+    constexpr int NCL = (NV * 8 + NTHR - 1) / NTHR;              //                 coarse tile
     float4 sf[NFL], sc[NCL];
-    auto load_tile = [&](int tile) {
+    unsigned fbase[NPL], cbase[NCL];                             // byte offsets relative to the tile origin
+    int fhw[NPL], chw[NCL];                                      // (row << 16 | column) inside the tile, -1 = no element
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int idx = tid + k * NTHR;
+        const int v = idx >> 3, f = idx & 7;
+        const int wx = v % EW, hy = v / EW;
+        fhw[k] = idx < EH * EW * 8 ? (hy << 16 | wx) : -1;
+        fbase[k] = (unsigned)(((hy * a.Wf + wx) * a.CF + cfb * 32 + 4 * f) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NCL; ++k) {
+        const int idx = tid + k * NTHR;
+        const int v = idx >> 3, f = idx & 7;
+        chw[k] = idx < NV * 8 ? ((v / TW) << 16 | (v % TW)) : -1;
+        cbase[k] = (unsigned)((((v / TW) * a.Wc + v % TW) * a.CC + ccb * 32 + 4 * f) * 4);
+    }
+    const long long fplane = (long long)a.Hf * a.Wf, cplane = (long long)a.Hc * a.Wc;
+    auto load_tile = [&](int tile, bool on) {
         int r = tile;
         const int wt = r % a.nWt; r /= a.nWt;
         const int ht = r % a.nHt; r /= a.nHt;
@@ -890,37 +1036,41 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
         const int b = r / a.Dc;
         const int oh0 = ht * TH, ow0 = wt * TW;
         const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        unsigned fvo[NPL];
 #pragma unroll
-        for (int k = 0; k < NFL; ++k) {
-            const int idx = tid + k * NTHR;
-            const int v = idx >> 3, f = idx & 7;
-            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-            const int gd = id0 + dz, gh = ih0 + hy, gw = iw0 + wx;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < ED * EH * EW * 8 && gd >= 0 && gd < a.Df && gh >= 0 && gh < a.Hf && gw >= 0 && gw < a.Wf)
-                val = stx_ld4(a.f + ((((size_t)b * a.Df + gd) * a.Hf + gh) * a.Wf + gw) * a.CF + cfb * 32 + 4 * f);
-            sf[k] = val;
+        for (int k = 0; k < NPL; ++k) {
+            const int gh = ih0 + (fhw[k] >> 16), gw = iw0 + (fhw[k] & 0xffff);
+            fvo[k] = (fhw[k] >= 0 && gh >= 0 && gh < a.Hf && gw >= 0 && gw < a.Wf) ? fbase[k] : STX_BUF_OOB;
         }
+        const long long forg = (long long)ih0 * a.Wf + iw0;     // tile origin inside a plane (voxels; negative on the low edges)
+#pragma unroll
+        for (int dz = 0; dz < ED; ++dz) {
+            const int gd = id0 + dz;
+            const bool in = on && gd >= 0 && gd < a.Df;
+            const stx_bufrsrc rs = stx_make_rsrc(a.f + (((long long)b * a.Df + (in ? gd : 0)) * fplane + forg) * a.CF,
+                                                 in ? (unsigned)((fplane - forg) * a.CF * 4) : 0u);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) sf[dz * NPL + k] = stx_buf_ld4(rs, fvo[k], 0u);
+        }
+        const long long corg = (long long)oh0 * a.Wc + ow0;
+        const stx_bufrsrc rc = stx_make_rsrc(a.c + (((long long)b * a.Dc + od) * cplane + corg) * a.CC,
+                                             on ? (unsigned)((cplane - corg) * a.CC * 4) : 0u);
 #pragma unroll
         for (int k = 0; k < NCL; ++k) {
-            const int idx = tid + k * NTHR;
-            const int v = idx >> 3, f = idx & 7;
-            const int ow = ow0 + v % TW, oh = oh0 + v / TW;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NV * 8 && oh < a.Hc && ow < a.Wc)
-                val = stx_ld4(a.c + ((((size_t)b * a.Dc + od) * a.Hc + oh) * a.Wc + ow) * a.CC + ccb * 32 + 4 * f);
-            sc[k] = val;
+            const bool ok = chw[k] >= 0 && oh0 + (chw[k] >> 16) < a.Hc && ow0 + (chw[k] & 0xffff) < a.Wc;
+            sc[k] = stx_buf_ld4(rc, ok ? cbase[k] : STX_BUF_OOB, 0u);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int k = 0; k < NFL; ++k) {
-            const int idx = tid + k * NTHR;
-            const int v = idx >> 3, f = idx & 7;
-            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
-            if (idx < ED * EH * EW * 8) stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, sf[k]);
-        }
+        for (int dz = 0; dz < ED; ++dz)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int wx = fhw[k] & 0xffff, hy = fhw[k] >> 16;
+                const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+                const int f = (tid + k * NTHR) & 7;
+                if (fhw[k] >= 0) stx_st4(ftile + ((dz * EH + hy) * EWS + slot) * 32 + 4 * f, sf[dz * NPL + k]);
+            }
 #pragma unroll
         for (int k = 0; k < NCL; ++k) {
             const int idx = tid + k * NTHR;
@@ -928,15 +1078,18 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
         }
     };
 
-    if (PIPE && (int)blockIdx.x < a.ntiles) load_tile(blockIdx.x);
+    if (PIPE && (int)blockIdx.x < a.ntiles) load_tile(blockIdx.x, a.ablate != 1);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        if (!PIPE && a.ablate != 1) load_tile(tile);
+        if (!PIPE) load_tile(tile, a.ablate != 1);
         __syncthreads();                 // every wave is done with the previous tile in LDS
         if (a.ablate != 1) store_tile();
         __syncthreads();
-        if (PIPE && tile + (int)gridDim.x < a.ntiles && a.ablate != 1) load_tile(tile + gridDim.x);
+        if (PIPE) {                      // (an empty descriptor behind the last tile: no branch in front of the MFMA loop)
+            const int nxt = tile + (int)gridDim.x;
+            load_tile(nxt < a.ntiles ? nxt : tile, nxt < a.ntiles && a.ablate != 1);
+        }
         if (a.ablate == 2) continue;
-        if (KS == 1) {
+        if constexpr (KS == 1) {
             // waves split the voxel pairs
             for (int p = wave; p < NV / 2; p += NW) {
                 const int v = 2 * p + half;
@@ -956,31 +1109,48 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
                                    : ((kd * EH + kh) * EWS + kw) * 32;
             }
-            float av[2][NTAP], bv[2];
-            auto load_pair = [&](int p, int buf) {
-                const int v = 2 * p + half;
-                const int lw = v % TW, lh = v / TW;
-                const int vb = ((lh * S) * EWS + lw) * 32 + i;
-                bv[buf] = ctile[v * 32 + i];
+            // The waves hold NTAP or NTAP - 1 taps (27 taps over 8 waves: three waves with four, five with three).  The loop
+            // is instantiated for both counts and chosen by a wave-uniform branch OUTSIDE it: a per-MFMA `if (tap exists)`
+            // compiles to an exec-mask save / branch / restore around the MFMA (the wave index is a VGPR value to the
+            // compiler), which cuts the loop body into basic blocks and costs six scalar instructions per four MFMAs.
+            auto mfma_tile = [&](auto na_c) {
+                constexpr int NA = decltype(na_c)::value;
+                float av[2][NA], bv[2];
+                auto load_pair = [&](int p, int buf) {
+                    const int v = 2 * p + half;
+                    const int lw = v % TW, lh = v / TW;
+                    const int vb = ((lh * S) * EWS + lw) * 32 + i;
+                    bv[buf] = ctile[v * 32 + i];
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) av[buf][t] = ftile[vb + toff[t]];
-            };
-            auto mma_pair = [&](int buf) {
+                    for (int t = 0; t < NA; ++t) av[buf][t] = ftile[vb + toff[t]];
+                };
+                auto mma_pair = [&](int buf) {
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t)
-                    if (t * NW + wave < T) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf], acc[t], 0, 0, 0);
+                    for (int t = 0; t < NA; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf], acc[t], 0, 0, 0);
+                };
+                auto two_pairs = [&](int p) {
+                    load_pair(p + 1, 1);
+                    STX_SCHED_BARRIER();
+                    mma_pair(0);
+                    STX_SCHED_BARRIER();
+                    load_pair((p + 2 < NV / 2) ? p + 2 : 0, 0);     // unconditional (wraps): keeps the lgkmcnt
+                    STX_SCHED_BARRIER();                            // pipeline one stage deep on every trip
+                    mma_pair(1);
+                    STX_SCHED_BARRIER();
+                };
+                load_pair(0, 0);
+                if constexpr (S == 2) {
+                    // (the stride-2 tile keeps 15 staging float4 in flight: unrolled, with one precomputed LDS address per
+                    //  pair, the loop spills under the 256-VGPR cap of two waves per SIMD)
+#pragma unroll 1
+                    for (int p = 0; p < NV / 2; p += 2) two_pairs(p);
+                } else {
+                    for (int p = 0; p < NV / 2; p += 2) two_pairs(p);
+                }
             };
-            load_pair(0, 0);
-            for (int p = 0; p < NV / 2; p += 2) {
-                load_pair(p + 1, 1);
-                STX_SCHED_BARRIER();
-                mma_pair(0);
-                STX_SCHED_BARRIER();
-                load_pair((p + 2 < NV / 2) ? p + 2 : 0, 0);     // unconditional (wraps): keeps the lgkmcnt
-                STX_SCHED_BARRIER();                            // pipeline one stage deep on every trip
-                mma_pair(1);
-                STX_SCHED_BARRIER();
-            }
+            if ((NTAP - 1) * NW + wave < T) mfma_tile(std::integral_constant<int, NTAP>{});
+            else mfma_tile(std::integral_constant<int, NTAP - 1>{});
         }
     }
     // partial slab: KS=3: [blockIdx.y][blockIdx.x][tap][cf 32][cc 32]; KS=1: [..][wave][32][32]
@@ -1081,7 +1251,7 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
 #define CONV_CASE(NT_, CK_)                                                                                        \
     if (NT == NT_ && CK == CK_)                                                                                    \
         return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, grid, lds, st, a);
-    CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32)
+    if constexpr (KS == 1) { CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32) }      // (conv_pick_ck: 3x3x3 takes 8-channel chunks only)
     CONV_CASE(1, 8) CONV_CASE(2, 8) CONV_CASE(4, 8)
 #undef CONV_CASE
     return stx_set_error(STX_ERR_ARG, "conv3d: unsupported NT=%d CK=%d", NT, CK);
@@ -1163,16 +1333,19 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
         m2.ncols = B * m2.c.nHt * m2.c.nWt;
         m2.ablate = stx_tune(STX_TUNE_MARCH_ABLATE);
-        if ((long long)m2.ncols * a.Do < (1ll << 31)) {
+        // (planes are addressed through buffer descriptors with 32-bit byte offsets)
+        if ((long long)m2.ncols * a.Do < (1ll << 31) && (long long)Hi * Wi * Cin * 4 < (1ll << 31) &&
+            (long long)a.Ho * a.Wo * Cout * 4 < (1ll << 31)) {
             const int nb2 = march_wgs((long long)m2.ncols * a.Do);
             const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
             // STX_MARCH_BS: 1 = one accumulator per (output, input plane), summed in the epilogue; 0 = one sequential chain per
-            // output.  STX_MARCH_ILV: 1 = operand reads of the next tap dealt between the MFMAs, 0 = issued as a burst in
-            // front of them (GPU call F of round 3, 32 -> 32 L0: 0.776 -> 0.757 ms without / 0.784 -> 0.767 ms with the
-            // blocked sums)
-            const int bs = stx_tune(STX_TUNE_MARCH_BS), ilv = stx_tune(STX_TUNE_MARCH_ILV);
-            void (*mk)(MarchArgs) = bs ? (ilv ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<1, 0>)
-                                       : (ilv ? conv3d_marchw_kernel<0, 1> : conv3d_marchw_kernel<0, 0>);
+            // output (GPU call F of round 3, 32 -> 32 L0: 0.757 -> 0.767 ms).  STX_MARCH_EPI: 1 = straight-line epilogue for
+            // the launches that admit it, 0 = general epilogue always.
+            const int bs = stx_tune(STX_TUNE_MARCH_BS), epi_fast = stx_tune(STX_TUNE_MARCH_EPI);
+            void (*mk_gen)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<0, 1>;
+            void (*mk_plain)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 0> : conv3d_marchw_kernel<0, 0>;
+            hipFuncSetAttribute((const void*)mk_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            void (*mk)(MarchArgs) = mk_gen;
             hipFuncSetAttribute((const void*)mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
             const int nk = Cin / 32, nn = stx_cdiv(Cout, 32);
@@ -1185,11 +1358,14 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
-                    hipLaunchKernelGGL(mk, dim3(nb2), dim3(256), lds2, st, m);
+                    const bool plain = epi_fast && !m.acc_in && !m.c.residual && m.c.relu != 2;
+                    hipLaunchKernelGGL(plain ? mk_plain : mk, dim3(nb2), dim3(256), lds2, st, m);
                 }
             return stx_check_launch("conv3d_fwd(march)");
         }
     }
+    STX_REQUIRE(halo_range_ok(Di, Hi, Wi, Cin), "conv3d_fwd: a batch item of %d x %d x %d x %d floats exceeds the 2 GiB "
+                "buffer-descriptor range", Di, Hi, Wi, Cin);
     // stride 2 stages a (2TD+1)(2TH+1)x65-voxel input tile: 8-channel K chunks (79 KB padded, 53 KB dense).
     const int CK = (stride == 2) ? 8 : conv_pick_ck(Cin, ks);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
@@ -1233,6 +1409,8 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
     a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
     a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     a.nDt = Di; a.nHt = stx_cdiv(Hi, 2); a.nWt = stx_cdiv(Wi, 32);
+    STX_REQUIRE(halo_range_ok(Di, Hi, Wi, Cin), "deconv3d_fwd: a batch item of %d x %d x %d x %d floats exceeds the 2 GiB "
+                "buffer-descriptor range", Di, Hi, Wi, Cin);
     dim3 grid(a.nDt * a.nHt * a.nWt, B);
     hipStream_t st = (hipStream_t)stream;
     // 8-channel K chunks (9.5 KB of LDS: four workgroups per CU; calls S/T of round 2: 32-channel chunks 0.153 / 0.266 ms,
@@ -1280,6 +1458,8 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
                 "conv3d_wgrad: channel counts (%d, %d) must be positive multiples of 32", CF, CC);
     STX_REQUIRE(Dc > 0 && Hc > 0 && Wc > 0, "conv3d_wgrad: empty volume");
     STX_REQUIRE((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1), "conv3d_wgrad: ks/stride");
+    STX_REQUIRE((long long)Hf * Wf * CF * 4 < (1ll << 31) && (long long)Hc * Wc * CC * 4 < (1ll << 31),
+                "conv3d_wgrad: a plane of %d x %d voxels exceeds the 2 GiB buffer-descriptor range", Hf, Wf);
     WgradArgs a;
     a.f = f; a.c = c; a.slab = workspace;
     a.B = B; a.Df = Df; a.Hf = Hf; a.Wf = Wf; a.CF = CF; a.Dc = Dc; a.Hc = Hc; a.Wc = Wc; a.CC = CC;
@@ -1308,8 +1488,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
         else if (pipe) WG_LAUNCH(3, 1, 4, 32, 8, true, ((size_t)3 * 6 * 34 + 128) * 32 * 4)
         else WG_LAUNCH(3, 1, 2, 32, 8, false, ((size_t)3 * 4 * 34 + 64) * 32 * 4)
     } else if (ks == 3) {
-        if (pipe) WG_LAUNCH(3, 2, 4, 16, 8, true, ((size_t)3 * 9 * 34 + 64) * 32 * 4)
-        else WG_LAUNCH(3, 2, 2, 16, 8, false, ((size_t)3 * 5 * 34 + 32) * 32 * 4)
+        WG_LAUNCH(3, 2, 4, 16, 8, true, ((size_t)3 * 9 * 34 + 64) * 32 * 4)      // (wgrad_pipe: always pipelined)
     } else {
         WG_LAUNCH(1, 1, 2, 32, 4, false, ((size_t)2 * 32 + 64) * 32 * 4)
     }

@@ -48,6 +48,14 @@ static inline float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsigned soff) {
     if (voff >= STX_BUF_OOB || off + 4 > r.bytes) return 0.f;
     return *reinterpret_cast<const float*>(r.base + off);
 }
+// Store through a descriptor: lanes with voff = STX_BUF_OOB are dropped.  (The hardware checks voff only, not voff + soff:
+// an in-range voff with an out-of-range sum would corrupt memory on the chip -- the emulator aborts on it.)
+static inline void stx_buf_st1(stx_bufrsrc r, unsigned voff, unsigned soff, float v) {
+    if (voff >= STX_BUF_OOB) return;
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (off + 4 > r.bytes) abort();
+    *reinterpret_cast<float*>(const_cast<char*>(r.base) + off) = v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t stx_bufrsrc;
 typedef unsigned int stx_u32x4 __attribute__((ext_vector_type(4)));
@@ -60,6 +68,9 @@ __device__ __forceinline__ float4 stx_buf_ld4(stx_bufrsrc r, unsigned voff, unsi
 }
 __device__ __forceinline__ float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsigned soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void stx_buf_st1(stx_bufrsrc r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
 }
 #endif
 // A pointer the program knows to be wave-uniform, forced into SGPRs (two v_readfirstlane): loads through it become
@@ -99,7 +110,7 @@ static inline int stx_cdiv(int a, int b) { return (a + b - 1) / b; }
 // tools/kernel_bench.py flip them inside one process).  None changes results beyond fp32 rounding.
 enum StxTune {
     STX_TUNE_MARCH_BS,       // STX_MARCH_BS       1  march kernel: one accumulator per (output, input plane), summed in the epilogue
-    STX_TUNE_MARCH_ILV,      // STX_MARCH_ILV      1  march kernel: operand reads of the next tap dealt between the MFMAs
+    STX_TUNE_MARCH_EPI,      // STX_MARCH_EPI      1  march kernel: straight-line epilogue for launches without partial sums / residual / Mish
     STX_TUNE_MARCH_ABLATE,   // STX_MARCH_ABLATE   0  profiling: 1 = no plane staging, 2 = no epilogue stores
     STX_TUNE_WGRAD_ABLATE,   // STX_WGRAD_ABLATE   0  profiling: 1 = no tile staging, 2 = no MFMA loop
     STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)

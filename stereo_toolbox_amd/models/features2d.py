@@ -204,7 +204,8 @@ def run_pair(extractor, left, right, training):
     if training:
         bns = [m for m in extractor.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
         if (os.environ.get("STX_FEAT2D_PAIRED", "1") != "0" and left.shape == right.shape and bns and fused_glue(left, *bns)
-                and all(b.momentum is not None for b in bns) and getattr(extractor, "fused_everywhere", False)):
+                and all(b.momentum is not None and not isinstance(b, nn.SyncBatchNorm) for b in bns)
+                and getattr(extractor, "fused_everywhere", False)):
             # one batched pass, per-view BatchNorm statistics (see view_groups); only for extractors whose EVERY BatchNorm
             # goes through the fused glue (a stock BatchNorm module would pool the two views)
             with view_groups(2):

@@ -361,12 +361,14 @@ class ConvRawFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------- batch norm
-def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps):
+def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, groups=1):
+    """partials [rows, 2, C] ([groups, rows, 2, C] for groups > 1) -> scale, shift, mean, invstd ([C] each, [groups, C] for
+    groups > 1: one launch, running statistics updated slab after slab)."""
     C = partials.shape[-1]
-    outs = [torch.empty(C, dtype=torch.float32, device=partials.device) for _ in range(4)]
-    _call("stx_bn_finalize", _p(partials), partials.shape[0], C, float(count), _p(gamma), _p(beta),
-          _p(running_mean), _p(running_var), float(momentum), float(eps), *[_p(o) for o in outs])
-    return outs   # scale, shift, mean, invstd
+    out = torch.empty(4, groups, C, dtype=torch.float32, device=partials.device)
+    _call("stx_bn_finalize_groups", _p(partials), partials.shape[-3], C, float(count), _p(gamma), _p(beta),
+          _p(running_mean), _p(running_var), float(momentum), float(eps), _p(out), groups)
+    return list(out.unbind(0)) if groups > 1 else list(out[:, 0].unbind(0))   # scale, shift, mean, invstd
 
 
 def bn_stats(z, groups=1):
@@ -424,16 +426,12 @@ class BnActFn(torch.autograd.Function):
         def affine(gamma, beta, bn):
             if bn["training"]:
                 partials, count = bn["partials"], bn["count"]
-                outs = []
-                for g in range(G):
-                    pg = partials[g] if G > 1 else partials
-                    cg = count
-                    if bn.get("sync"):
-                        pg, cg = _sync_bn_partials(pg, cg, *bn["sync"])
-                    outs.append(bn_finalize(pg, cg, gamma, beta, bn["running_mean"], bn["running_var"], bn["momentum"], bn["eps"]))
-                if G == 1:
-                    return outs[0]
-                return [torch.stack([o[k] for o in outs]).contiguous() for k in range(4)]      # [G, C] each
+                if bn.get("sync"):
+                    if G > 1:
+                        raise StxError("BnActFn: SyncBatchNorm with groups is not wired (SyncBN runs the views separately)")
+                    partials, count = _sync_bn_partials(partials, count, *bn["sync"])
+                return bn_finalize(partials, count, gamma, beta, bn["running_mean"], bn["running_var"], bn["momentum"],
+                                   bn["eps"], G)                                              # [C] each ([G, C] for G > 1)
             invstd = torch.rsqrt(bn["running_var"] + bn["eps"])
             scale = gamma * invstd
             res = (scale, beta - bn["running_mean"] * scale, bn["running_mean"].clone(), invstd)

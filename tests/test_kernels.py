@@ -333,6 +333,7 @@ CONV_CASES = [
     (1, 32, 32, 9, 3, 70, 3, 1),     # march kernel, long D, W spanning 5 16-wide tiles (8 x 16 columns)
     (1, 32, 32, 3, 9, 60, 3, 1),     # march kernel, 4 x 32 columns (W = 60 wastes the same either way), ragged H
     (2, 32, 64, 4, 6, 64, 3, 1),     # march kernel, 4 x 32 columns, NT=2
+    (2, 32, 24, 5, 11, 21, 3, 1),    # march kernel, 24 of a slice's 32 output channels, ragged H / W, two batch items
 ]
 
 
@@ -351,6 +352,8 @@ def test_conv3d_fwd(be, case):
     got2, _ = run_conv(be, x, w, ks, s, sc, bs, res, 1)
     ref2 = F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res)
     _close(got2, ref2)
+    got4, _ = run_conv(be, x, w, ks, s, sc, bs, None, 1)             # affine + ReLU without residual (march: straight-line epilogue)
+    _close(got4, F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1)))
     got3, _ = run_conv(be, x, w, ks, s, sc, bs, res, 2)              # activation code 2: Mish in the epilogue
     _close(got3, F.mish(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res), rtol=1e-4, atol=1e-5)
 
@@ -434,7 +437,9 @@ def run_wgrad(be, fine, coarse, ks, stride):
     return dw.cpu()
 
 
-@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1)])
+@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1),
+                                  (2, 64, 64, 3, 5, 37, 3, 1), (1, 64, 64, 2, 3, 60, 3, 1),     # four channel-block pairs: un-pipelined staging, 4 x 16 / 2 x 32 tiles
+                                  (1, 64, 128, 3, 7, 21, 3, 2)])
 def test_conv3d_wgrad(be, case):
     B, Cin, Cout, D, H, W, ks, s = case
     torch.manual_seed(8)
@@ -826,6 +831,25 @@ def test_conv3d_march_blocked_sums(be, tune):
         e_blk = (got.double() - ref64).abs().mean().item()
         e_seq = (seq.double() - ref64).abs().mean().item()
         assert e_blk < 0.85 * e_seq, (e_blk, e_seq)
+
+
+def test_conv3d_march_epilogues_agree(be, tune):
+    """The straight-line epilogue of the march kernel (buffer-descriptor stores, validity bits; STX_MARCH_EPI=1, the default
+    for launches without partial sums / residual / Mish) and the general one produce the same bits: outputs, BN partial
+    sums, affine + ReLU; ragged tiles, sliced channels, several runs per workgroup."""
+    torch.manual_seed(6)
+    for B, Cin, Cout, D, H, W in ((1, 32, 32, 7, 9, 37), (2, 32, 64, 5, 6, 40), (1, 64, 32, 4, 8, 33), (2, 32, 24, 3, 11, 21)):
+        x = torch.randn(B, Cin, D, H, W)
+        w = torch.randn(Cout, Cin, 3, 3, 3) * 0.1
+        sc, bs = torch.rand(Cout) + 0.5, torch.randn(Cout)
+        outs = []
+        for epi in (1, 0):
+            tune("STX_MARCH_EPI", epi)
+            raw, st = run_conv(be, x, w, 3, 1, stats=True)
+            act, _ = run_conv(be, x, w, 3, 1, sc, bs, None, 1)
+            outs.append((raw, st, act))
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize("two", [False, True])

@@ -66,7 +66,7 @@ def pack(w, mode):
 # comparison costs one interpreter start.  (label, kernel filter, {switch: value})
 AB_SETS = [
     ("march kernel: one sequential accumulation chain per output", "conv_32_32_L0_fwd,conv_64_32_L0_fwd", {"STX_MARCH_BS": 0}),
-    ("march kernel: operand reads as a burst in front of the MFMAs", "conv_32_32_L0_fwd,conv_64_32_L0_fwd", {"STX_MARCH_ILV": 0}),
+    ("march kernel: general (branchy) epilogue for every launch", "conv_32_32_L0_fwd,conv_64_32_L0_fwd", {"STX_MARCH_EPI": 0}),
     ("march kernel: no plane staging (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 1}),
     ("march kernel: no epilogue stores (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 2}),
     ("stride-2 32->64 with the padded LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": 0}),

@@ -29,7 +29,6 @@
 // statistics (finalised by stx_bn_finalize; deterministic, no atomics).
 #include "stx_common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -987,7 +986,7 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     float* ctile = ftile + ED * EH * EWS * 32;              // [NV][32]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform: scalar branches on it)
+    const int wave = tid >> 6;
     const int i = lane & 31, half = lane >> 5;
     const int ncf = a.CF / 32;
     const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;
@@ -1089,7 +1088,7 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
             load_tile(nxt < a.ntiles ? nxt : tile, nxt < a.ntiles && a.ablate != 1);
         }
         if (a.ablate == 2) continue;
-        if constexpr (KS == 1) {
+        if (KS == 1) {
             // waves split the voxel pairs
             for (int p = wave; p < NV / 2; p += NW) {
                 const int v = 2 * p + half;
@@ -1109,48 +1108,34 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
                 toff[t] = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * 32
                                    : ((kd * EH + kh) * EWS + kw) * 32;
             }
-            // The waves hold NTAP or NTAP - 1 taps (27 taps over 8 waves: three waves with four, five with three).  The loop
-            // is instantiated for both counts and chosen by a wave-uniform branch OUTSIDE it: a per-MFMA `if (tap exists)`
-            // compiles to an exec-mask save / branch / restore around the MFMA (the wave index is a VGPR value to the
-            // compiler), which cuts the loop body into basic blocks and costs six scalar instructions per four MFMAs.
-            auto mfma_tile = [&](auto na_c) {
-                constexpr int NA = decltype(na_c)::value;
-                float av[2][NA], bv[2];
-                auto load_pair = [&](int p, int buf) {
-                    const int v = 2 * p + half;
-                    const int lw = v % TW, lh = v / TW;
-                    const int vb = ((lh * S) * EWS + lw) * 32 + i;
-                    bv[buf] = ctile[v * 32 + i];
+            // (Instantiating the loop per tap count -- three waves hold four taps, five hold three -- behind a wave-uniform
+            //  branch removes the exec-mask save / restore around the conditional MFMAs but measured SLOWER, GPU call L of
+            //  round 3: 32 -> 32 L0 0.795 -> 0.865 ms, 64 -> 64 L1 0.432 -> 0.476 ms; two unrolled loop bodies per workgroup.)
+            float av[2][NTAP], bv[2];
+            auto load_pair = [&](int p, int buf) {
+                const int v = 2 * p + half;
+                const int lw = v % TW, lh = v / TW;
+                const int vb = ((lh * S) * EWS + lw) * 32 + i;
+                bv[buf] = ctile[v * 32 + i];
 #pragma unroll
-                    for (int t = 0; t < NA; ++t) av[buf][t] = ftile[vb + toff[t]];
-                };
-                auto mma_pair = [&](int buf) {
-#pragma unroll
-                    for (int t = 0; t < NA; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf], acc[t], 0, 0, 0);
-                };
-                auto two_pairs = [&](int p) {
-                    load_pair(p + 1, 1);
-                    STX_SCHED_BARRIER();
-                    mma_pair(0);
-                    STX_SCHED_BARRIER();
-                    load_pair((p + 2 < NV / 2) ? p + 2 : 0, 0);     // unconditional (wraps): keeps the lgkmcnt
-                    STX_SCHED_BARRIER();                            // pipeline one stage deep on every trip
-                    mma_pair(1);
-                    STX_SCHED_BARRIER();
-                };
-                load_pair(0, 0);
-                if constexpr (S == 2) {
-                    // (the stride-2 tile keeps 15 staging float4 in flight: unrolled, with one precomputed LDS address per
-                    //  pair, the loop spills under the 256-VGPR cap of two waves per SIMD)
-#pragma unroll 1
-                    for (int p = 0; p < NV / 2; p += 2) two_pairs(p);
-                } else {
-                    for (int p = 0; p < NV / 2; p += 2) two_pairs(p);
-                }
+                for (int t = 0; t < NTAP; ++t) av[buf][t] = ftile[vb + toff[t]];
             };
-            if ((NTAP - 1) * NW + wave < T) mfma_tile(std::integral_constant<int, NTAP>{});
-            else mfma_tile(std::integral_constant<int, NTAP - 1>{});
+            auto mma_pair = [&](int buf) {
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+                    if (t * NW + wave < T) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][t], bv[buf], acc[t], 0, 0, 0);
+            };
+            load_pair(0, 0);
+            for (int p = 0; p < NV / 2; p += 2) {
+                load_pair(p + 1, 1);
+                STX_SCHED_BARRIER();
+                mma_pair(0);
+                STX_SCHED_BARRIER();
+                load_pair((p + 2 < NV / 2) ? p + 2 : 0, 0);     // unconditional (wraps): keeps the lgkmcnt
+                STX_SCHED_BARRIER();                            // pipeline one stage deep on every trip
+                mma_pair(1);
+                STX_SCHED_BARRIER();
+            }
         }
     }
     // partial slab: KS=3: [blockIdx.y][blockIdx.x][tap][cf 32][cc 32]; KS=1: [..][wave][32][32]

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_mfma_kernel(const floa
                                                                       int nHt, int nWt, int ncols) {
     STX_DYN_SMEM(smem);
     float* Ps = reinterpret_cast<float*>(smem);                  // [2][C1F_NV][27]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, half = lane >> 5;
     // B operand: step s multiplies channel 16 half + s; lane column = tap i
     float wreg[16];
@@ -352,9 +352,15 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_mfma_kernel(const floa
     for (int s_ = 0; s_ < 16; ++s_) wreg[s_] = (i < 27) ? w[(size_t)(16 * half + s_) * 27 + i] : 0.f;
     const int lh = tid / C1F_TW, lw = tid % C1F_TW;              // my output column of the tile
 
+    // A operand of the NEXT plane in flight while this plane is multiplied and gathered (the first version loaded, waited
+    // and multiplied M-tile after M-tile: three exposed memory round trips per plane, 0.102 ms = 0.27 of the HBM rate).  The
+    // loads go through a descriptor of the input plane: per-lane byte offsets once per column (halo voxels outside the
+    // volume get the out-of-range offset and read zeros), planes outside [0, D) an empty descriptor.
+    constexpr int MTW = (C1F_MT + 3) / 4;                          // M-tiles per wave (3, 3, 3, 2)
     const long long units = (long long)ncols * D;
-    int u = (int)(units * blockIdx.x / gridDim.x);
-    const int u_end = (int)(units * (blockIdx.x + 1) / gridDim.x);
+    int u = __builtin_amdgcn_readfirstlane((int)(units * blockIdx.x / gridDim.x));
+    const int u_end = __builtin_amdgcn_readfirstlane((int)(units * (blockIdx.x + 1) / gridDim.x));
+    const unsigned plane_bytes = (unsigned)H * (unsigned)W * 32u * 4u;
     while (u < u_end) {
         const int col = u / D;
         const int d_lo = u - col * D;
@@ -365,42 +371,58 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_fwd_mfma_kernel(const floa
         const int h0 = ht * C1F_TH, w0 = wt * C1F_TW;
         const int oh = h0 + lh, ow = w0 + lw;
         const bool ook = oh < H && ow < W;
+        unsigned voff[MTW];
+#pragma unroll
+        for (int t = 0; t < MTW; ++t) {
+            const int hv = (wave + 4 * t) * 32 + i;
+            const int hy = hv / C1F_EW, wx = hv - hy * C1F_EW;
+            const int gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+            const bool ok = wave + 4 * t < C1F_MT && hv < C1F_NV && gh >= 0 && gh < H && gw >= 0 && gw < W;
+            voff[t] = ok ? (unsigned)(((gh * W + gw) * 32 + 16 * half) * 4) : STX_BUF_OOB;
+        }
+        float4 nxt[MTW][4];
+        auto load_plane = [&](int p) {
+            const bool in = p >= 0 && p < D && p <= d_hi;
+            const stx_bufrsrc rs = stx_make_rsrc(x + ((size_t)b * D + (in ? p : 0)) * H * W * 32, in ? plane_bytes : 0u);
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) nxt[t][q] = stx_buf_ld4(rs, voff[t], 16u * q);
+        };
         float accA = 0.f, accB = 0.f;
+        load_plane(d_lo - 1);
         __syncthreads();                                          // previous run is done with Ps
         for (int p = d_lo - 1; p <= d_hi; ++p) {
             float* Pb = Ps + ((p + 2) & 1) * (C1F_NV * 27);
             const bool pin = p >= 0 && p < D;
+            float4 cur[MTW][4];
+#pragma unroll
+            for (int t = 0; t < MTW; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cur[t][q] = nxt[t][q];
+            load_plane(p + 1);
             if (pin) {
-#pragma unroll 1
-                for (int m = wave; m < C1F_MT; m += 4) {
-                    const int hv = m * 32 + i;
-                    const int hy = hv / C1F_EW, wx = hv - hy * C1F_EW;
-                    const int gh = h0 - 1 + hy, gw = w0 - 1 + wx;
-                    float4 a4[4];
-                    if (hv < C1F_NV && gh >= 0 && gh < H && gw >= 0 && gw < W) {
-                        const float* xp = x + ((((size_t)b * D + p) * H + gh) * W + gw) * 32 + 16 * half;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) a4[q] = stx_ld4(xp + 4 * q);
-                    } else {
+                for (int t = 0; t < MTW; ++t) {
+                    const int m = wave + 4 * t;
+                    if (m < C1F_MT) {
+                        f32x16 acc;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) a4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                    f32x16 acc;
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][q].x, wreg[4 * q + 0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][q].y, wreg[4 * q + 1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][q].z, wreg[4 * q + 2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[t][q].w, wreg[4 * q + 3], acc, 0, 0, 0);
+                        }
+                        // D: acc[r] = P[voxel (r & 3) + 8 (r >> 2) + 4 half of the M-tile][tap i]
+                        if (i < 27) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].x, wreg[4 * q + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].y, wreg[4 * q + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].z, wreg[4 * q + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q].w, wreg[4 * q + 3], acc, 0, 0, 0);
-                    }
-                    // D: acc[r] = P[voxel (r & 3) + 8 (r >> 2) + 4 half of the M-tile][tap i]
-                    if (i < 27) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int v = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            if (v < C1F_NV) Pb[v * 27 + i] = acc[r];
+                            for (int r = 0; r < 16; ++r) {
+                                const int v = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                if (v < C1F_NV) Pb[v * 27 + i] = acc[r];
+                            }
                         }
                     }
                 }
@@ -438,7 +460,7 @@ extern "C" int stx_conv3d_c1_fwd(const float* x, const float* w, const float* re
     stx_begin();
     STX_REQUIRE(x && w && out && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_c1_fwd: bad shape");
     STX_REQUIRE(Cin % C1_CK == 0, "conv3d_c1_fwd: Cin=%d must be a multiple of %d", Cin, C1_CK);
-    if (Cin == 32) {                                   // (other widths: the streaming VALU kernel below)
+    if (Cin == 32 && (long long)H * W * 128 < (1ll << 31)) {   // (other widths, planes beyond the descriptor range: VALU kernel below)
         const int nHt = stx_cdiv(H, C1F_TH), nWt = stx_cdiv(W, C1F_TW);
         const long long ncols = (long long)B * nHt * nWt, units = ncols * D;
         STX_REQUIRE(units < (1ll << 31), "conv3d_c1_fwd: volume too large");

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 3, GPU call L: weight-gradient loop per tap count, grouped BN finalize, small-shape train parity with the stock / fused 2-D glue.
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+L=gpurun_out/r3l
+( timeout 900 python -m pytest tests/test_kernels.py -m gpu -q -p no:cacheprovider 2>&1 | tail -4 ) | tee ${L}_pytest.log | cut -c1-200
+for f in 1 0; do ( STX_FEAT2D_FUSED=$f timeout 300 python -m pytest tests/test_models.py -m gpu -q -p no:cacheprovider --tb=short -k "gwcnet_gc_train_parity or acvnet_train_parity" 2>&1 | grep -E "grad err|passed|failed|Error|train_grads" | cut -c1-400 | sed "s/^/fused=$f /" ) | tee -a ${L}_small_train.txt; done
+timeout 300 python tools/kernel_bench.py --iters 20 --only wgrad,bn_ > ${L}_kernel_bench.log 2>&1; grep -E '"kernel"' ${L}_kernel_bench.log | cut -c1-110
+timeout 500 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep '^{' | tail -1 | tee ${L}_bench.json | cut -c1-400

@@ -95,9 +95,12 @@ long long stx_conv3d_packed_floats(int K, int N, int T);
 int stx_conv3d_pack_weight(const float* w, float* wp, int A, int B, int T, int mode, void* stream);
 /* out = act(conv(x) * scale[c] + bias[c] + residual); `relu` is the activation code: 0 none, 1 ReLU, 2 Mish
  * (x * tanh(softplus(x)), models/PCWNet/submodule.py:11-18); scale/bias/residual may be NULL; if `stats` != NULL the
- * per-workgroup (sum, sum of squares) of the RAW conv output are written to stats[B*blocks][2][Cout]
- * (blocks = stx_conv3d_fwd_blocks(Do,Ho,Wo)) for train-mode BatchNorm. Cin % 8 == 0, Cout <= 128. */
+ * per-workgroup (sum, sum of squares) of the RAW conv output are written to stats[rows][2][Cout] for train-mode
+ * BatchNorm: rows = stx_conv3d_fwd_stat_rows(same shape arguments) -- every one of these rows is written, nothing beyond
+ * them is touched (no zero-fill pass: hand exactly `rows` rows to stx_bn_finalize).  Cin % 8 == 0, Cout <= 128.
+ * stx_conv3d_fwd_blocks(Do,Ho,Wo) * B is an upper bound of `rows` for any channel configuration. */
 int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo);
+long long stx_conv3d_fwd_stat_rows(int B, int Di, int Hi, int Wi, int Cin, int Cout, int ks, int stride);
 int stx_conv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
                    const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout, int ks,
                    int stride, int relu, void* stream);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "stx_conv3d_packed_floats": [_I, _I, _I],
     "stx_conv3d_pack_weight": [_P, _P, _I, _I, _I, _I, _P],
     "stx_conv3d_fwd_blocks": [_I, _I, _I],
+    "stx_conv3d_fwd_stat_rows": [_I, _I, _I, _I, _I, _I, _I, _I],
     "stx_deconv3d_fwd_blocks": [_I, _I, _I],
     "stx_conv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -105,7 +106,7 @@ class StxLib:
             fn = getattr(self._dll, name, None)
             if fn is None:
                 continue
-            fn.restype = ctypes.c_longlong if name.endswith("_floats") else _I
+            fn.restype = ctypes.c_longlong if name.endswith(("_floats", "_stat_rows")) else _I
             fn.argtypes = argtypes
             self._fns[name] = fn
 

@@ -168,7 +168,7 @@ template <int KS, int S, int TD, int TH, int NT, int CK, int VPAD = 4>
 // (occupancy hint: without it hipcc spends 132-180 VGPRs on the 1-2 column-block variants and two workgroups share a CU;
 //  with it the 8- and 16-channel chunk variants take 101 without spilling and four do -- GPU call T: 64->64 L1
 //  0.486 -> 0.430 ms with 8-channel chunks)
-__global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void conv3d_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4) : 2) void conv3d_igemm_kernel(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void con
     }
 
     using HM = HaloMap<ED, EH, EW, NF4>;
-    constexpr int NST = HM::NST, SG = (NST > 8) ? (NST + 1) / 2 : NST;    // float4 in flight per thread (two rounds for the stride-2 tile)
+    constexpr int NST = HM::NST;
     unsigned vo[NST];
     {
         HM hm;
@@ -209,25 +209,29 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? 4 : 2) void con
         hm.offsets(id0, ih0, iw0, a.Di, a.Hi, a.Wi, vo);
     }
     const stx_bufrsrc xrs = HM::rsrc(a.x, b, id0, ih0, iw0, a.Di, a.Hi, a.Wi, a.Cin);
+    // the halo tile of the NEXT K chunk is in flight (global -> registers) during this chunk's tap loop and goes to LDS
+    // between the two barriers that separate the chunks: only the first chunk's memory latency is exposed
+    float4 stg[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, vo[k], 0u);
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
+        __syncthreads();                             // every wave is done reading the previous chunk's tile
 #pragma unroll
-        for (int k0 = 0; k0 < NST; k0 += SG) {
-            float4 val[SG];
-#pragma unroll
-            for (int j = 0; j < SG; ++j)
-                if (k0 + j < NST) val[j] = stx_buf_ld4(xrs, vo[k0 + j], (unsigned)c0 * 4u);
-            if (k0 == 0) __syncthreads();            // (the loads are in flight while the last readers of the tile finish)
-#pragma unroll
-            for (int j = 0; j < SG; ++j) {
-                const int e = tid + (k0 + j) * CONV_THREADS;
-                const int v = e / NF4, f = e - v * NF4;
-                const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
-                const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
-                if (k0 + j < NST && e < HM::NE) stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, val[j]);
-            }
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * CONV_THREADS;
+            const int v = e / NF4, f = e - v * NF4;
+            const int wx = v % EW, hy = (v / EW) % EH, dz = v / (EW * EH);
+            const int slot = (S == 2) ? (wx & 1) * EWH + (wx >> 1) : wx;
+            if (e < HM::NE) stx_st4(tile + ((dz * EH + hy) * EWS + slot) * VS + 4 * f, stg[k]);
         }
         __syncthreads();
+        {
+            // (behind the last chunk: an empty descriptor range -- no memory traffic, no branch)
+            const bool more = c0 + CK < a.Cin;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
+        }
         // Both operands are register double-buffered one tap ahead (A from the LDS tile, B = packed
         // weights from L2); the scheduling fences keep "issue next tap's loads, then this tap's
         // MFMAs" -- otherwise hipcc sinks the loads next to their use and every tap eats an L2 round trip.
@@ -506,7 +510,10 @@ constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed we
 // training-mode launch and most inference ones) is straight-line code: the row's voxel goes through a buffer descriptor of the
 // output PLANE (wave-uniform base in SGPRs, one per-lane byte offset per column of the work list, a wave-uniform row offset in
 // soffset), rows outside the volume get the out-of-range offset (the store is dropped by the bounds check) and contribute
-// zeros to the BN sums.  EPI = 1 is the general epilogue.  The plane staging loads go through a descriptor of the input
+// zeros to the BN sums.  EPI = 2 is the same with the partial sums of an earlier K slice added (second half of a 64 -> 32
+// layer: its 16 values per lane are loaded through the same descriptor at the START of the step, nine taps before the first
+// is needed -- the general epilogue waited for each of them with s_waitcnt vmcnt(0): 1.10 vs 0.70 ms per launch in the
+// step trace of GPU call N).  EPI = 1 is the general epilogue.  The plane staging loads go through a descriptor of the input
 // plane the same way for both (offsets precomputed per column; halo voxels outside the volume and planes outside [0, Di)
 // read zeros through the bounds check: no address clamps, no branches).
 template <int BS, int EPI = 1>
@@ -600,11 +607,20 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     // EPI = 0: the same row as straight-line code (see the kernel comment); `vmask` = validity bits of this lane's rows in the
     // finished plane (zero when there is none), `ors` = descriptor of that output plane
     const bool relu_on = a.relu == 1;
+    float accp[16];                                                  // EPI = 2: partial sums of the earlier K slice (rows of plane p-1)
+    auto load_partials = [&](unsigned vmask, const stx_bufrsrc& ors) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
+            accp[r] = stx_buf_ld1(ors, ((vmask >> r) & 1u) ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4));
+        }
+    };
     auto emit_row_plain = [&](const f32x16& done0, const f32x16& done1, const f32x16& done, int r, unsigned vmask,
                               const stx_bufrsrc& ors) {
         const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
         const bool ok = (vmask >> r) & 1u;
         float v = BS ? (done0[r] + done1[r]) + done[r] : done[r];
+        if (EPI == 2) v += accp[r];
         v = ok ? v : 0.f;
         s1 += v;
         s2 = fmaf(v, v, s2);
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             }
             // rows epi0 + t9 of the finished plane: 16 rows over the 18 taps of the kd = 1 and kd = 0 planes
             const int r = epi0 + t9;
-            if (EPI == 0) {
+            if (EPI != 1) {
                 if (epi0 >= 0 && r < 16) emit_row_plain(done0, done1, done, r, vmask, ors);
             }
             if (t9 + 1 < 9) {
@@ -651,10 +667,10 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
                 for (int g = 0; g < 8; ++g) {
                     STX_SCHED_GROUP(0x008, 2);
                     STX_SCHED_GROUP(0x100, 1);
-                    if (EPI == 0) STX_SCHED_GROUP(0x002, 2);
+                    if (EPI != 1) STX_SCHED_GROUP(0x002, 2);
                 }
             }
-            if (EPI != 0 && with_epi && r < 16) emit_row(done0, done1, done, r, dprev);
+            if (EPI == 1 && with_epi && r < 16) emit_row(done0, done1, done, r, dprev);
             STX_SCHED_BARRIER();
         }
     };
@@ -672,6 +688,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         const unsigned vmask = st_on ? ovalid : 0u;
         const stx_bufrsrc ors = stx_make_rsrc(a.out + ((size_t)b * a.Do + (st_on ? p - 1 : 0)) * a.Ho * a.Wo * ma.os,
                                               st_on ? oplane_bytes : 0u);
+        if (EPI == 2) load_partials(vmask, ors);                     // (acc_in == out: the rows this step finishes, read before written)
         if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, -1, 0u, ors);
         // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
         // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             // no MFMAs to hide behind: plain epilogue of rows 0..8
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
-                if (EPI == 0) emit_row_plain(pA, pB, pC, r, vmask, ors);
+                if (EPI != 1) emit_row_plain(pA, pB, pC, r, vmask, ors);
                 else emit_row(pA, pB, pC, r, p - 1);
             }
         }
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         else if (vOld) {
 #pragma unroll
             for (int r = 9; r < 16; ++r) {
-                if (EPI == 0) emit_row_plain(pA, pB, pC, r, vmask, ors);
+                if (EPI != 1) emit_row_plain(pA, pB, pC, r, vmask, ors);
                 else emit_row(pA, pB, pC, r, p - 1);
             }
         }
@@ -877,10 +894,10 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
     }
     const stx_bufrsrc xrs = HM::rsrc(a.x, b, md0, mh0, mw0, a.Di, a.Hi, a.Wi, a.Cin);
 
-    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-        float4 val[NST];
+    float4 val[NST];                                 // the next K chunk's tile: in flight during this chunk's taps
 #pragma unroll
-        for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, vo[k], (unsigned)c0 * 4u);
+    for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, vo[k], 0u);
+    for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
@@ -890,6 +907,11 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
             if (e < HM::NE) stx_st4(tile + ((dz * EH + hy) * EW + wx) * VS + 4 * f, val[k]);
         }
         __syncthreads();
+        {
+            const bool more = c0 + CK < a.Cin;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
+        }
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
         if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
         else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
@@ -1217,14 +1239,10 @@ size_t conv_lds_bytes(int CK, int NT) {
 
 // Persistent pipelined launch: 256 * (workgroups per CU the LDS tile admits, at most 2) workgroups share the tiles evenly.
 template <typename K>
-int launch_persistent(K kernel, size_t lds, hipStream_t st, ConvArgs a, int ntiles) {
+int launch_persistent(K kernel, size_t lds, hipStream_t st, ConvArgs a, int ntiles, int grid) {
     if (lds > 160 * 1024) return stx_set_error(STX_ERR_ARG, "conv3d: LDS tile of %zu B exceeds 160 KiB", lds);
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = (int)((160 * 1024) / (lds + 512));
-    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
-    int grid = 256 * per_cu;
-    if (grid > ntiles) grid = ntiles;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(CONV_THREADS), lds, st, a, ntiles);
     return 0;
 }
@@ -1288,6 +1306,46 @@ extern "C" int stx_conv3d_fwd_blocks(int Do, int Ho, int Wo) {
 extern "C" int stx_deconv3d_fwd_blocks(int Di, int Hi, int Wi) {
     stx_begin(); return Di * stx_cdiv(Hi, 2) * stx_cdiv(Wi, 32); }
 
+// Which kernel stx_conv3d_fwd runs for a shape, and how many rows of the BN-statistics slab it writes (one per workgroup
+// that owns outputs): the single source for the launch below and for stx_conv3d_fwd_stat_rows.
+struct ConvPlan { int kind; int march_wgs; int pgrid; long long rows; };     // kind: 0 march, 1 pipelined (128 channels), 2 implicit GEMM
+static int persistent_grid(size_t lds, long long ntiles) {
+    int per_cu = (int)((160 * 1024) / (lds + 512));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    const long long g = 256ll * per_cu;
+    return (int)(g > ntiles ? ntiles : g);
+}
+static ConvPlan conv_plan(int B, int Di, int Hi, int Wi, int Cin, int Cout, int ks, int stride) {
+    const int pad = ks / 2;
+    const int Do = (Di + 2 * pad - ks) / stride + 1, Ho = (Hi + 2 * pad - ks) / stride + 1, Wo = (Wi + 2 * pad - ks) / stride + 1;
+    ConvPlan p{2, 0, 0, 0};
+    if (ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
+        const long long ncols = (long long)B * stx_cdiv(Ho, MW2_TH) * stx_cdiv(Wo, MW2_MW);
+        // (planes are addressed through buffer descriptors with 32-bit byte offsets)
+        if (ncols * Do < (1ll << 31) && (long long)Hi * Wi * Cin * 4 < (1ll << 31) && (long long)Ho * Wo * Cout * 4 < (1ll << 31)) {
+            p.kind = 0; p.march_wgs = march_wgs(ncols * Do); p.rows = p.march_wgs;
+            return p;
+        }
+    }
+    const long long tiles = (long long)stx_cdiv(Do, CONV_TD) * stx_cdiv(Ho, CONV_TH) * stx_cdiv(Wo, 32);
+    if (conv_nt(Cout) == 4 && ks == 3 && tiles * B < (1ll << 31)) {
+        const size_t lds = stride == 1 ? conv_lds_bytes<3, 1>(8, 4) : conv_lds_bytes<3, 2>(8, 4);
+        p.kind = 1; p.pgrid = persistent_grid(lds, tiles * B); p.rows = p.pgrid;
+        return p;
+    }
+    p.rows = tiles * B;
+    return p;
+}
+
+// Rows of the `stats` slab stx_conv3d_fwd writes for this call ([rows][2][Cout], every row written, nothing beyond):
+// allocate exactly this many and hand them all to stx_bn_finalize.
+extern "C" long long stx_conv3d_fwd_stat_rows(int B, int Di, int Hi, int Wi, int Cin, int Cout, int ks, int stride) {
+    stx_begin();
+    if (B < 1 || Di < 1 || Hi < 1 || Wi < 1 || Cin < 1 || Cout < 1 || !((ks == 3 && (stride == 1 || stride == 2)) || (ks == 1 && stride == 1)))
+        return 0;
+    return conv_plan(B, Di, Hi, Wi, Cin, Cout, ks, stride).rows;
+}
+
 extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const float* scale, const float* bias,
                               const float* residual, float* stats, int B, int Di, int Hi, int Wi, int Cin, int Cout,
                               int ks, int stride, int relu, void* stream) {
@@ -1306,22 +1364,19 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     a.nDt = stx_cdiv(a.Do, CONV_TD); a.nHt = stx_cdiv(a.Ho, CONV_TH); a.nWt = stx_cdiv(a.Wo, 32);
     const int NT = conv_nt(Cout);
     hipStream_t st = (hipStream_t)stream;
-    // the slab has stx_conv3d_fwd_blocks() rows per batch item; rows no workgroup writes must read 0
-    if (stats) hipMemsetAsync(stats, 0, (size_t)B * stx_conv3d_fwd_blocks(a.Do, a.Ho, a.Wo) * 2 * Cout * 4, st);
+    const ConvPlan plan = conv_plan(B, Di, Hi, Wi, Cin, Cout, ks, stride);       // (the slab has plan.rows rows, all written)
     // March kernel (weights resident in LDS, input-stationary planes) for the 3x3x3 stride-1 layers in 32 x 32 channel
     // slices: 32 -> <=32 directly; 64 -> <=32 as two K slices (the second adds the first's partial sums and applies the
     // epilogue); 32 -> <=64 as two N slices (dgrad of the 64 -> 32 layer).
-    if (ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
+    if (plan.kind == 0) {
         MarchArgs m2;
         m2.c = a;
         m2.c.nHt = stx_cdiv(a.Ho, MW2_TH);
         m2.c.nWt = stx_cdiv(a.Wo, MW2_MW);
         m2.ncols = B * m2.c.nHt * m2.c.nWt;
         m2.ablate = stx_tune(STX_TUNE_MARCH_ABLATE);
-        // (planes are addressed through buffer descriptors with 32-bit byte offsets)
-        if ((long long)m2.ncols * a.Do < (1ll << 31) && (long long)Hi * Wi * Cin * 4 < (1ll << 31) &&
-            (long long)a.Ho * a.Wo * Cout * 4 < (1ll << 31)) {
-            const int nb2 = march_wgs((long long)m2.ncols * a.Do);
+        {
+            const int nb2 = plan.march_wgs;
             const size_t lds2 = ((size_t)MW2_WFLOATS + 2 * (size_t)MW2_SLOT) * 4;
             // STX_MARCH_BS: 1 = one accumulator per (output, input plane), summed in the epilogue; 0 = one sequential chain per
             // output (GPU call F of round 3, 32 -> 32 L0: 0.757 -> 0.767 ms).  STX_MARCH_EPI: 1 = straight-line epilogue for
@@ -1329,7 +1384,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
             const int bs = stx_tune(STX_TUNE_MARCH_BS), epi_fast = stx_tune(STX_TUNE_MARCH_EPI);
             void (*mk_gen)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<0, 1>;
             void (*mk_plain)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 0> : conv3d_marchw_kernel<0, 0>;
+            void (*mk_acc)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 2> : conv3d_marchw_kernel<0, 2>;
             hipFuncSetAttribute((const void*)mk_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipFuncSetAttribute((const void*)mk_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             void (*mk)(MarchArgs) = mk_gen;
             hipFuncSetAttribute((const void*)mk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             m2.xs = Cin; m2.os = Cout; m2.wq_total = Cin / 8; m2.wnt_total = conv_nt(Cout);
@@ -1343,8 +1400,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     if (kslice + 1 < nk) {      // partial sums only: raw accumulators to `out`, epilogue in the last slice
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
-                    const bool plain = epi_fast && !m.acc_in && !m.c.residual && m.c.relu != 2;
-                    hipLaunchKernelGGL(plain ? mk_plain : mk, dim3(nb2), dim3(256), lds2, st, m);
+                    // (the straight-line epilogues read the partial sums through the OUTPUT descriptor: acc_in is `out`)
+                    const bool plain = epi_fast && !m.c.residual && m.c.relu != 2;
+                    hipLaunchKernelGGL(plain ? (m.acc_in ? mk_acc : mk_plain) : mk, dim3(nb2), dim3(256), lds2, st, m);
                 }
             return stx_check_launch("conv3d_fwd(march)");
         }
@@ -1358,13 +1416,13 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     // 128 output channels: persistent software-pipelined kernel (its staging registers cost the second resident workgroup,
     // so it wins only there: measured at the 576x960 shapes 128->128 L2 0.283 -> 0.245 ms, stride-2 64->128 0.176 -> 0.154 ms,
     // but 64->64 L1 0.470 -> 0.537 ms, stride-2 32->64 0.327 -> 0.353 ms: round 2, profiles/r02_conv_ab.txt)
-    if (NT == 4 && ks == 3 && CK == 8) {
+    if (plan.kind == 1) {
         const long long nt_all = (long long)grid.x * B;
-        if (nt_all < (1ll << 31)) {
-            // the stats slab has stx_conv3d_fwd_blocks() rows per batch item and this kernel writes row blockIdx.x
+        {
+            // this kernel writes row blockIdx.x of the stats slab
             const size_t lds = stride == 1 ? conv_lds_bytes<3, 1>(8, 4) : conv_lds_bytes<3, 2>(8, 4);
-            rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all)
-                             : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all);
+            rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all, plan.pgrid)
+                             : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all, plan.pgrid);
             if (rc) return rc;
             return stx_check_launch("conv3d_fwd(pipelined)");
         }

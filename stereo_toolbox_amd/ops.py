@@ -188,8 +188,8 @@ def conv3d_forward(x, wp, Cout, ks, stride, scale=None, bias=None, residual=None
     out = torch.empty(B, Do, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     stats = None
     if want_stats:
-        nb = get_lib().raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
-        stats = torch.empty(B * nb, 2, Cout, dtype=torch.float32, device=x.device)
+        rows = get_lib().raw("stx_conv3d_fwd_stat_rows")(B, D, H, W, Cin, Cout, ks, stride)   # (exactly the rows the launch writes)
+        stats = torch.empty(rows, 2, Cout, dtype=torch.float32, device=x.device)
     _call("stx_conv3d_fwd", _p(x), _p(wp), _p(out), _p(scale), _p(bias), _p(residual), _p(stats), B, D, H, W, Cin,
           Cout, ks, stride, int(relu))
     return out, stats

@@ -48,7 +48,7 @@ def test_run_to_run_bitwise_reproducibility(be):
         wp = pack(be, torch.randn(Cout, Cin, ks, ks, ks) * 0.1, 0)
         pad = ks // 2
         Do, Ho, Wo = [(d + 2 * pad - ks) // s + 1 for d in (Dv, Hv, Wv)]
-        nb = be.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+        nb = be.raw("stx_conv3d_fwd_stat_rows")(1, Dv, Hv, Wv, Cin, Cout, ks, s)
         _twice(be, lambda o: be.call("stx_conv3d_fwd", ptr(x), ptr(wp), ptr(o[0]), None, None, None, ptr(o[1]), 1, Dv, Hv, Wv,
                                      Cin, Cout, ks, s, 0),
                lambda: [be.empty(1, Do, Ho, Wo, Cout), be.empty(nb, 2, Cout)])

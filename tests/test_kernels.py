@@ -310,8 +310,9 @@ def run_conv(be, x, w, ks, stride, scale=None, bias=None, res=None, relu=0, stat
     pad = ks // 2
     Do, Ho, Wo = [(d + 2 * pad - ks) // stride + 1 for d in (D, H, W)]
     out = be.empty(B, Do, Ho, Wo, Cout)
-    nb = be.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
-    st = be.empty(B * nb, 2, Cout) if stats else None
+    rows = be.raw("stx_conv3d_fwd_stat_rows")(B, D, H, W, Cin, Cout, ks, stride)
+    assert 0 < rows <= B * be.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
+    st = be.empty(rows, 2, Cout).fill_(float("nan")) if stats else None       # (every row must be written)
     xl = be.dev(ndhwc(x))
     rl = be.dev(ndhwc(res)) if res is not None else None
     be.call("stx_conv3d_fwd", ptr(xl), ptr(wp), ptr(out), ptr(be.dev(scale)), ptr(be.dev(bias)), ptr(rl), ptr(st),

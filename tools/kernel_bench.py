@@ -164,8 +164,7 @@ def run_table(a, only_arg, only_exact=False):
         wp = pack(w, 0)
         Do, Ho, Wo = [(d + 2 * (ks // 2) - ks) // s + 1 for d in (D, Hh, Ww)]
         out = torch.empty(B, Do, Ho, Wo, Cout, device=dev)
-        nblk = lib.raw("stx_conv3d_fwd_blocks")(Do, Ho, Wo)
-        st = torch.empty(B * nblk, 2, Cout, device=dev)
+        st = torch.empty(lib.raw("stx_conv3d_fwd_stat_rows")(B, D, Hh, Ww, Cin, Cout, ks, s), 2, Cout, device=dev)
         fl = 2.0 * B * Do * Ho * Wo * Cout * Cin * ks ** 3
         if want(name + "_fwd"):
             ms = timeit(lambda: lib.call("stx_conv3d_fwd", P(x), P(wp), P(out), None, None, None, P(st), B, D, Hh, Ww,
@@ -216,7 +215,7 @@ def run_table(a, only_arg, only_exact=False):
         sc, sh = torch.rand(C, device=dev), torch.rand(C, device=dev)
         ms = timeit(lambda: lib.call("stx_bn_apply", P(z), P(sc), P(sh), None, None, None, P(y), nvox, C, 1, 1, stream()), it)
         report("bn_apply_L0", ms, nbytes=z.numel() * 8)
-        nrows = lib.raw("stx_conv3d_fwd_blocks")(D, Hh, Ww) * B
+        nrows = lib.raw("stx_conv3d_fwd_stat_rows")(B, D, Hh, Ww, C, C, 3, 1)
         fpart = torch.randn(nrows, 2, C, device=dev)
         fo = [torch.empty(C, device=dev) for _ in range(6)]
         ms = timeit(lambda: lib.call("stx_bn_finalize", P(fpart), nrows, C, float(nvox), P(sc), P(sh), P(fo[4]), P(fo[5]),

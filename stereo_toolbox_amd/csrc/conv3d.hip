@@ -513,7 +513,8 @@ constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed we
 // zeros to the BN sums.  EPI = 2 is the same with the partial sums of an earlier K slice added (second half of a 64 -> 32
 // layer: its 16 values per lane are loaded through the same descriptor at the START of the step, nine taps before the first
 // is needed -- the general epilogue waited for each of them with s_waitcnt vmcnt(0): 1.10 vs 0.70 ms per launch in the
-// step trace of GPU call N).  EPI = 1 is the general epilogue.  The plane staging loads go through a descriptor of the input
+// step trace of GPU call N); EPI = 3 the same with a residual added behind the affine (inference: dres1's second conv).
+// EPI = 1 is the general epilogue (partial sums AND residual, Mish).  The plane staging loads go through a descriptor of the input
 // plane the same way for both (offsets precomputed per column; halo voxels outside the volume and planes outside [0, Di)
 // read zeros through the bounds check: no address clamps, no branches).
 template <int BS, int EPI = 1>
@@ -608,11 +609,11 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     // finished plane (zero when there is none), `ors` = descriptor of that output plane
     const bool relu_on = a.relu == 1;
     float accp[16];                                                  // EPI = 2: partial sums of the earlier K slice (rows of plane p-1)
-    auto load_partials = [&](unsigned vmask, const stx_bufrsrc& ors) {
+    auto load_partials = [&](unsigned vmask, const stx_bufrsrc& rs) {      // (EPI = 3: the residual rows instead)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
-            accp[r] = stx_buf_ld1(ors, ((vmask >> r) & 1u) ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4));
+            accp[r] = stx_buf_ld1(rs, ((vmask >> r) & 1u) ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4));
         }
     };
     auto emit_row_plain = [&](const f32x16& done0, const f32x16& done1, const f32x16& done, int r, unsigned vmask,
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         s1 += v;
         s2 = fmaf(v, v, s2);
         v = fmaf(v, sc, bs);
+        if (EPI == 3) v += accp[r];
         const float vr = fmaxf(v, 0.f);
         v = relu_on ? vr : v;
         stx_buf_st1(ors, ok ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4), v);
@@ -689,6 +691,9 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         const stx_bufrsrc ors = stx_make_rsrc(a.out + ((size_t)b * a.Do + (st_on ? p - 1 : 0)) * a.Ho * a.Wo * ma.os,
                                               st_on ? oplane_bytes : 0u);
         if (EPI == 2) load_partials(vmask, ors);                     // (acc_in == out: the rows this step finishes, read before written)
+        if (EPI == 3)
+            load_partials(vmask, stx_make_rsrc(a.residual + ((size_t)b * a.Do + (st_on ? p - 1 : 0)) * a.Ho * a.Wo * ma.os,
+                                               st_on ? oplane_bytes : 0u));
         if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, -1, 0u, ors);
         // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
         // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
@@ -1385,6 +1390,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
             void (*mk_gen)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 1> : conv3d_marchw_kernel<0, 1>;
             void (*mk_plain)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 0> : conv3d_marchw_kernel<0, 0>;
             void (*mk_acc)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 2> : conv3d_marchw_kernel<0, 2>;
+            void (*mk_res)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 3> : conv3d_marchw_kernel<0, 3>;
+            hipFuncSetAttribute((const void*)mk_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             void (*mk)(MarchArgs) = mk_gen;
@@ -1401,8 +1408,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
                     // (the straight-line epilogues read the partial sums through the OUTPUT descriptor: acc_in is `out`)
-                    const bool plain = epi_fast && !m.c.residual && m.c.relu != 2;
-                    hipLaunchKernelGGL(plain ? (m.acc_in ? mk_acc : mk_plain) : mk, dim3(nb2), dim3(256), lds2, st, m);
+                    const bool plain = epi_fast && !(m.c.residual && m.acc_in) && m.c.relu != 2;
+                    hipLaunchKernelGGL(plain ? (m.acc_in ? mk_acc : (m.c.residual ? mk_res : mk_plain)) : mk, dim3(nb2), dim3(256),
+                                       lds2, st, m);
                 }
             return stx_check_launch("conv3d_fwd(march)");
         }

@@ -848,7 +848,8 @@ def test_conv3d_march_epilogues_agree(be, tune):
             tune("STX_MARCH_EPI", epi)
             raw, st = run_conv(be, x, w, 3, 1, stats=True)
             act, _ = run_conv(be, x, w, 3, 1, sc, bs, None, 1)
-            outs.append((raw, st, act))
+            res, _ = run_conv(be, x, w, 3, 1, sc, bs, torch.randn(B, Cout, D, H, W, generator=torch.Generator().manual_seed(3)), 1)
+            outs.append((raw, st, act, res))
         for a_, b_ in zip(*outs):
             assert torch.equal(a_, b_)
 

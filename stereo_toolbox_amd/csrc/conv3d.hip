@@ -160,6 +160,65 @@ __device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[
     }
 }
 
+// The 27 taps of one K chunk of the implicit-GEMM kernels (3x3x3).  A operands come from the LDS halo tile one tap ahead; the
+// packed weights (B) come from L2 and are kept TWO taps ahead in a ring of three register sets that runs on across the chunks
+// (27 = 0 mod 3: tap t always lives in set t % 3; the last two taps of a chunk prefetch the first two of the next from
+// `wq_next`).  One tap is 4 MT NT NQC MFMAs = 0.2-0.4 us of matrix work per wave, an L2 round trip 0.5-0.8 us: with the weights
+// only one tap ahead (rounds 1-2) every tap ended in an s_waitcnt that the two or three other waves of the SIMD could not
+// always cover -- these kernels sat at 0.47-0.71 of the MFMA peak while the weights-in-LDS march kernel reached 0.84.
+template <int S, int MT, int NT, int NQC, int EH, int EWS, int EWH, int VS>
+__device__ __forceinline__ void conv_chunk_taps27(const float* tile, const int (&abase)[MT], const float* wq, const float* wq_next,
+                                                  int NQ, f32x16 (&acc)[MT][NT], float4 (&bq)[3][NQC][NT]) {
+    constexpr int T = 27;
+    float4 av[2][NQC][MT];
+    auto load_a = [&](int tap, int buf) {
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS : ((kd * EH + kh) * EWS + kw) * VS;
+#pragma unroll
+        for (int q = 0; q < NQC; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[buf][q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
+    };
+    auto load_b = [&](const float* w, int tap, int slot) {
+        const float* wtap = w + (size_t)tap * NQ * NT * 256;
+#pragma unroll
+        for (int q = 0; q < NQC; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[slot][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+    };
+    load_a(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+        if (tap + 2 < T) load_b(wq, tap + 2, (tap + 2) % 3);
+        else if (wq_next) load_b(wq_next, tap + 2 - T, (tap + 2) % 3);           // (wave-uniform)
+        if (tap + 1 < T) load_a(tap + 1, (tap + 1) & 1);
+        STX_SCHED_BARRIER();
+        const int cb = tap & 1, sb = tap % 3;
+#pragma unroll
+        for (int q = 0; q < NQC; ++q)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q][m].x, bq[sb][q][nt].x, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q][m].y, bq[sb][q][nt].y, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q][m].z, bq[sb][q][nt].z, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q][m].w, bq[sb][q][nt].w, acc[m][nt], 0, 0, 0);
+                }
+        STX_SCHED_BARRIER();
+    }
+}
+// the ring's first two sets (taps 0 and 1 of a kernel's first chunk)
+template <int NT, int NQC>
+__device__ __forceinline__ void conv_ring_prologue(const float* wq, int NQ, float4 (&bq)[3][NQC][NT]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < NQC; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[t][q][nt] = stx_ld4(wq + (size_t)t * NQ * NT * 256 + (size_t)(q * NT + nt) * 256);
+}
+
 // ------------------------------------------------------------------------------------------
 // Direct convolution, kernel KS^3 (pad KS/2), stride S.
 // VPAD: LDS padding per staged voxel in floats (4 = conflict-free operand reads; 0 = the opt-in dense layout of the
@@ -214,6 +273,8 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
     float4 stg[NST];
 #pragma unroll
     for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, vo[k], 0u);
+    float4 bring[3][NQC][NT];                        // packed weights, two taps ahead (3x3x3: conv_chunk_taps27)
+    if constexpr (KS == 3) conv_ring_prologue<NT, NQC>(a.wp + (size_t)lane * 4, NQ, bring);
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();                             // every wave is done reading the previous chunk's tile
@@ -232,46 +293,47 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
 #pragma unroll
             for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
         }
-        // Both operands are register double-buffered one tap ahead (A from the LDS tile, B = packed
-        // weights from L2); the scheduling fences keep "issue next tap's loads, then this tap's
-        // MFMAs" -- otherwise hipcc sinks the loads next to their use and every tap eats an L2 round trip.
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        float4 bcur[NQC][NT], bnxt[NQC][NT], acur[NQC][MT], anxt[NQC][MT];
-        auto load_tap = [&](int tap, float4 (&av)[NQC][MT], float4 (&bv)[NQC][NT]) {
-            const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-            const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
-                                      : ((kd * EH + kh) * EWS + kw) * VS;
-            const float* wtap = wq + (size_t)tap * NQ * NT * 256;
+        if constexpr (KS == 3) {
+            conv_chunk_taps27<S, MT, NT, NQC, EH, EWS, EWH, VS>(tile, abase, wq, c0 + CK < a.Cin ? wq + (size_t)NQC * NT * 256 : nullptr,
+                                                               NQ, acc, bring);
+        } else {
+            // 1x1x1: both operands one step ahead in registers (A from the LDS tile, B = packed weights from L2); the
+            // scheduling fences keep "issue the next loads, then this step's MFMAs"
+            float4 bcur[NQC][NT], bnxt[NQC][NT], acur[NQC][MT], anxt[NQC][MT];
+            auto load_tap = [&](int tap, float4 (&av)[NQC][MT], float4 (&bv)[NQC][NT]) {
+                const float* wtap = wq + (size_t)tap * NQ * NT * 256;
 #pragma unroll
-            for (int q = 0; q < NQC; ++q) {
+                for (int q = 0; q < NQC; ++q) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+                    for (int nt = 0; nt < NT; ++nt) bv[q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
-            }
-        };
-        load_tap(0, acur, bcur);
-        for (int tap = 0; tap < T; ++tap) {
-            if (tap + 1 < T) load_tap(tap + 1, anxt, bnxt);
-            STX_SCHED_BARRIER();
+                    for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + q * 8);
+                }
+            };
+            load_tap(0, acur, bcur);
+            for (int tap = 0; tap < T; ++tap) {
+                if (tap + 1 < T) load_tap(tap + 1, anxt, bnxt);
+                STX_SCHED_BARRIER();
 #pragma unroll
-            for (int q = 0; q < NQC; ++q)
+                for (int q = 0; q < NQC; ++q)
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
-                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
-                    }
-            STX_SCHED_BARRIER();
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
+                        }
+                STX_SCHED_BARRIER();
 #pragma unroll
-            for (int q = 0; q < NQC; ++q) {
+                for (int q = 0; q < NQC; ++q) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
+                    for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) acur[q][m] = anxt[q][m];
+                    for (int m = 0; m < MT; ++m) acur[q][m] = anxt[q][m];
+                }
             }
         }
     }
@@ -377,7 +439,12 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
     f32x16 acc[MT][NT];
-    if (t_lo < t_hi) load_item(t_lo, 0);
+    float4 bring[3][NQC][NT];                        // packed weights, two taps ahead (conv_chunk_taps27)
+    static_assert(KS == 3, "the pipelined kernel serves 3x3x3 only");
+    if (t_lo < t_hi) {
+        load_item(t_lo, 0);
+        conv_ring_prologue<NT, NQC>(a.wp + (size_t)lane * 4, NQ, bring);
+    }
     for (int t = t_lo; t < t_hi; ++t) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -393,44 +460,9 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
                 if (ntl < t_hi) load_item(ntl, nch * CK);
             }
             const float* wq = a.wp + ((size_t)(ch * (CK / 8)) * NT * 64 + lane) * 4;
-            float4 bcur[NQC][NT], bnxt[NQC][NT], acur[NQC][MT], anxt[NQC][MT];
-            auto load_tap = [&](int tap, float4 (&av)[NQC][MT], float4 (&bv)[NQC][NT]) {
-                const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-                const int toff = (S == 2) ? ((kd * EH + kh) * EWS + (kw & 1) * EWH + (kw >> 1)) * VS
-                                          : ((kd * EH + kh) * EWS + kw) * VS;
-                const float* wtap = wq + (size_t)tap * NQ * NT * 256;
-#pragma unroll
-                for (int q = 0; q < NQC; ++q) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) av[q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
-                }
-            };
-            load_tap(0, acur, bcur);
-            for (int tap = 0; tap < T; ++tap) {
-                if (tap + 1 < T) load_tap(tap + 1, anxt, bnxt);
-                STX_SCHED_BARRIER();
-#pragma unroll
-                for (int q = 0; q < NQC; ++q)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].x, bcur[q][nt].x, acc[m][nt], 0, 0, 0);
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].y, bcur[q][nt].y, acc[m][nt], 0, 0, 0);
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].z, bcur[q][nt].z, acc[m][nt], 0, 0, 0);
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[q][m].w, bcur[q][nt].w, acc[m][nt], 0, 0, 0);
-                        }
-                STX_SCHED_BARRIER();
-#pragma unroll
-                for (int q = 0; q < NQC; ++q) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bcur[q][nt] = bnxt[q][nt];
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) acur[q][m] = anxt[q][m];
-                }
-            }
+            // (the weight ring runs on across chunks AND tiles: behind a tile's last chunk come the first taps of chunk 0)
+            const float* wq_next = ch + 1 < nchunk ? wq + (size_t)NQC * NT * 256 : (t + 1 < t_hi ? a.wp + (size_t)lane * 4 : nullptr);
+            conv_chunk_taps27<S, MT, NT, NQC, EH, EWS, EWH, VS>(tile, abase, wq, wq_next, NQ, acc, bring);
         }
         int b, od0, oh0, ow0;
         tile_origin(t, b, od0, oh0, ow0);
@@ -819,48 +851,67 @@ constexpr DcEntries dc_entries(int cset) {
     return e;
 }
 
-// One K chunk of the transposed convolution for a wave: the work list above as straight-line code, the weight operands
-// of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The first version walked
-// the classes and taps in a loop nest with run-time bounds; hipcc kept it rolled and waited for each tap's loads right
-// before its first MFMA, an L2 round trip per 16 MFMAs: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes, GPU
-// call O of round 2.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower:
-// calls Q-T of round 2, call G of round 3.)
+// One K chunk of the transposed convolution for a wave: the work list above as straight-line code.  An entry is only
+// 4 * CK/8 * NT MFMAs (0.1-0.2 us), an L2 round trip for its packed weights 0.5-0.8 us: the weights run SIX entries ahead in a
+// ring of seven register sets that continues across the K chunks (the list is padded to 14 entries, 14 = 0 mod 7, so entry t
+// always lives in set t % 7; the last six entries of a chunk prefetch the first six of the next from `wq_next`).
+// (History: the first version walked classes and taps in a rolled loop nest and waited for each tap's loads right before its
+//  first MFMA: 0.45 / 0.33 of the fp32-MFMA peak, GPU call O of round 2; straight-line code with the weights ONE entry ahead:
+//  0.52-0.59, rounds 2-3.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower.)
+constexpr int DC_RING = 7, DC_PAD = 14;
 template <int CSET, int NT, int CK>
-__device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
+__device__ __forceinline__ void deconv_ring_prologue(const float* wq, int NQ, float4 (&bq)[DC_RING][CK / 8][NT]) {
     constexpr DcEntries E = dc_entries(CSET);
-    constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8;
-    float4 bv[2][QS][NT], av[2][QS];
-    auto load_b = [&](int t, int buf) {
-        const float* wtap = wq + (size_t)E.tap[t] * NQ * NT * 256;
+#pragma unroll
+    for (int t = 0; t < DC_RING - 1; ++t)
+#pragma unroll
+        for (int q = 0; q < CK / 8; ++q)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bq[t][q][nt] = stx_ld4(wq + (size_t)E.tap[t] * NQ * NT * 256 + (size_t)(q * NT + nt) * 256);
+}
+template <int CSET, int NT, int CK>
+__device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, const float* wq_next, int NQ,
+                                                  f32x16 (&acc)[4][NT], float4 (&bq)[DC_RING][CK / 8][NT]) {
+    constexpr DcEntries E = dc_entries(CSET);
+    constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8, PF = DC_RING - 1;
+    static_assert(DC_PAD % DC_RING == 0 && PF < 13, "ring / list geometry");
+    float4 av[2][QS];
+    auto load_b = [&](const float* w, int t, int slot) {
+        const float* wtap = w + (size_t)E.tap[t] * NQ * NT * 256;
 #pragma unroll
         for (int q = 0; q < QS; ++q)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[buf][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+            for (int nt = 0; nt < NT; ++nt) bq[slot][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
     };
     auto load_a = [&](int t, int buf) {
         const int toff = ((E.dd[t] * EH + E.dh[t]) * EW + E.dw[t]) * VS;
 #pragma unroll
         for (int q = 0; q < QS; ++q) av[buf][q] = stx_ld4(atile + toff + q * 8);
     };
-    load_b(0, 0);
 #pragma unroll
-    for (int t = 0; t < E.n; ++t) {
-        if (t + 1 < E.n) load_b(t + 1, (t + 1) & 1);
-        STX_SCHED_BARRIER();
-        load_a(t, t & 1);
+    for (int t = 0; t < DC_PAD; ++t) {
+        // entry t + PF of the flattened (chunk, padded entry) sequence; pad entries (t >= E.n) carry no work
+        const int tf = t + PF;
+        if (tf < DC_PAD) { if (tf < E.n) load_b(wq, tf, tf % DC_RING); }
+        else if (tf - DC_PAD < E.n) { if (wq_next) load_b(wq_next, tf - DC_PAD, tf % DC_RING); }     // (wave-uniform)
+        if (t < E.n) {
+            STX_SCHED_BARRIER();
+            load_a(t, t & 1);
 #pragma unroll
-        for (int q = 0; q < QS; ++q) {
-            const float4 a4 = av[t & 1][q];
+            for (int q = 0; q < QS; ++q) {
+                const float4 a4 = av[t & 1][q];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 b = bv[t & 1][q][nt];
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
-                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b = bq[t % DC_RING][q][nt];
+                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
+                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
+                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
+                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
+                }
             }
+            STX_SCHED_BARRIER();
         }
-        STX_SCHED_BARRIER();
     }
 }
 
@@ -902,6 +953,9 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
     float4 val[NST];                                 // the next K chunk's tile: in flight during this chunk's taps
 #pragma unroll
     for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, vo[k], 0u);
+    float4 bring[DC_RING][CK / 8][NT];               // packed weights, six entries ahead
+    if (cset == 0) deconv_ring_prologue<0, NT, CK>(a.wp + (size_t)lane * 4, NQ, bring);
+    else deconv_ring_prologue<1, NT, CK>(a.wp + (size_t)lane * 4, NQ, bring);
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
 #pragma unroll
@@ -918,8 +972,9 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
             for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
         }
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
-        else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
+        const float* wq_next = c0 + CK < a.Cin ? wq + (size_t)(CK / 8) * NT * 256 : nullptr;
+        if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, wq_next, NQ, acc, bring);
+        else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, wq_next, NQ, acc, bring);
     }
 
     float s1[NT], s2[NT];

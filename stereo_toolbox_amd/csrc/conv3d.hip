@@ -851,67 +851,49 @@ constexpr DcEntries dc_entries(int cset) {
     return e;
 }
 
-// One K chunk of the transposed convolution for a wave: the work list above as straight-line code.  An entry is only
-// 4 * CK/8 * NT MFMAs (0.1-0.2 us), an L2 round trip for its packed weights 0.5-0.8 us: the weights run SIX entries ahead in a
-// ring of seven register sets that continues across the K chunks (the list is padded to 14 entries, 14 = 0 mod 7, so entry t
-// always lives in set t % 7; the last six entries of a chunk prefetch the first six of the next from `wq_next`).
-// (History: the first version walked classes and taps in a rolled loop nest and waited for each tap's loads right before its
-//  first MFMA: 0.45 / 0.33 of the fp32-MFMA peak, GPU call O of round 2; straight-line code with the weights ONE entry ahead:
-//  0.52-0.59, rounds 2-3.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower.)
-constexpr int DC_RING = 7, DC_PAD = 14;
+// One K chunk of the transposed convolution for a wave: the work list above as straight-line code, the weight operands
+// of entry t+1 in flight (second register buffer) during the 4 * CK/8 * NT MFMAs of entry t.  (The first version walked
+// the classes and taps in a loop nest with run-time bounds; hipcc kept it rolled and waited for each tap's loads right
+// before its first MFMA, an L2 round trip per 16 MFMAs: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes, GPU
+// call O of round 2.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower:
+// calls Q-T of round 2, call G of round 3; the weights SIX entries ahead in a ring of seven register sets that runs on
+// across the K chunks: 0.138 / 0.245 -> 0.141 / 0.252 ms, call R of round 3 -- no gain, removed.)
 template <int CSET, int NT, int CK>
-__device__ __forceinline__ void deconv_ring_prologue(const float* wq, int NQ, float4 (&bq)[DC_RING][CK / 8][NT]) {
+__device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
     constexpr DcEntries E = dc_entries(CSET);
-#pragma unroll
-    for (int t = 0; t < DC_RING - 1; ++t)
-#pragma unroll
-        for (int q = 0; q < CK / 8; ++q)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                bq[t][q][nt] = stx_ld4(wq + (size_t)E.tap[t] * NQ * NT * 256 + (size_t)(q * NT + nt) * 256);
-}
-template <int CSET, int NT, int CK>
-__device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, const float* wq_next, int NQ,
-                                                  f32x16 (&acc)[4][NT], float4 (&bq)[DC_RING][CK / 8][NT]) {
-    constexpr DcEntries E = dc_entries(CSET);
-    constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8, PF = DC_RING - 1;
-    static_assert(DC_PAD % DC_RING == 0 && PF < 13, "ring / list geometry");
-    float4 av[2][QS];
-    auto load_b = [&](const float* w, int t, int slot) {
-        const float* wtap = w + (size_t)E.tap[t] * NQ * NT * 256;
+    constexpr int EH = 3, EW = 33, VS = CK + 4, QS = CK / 8;
+    float4 bv[2][QS][NT], av[2][QS];
+    auto load_b = [&](int t, int buf) {
+        const float* wtap = wq + (size_t)E.tap[t] * NQ * NT * 256;
 #pragma unroll
         for (int q = 0; q < QS; ++q)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[slot][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+            for (int nt = 0; nt < NT; ++nt) bv[buf][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
     };
     auto load_a = [&](int t, int buf) {
         const int toff = ((E.dd[t] * EH + E.dh[t]) * EW + E.dw[t]) * VS;
 #pragma unroll
         for (int q = 0; q < QS; ++q) av[buf][q] = stx_ld4(atile + toff + q * 8);
     };
+    load_b(0, 0);
 #pragma unroll
-    for (int t = 0; t < DC_PAD; ++t) {
-        // entry t + PF of the flattened (chunk, padded entry) sequence; pad entries (t >= E.n) carry no work
-        const int tf = t + PF;
-        if (tf < DC_PAD) { if (tf < E.n) load_b(wq, tf, tf % DC_RING); }
-        else if (tf - DC_PAD < E.n) { if (wq_next) load_b(wq_next, tf - DC_PAD, tf % DC_RING); }     // (wave-uniform)
-        if (t < E.n) {
-            STX_SCHED_BARRIER();
-            load_a(t, t & 1);
+    for (int t = 0; t < E.n; ++t) {
+        if (t + 1 < E.n) load_b(t + 1, (t + 1) & 1);
+        STX_SCHED_BARRIER();
+        load_a(t, t & 1);
 #pragma unroll
-            for (int q = 0; q < QS; ++q) {
-                const float4 a4 = av[t & 1][q];
+        for (int q = 0; q < QS; ++q) {
+            const float4 a4 = av[t & 1][q];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b = bq[t % DC_RING][q][nt];
-                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
-                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
-                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
-                    acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const float4 b = bv[t & 1][q][nt];
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b.x, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b.y, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b.z, acc[E.slot[t]][nt], 0, 0, 0);
+                acc[E.slot[t]][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b.w, acc[E.slot[t]][nt], 0, 0, 0);
             }
-            STX_SCHED_BARRIER();
         }
+        STX_SCHED_BARRIER();
     }
 }
 
@@ -953,9 +935,6 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
     float4 val[NST];                                 // the next K chunk's tile: in flight during this chunk's taps
 #pragma unroll
     for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, vo[k], 0u);
-    float4 bring[DC_RING][CK / 8][NT];               // packed weights, six entries ahead
-    if (cset == 0) deconv_ring_prologue<0, NT, CK>(a.wp + (size_t)lane * 4, NQ, bring);
-    else deconv_ring_prologue<1, NT, CK>(a.wp + (size_t)lane * 4, NQ, bring);
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();
 #pragma unroll
@@ -972,9 +951,8 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_
             for (int k = 0; k < NST; ++k) val[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
         }
         const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
-        const float* wq_next = c0 + CK < a.Cin ? wq + (size_t)(CK / 8) * NT * 256 : nullptr;
-        if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, wq_next, NQ, acc, bring);
-        else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, wq_next, NQ, acc, bring);
+        if (cset == 0) deconv_chunk_taps<0, NT, CK>(tile + abase, wq, NQ, acc);
+        else deconv_chunk_taps<1, NT, CK>(tile + abase, wq, NQ, acc);
     }
 
     float s1[NT], s2[NT];

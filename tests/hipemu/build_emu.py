@@ -13,7 +13,7 @@ CSRC = os.path.join(ROOT, "stereo_toolbox_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libstx_emu.so")
 CXX = os.environ.get("STX_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DSTX_HIPEMU", "-ffp-contract=off",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-pthread", "-DSTX_HIPEMU", "-ffp-contract=off",
          "-Wno-unused-value", "-Wno-deprecated-declarations", "-I", HERE, "-I", CSRC]
 
 
@@ -59,7 +59,7 @@ def build_emu(force=False, verbose=False, asan=None):
         with ThreadPoolExecutor(max_workers=8) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([CXX, "-shared", "-fPIC", *(["-fsanitize=address", "-shared-libsan"] if asan else []), *objs, "-o", LIB])
+        run([CXX, "-shared", "-fPIC", "-pthread", *(["-fsanitize=address", "-shared-libsan"] if asan else []), *objs, "-o", LIB])
     return LIB
 
 

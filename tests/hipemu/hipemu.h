@@ -6,7 +6,9 @@
 // LDS tiling, barriers and the MFMA fragment layouts can be validated against
 // the oracle in this GPU-less container before GPU minutes are spent.
 //
-//  * every GPU thread is a ucontext fiber; one workgroup runs at a time;
+//  * every GPU thread is a fiber; a workgroup runs on one host thread, up to STX_EMU_THREADS (default: the host's
+//    cores, at most 8) workgroups of a launch run concurrently on their own host threads (workgroups of these kernels
+//    never wait for each other; global atomics are real atomics);
 //  * __syncthreads() / wave collectives (shuffles, MFMA) are rendezvous points;
 //  * MFMA lane layouts follow /opt/skills/guides/cdna_hip_programming.md §3
 //    (32x32x2f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
@@ -22,14 +24,17 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
+#include <sys/mman.h>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local          // (one workgroup per host thread at a time)
 
 struct dim3 {
     unsigned x, y, z;
@@ -66,7 +71,8 @@ struct Fiber {
 struct State {
     void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
-    std::vector<char> stacks;
+    char* stacks = nullptr;            // mmap'ed lazily-committed fiber stacks (grow-only)
+    size_t stacks_bytes = 0;
     unsigned nthreads = 0;
     unsigned cur = 0;
     // block barrier
@@ -77,8 +83,9 @@ struct State {
     float slot[64][64][4];
     std::vector<char> dyn;
     void (*entry)() = nullptr;
+    ~State() { if (stacks) munmap(stacks, stacks_bytes); }
 };
-inline State& S() { static State s; return s; }
+inline State& S() { static thread_local State s; return s; }
 
 extern "C" inline void hipemu_trampoline() {
     State& s = S();
@@ -99,8 +106,8 @@ inline char* dyn_smem() { return S().dyn.data(); }
 }  // namespace hipemu
 
 // The scheduler refreshes these on every fiber switch.
-inline uint3_emu threadIdx, blockIdx;
-inline dim3 blockDim, gridDim;
+inline thread_local uint3_emu threadIdx, blockIdx;
+inline thread_local dim3 blockDim, gridDim;
 
 static inline void __syncthreads() {
     hipemu::State& s = hipemu::S();
@@ -210,9 +217,19 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_4x4x1f32(float a, float b, 
     return c;
 }
 
-static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
-static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
-static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) {
+    unsigned* q = reinterpret_cast<unsigned*>(p);
+    unsigned o = __atomic_load_n(q, __ATOMIC_RELAXED), n;
+    float of;
+    do {
+        memcpy(&of, &o, 4);
+        const float nf = of + v;
+        memcpy(&n, &nf, 4);
+    } while (!__atomic_compare_exchange_n(q, &o, n, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return of;
+}
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
@@ -227,53 +244,94 @@ struct Thunk {
 };
 template <typename F> F* Thunk<F>::f = nullptr;
 
-template <typename F>
-inline void run_grid(dim3 grid, dim3 block, size_t shmem, F body) {
+inline unsigned host_threads() {
+    static const unsigned n = [] {
+        const char* e = getenv("STX_EMU_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        if (!e && v > 8) v = 8;
+        return v < 1 ? 1u : v;
+    }();
+    return n;
+}
+
+// one workgroup on the calling host thread
+inline void run_block(dim3 grid, dim3 block, size_t shmem, void (*entry)(), unsigned bx, unsigned by, unsigned bz) {
     State& s = S();
     const unsigned nt = block.x * block.y * block.z;
     const size_t STK = 256 * 1024;
-    if (nt > 1024) { fprintf(stderr, "hipemu: block too large\n"); abort(); }
-    if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of dynamic LDS exceeds the 160 KiB of a gfx950 CU\n", shmem); abort(); }
     s.nthreads = nt;
     if (s.fibers.size() < nt) s.fibers.resize(nt);
-    if (s.stacks.size() < nt * STK) s.stacks.resize(nt * STK);
+    if (s.stacks_bytes < nt * STK) {
+        if (s.stacks) munmap(s.stacks, s.stacks_bytes);
+        s.stacks_bytes = nt * STK;
+        s.stacks = (char*)mmap(nullptr, s.stacks_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (s.stacks == (char*)MAP_FAILED) { fprintf(stderr, "hipemu: mmap of fiber stacks failed\n"); abort(); }
+    }
     s.dyn.assign(shmem + 64, 0);
-    Thunk<F>::f = &body;
-    s.entry = &Thunk<F>::run;
+    s.entry = entry;
     blockDim = block;
     gridDim = grid;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
-        s.bar_count = 0; s.live = nt;
-        memset(s.wave_count, 0, sizeof(s.wave_count));
+    s.bar_count = 0; s.live = nt;
+    memset(s.wave_count, 0, sizeof(s.wave_count));
+    for (unsigned t = 0; t < nt; ++t) {
+        Fiber& f = s.fibers[t];
+        f.done = false; f.tid = t;
+        uintptr_t top = (uintptr_t)(s.stacks + (size_t)(t + 1) * STK);
+        top &= ~(uintptr_t)15;
+        void** sp = (void**)top;
+        *--sp = nullptr;                              // fake return address of the trampoline
+        *--sp = (void*)hipemu_trampoline;             // popped by hipemu_switch's `ret`
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
+        f.sp = (void*)sp;
+    }
+    unsigned remaining = nt;
+    while (remaining) {
+        remaining = 0;
         for (unsigned t = 0; t < nt; ++t) {
             Fiber& f = s.fibers[t];
-            f.done = false; f.tid = t;
-            uintptr_t top = (uintptr_t)(s.stacks.data() + (size_t)(t + 1) * STK);
-            top &= ~(uintptr_t)15;
-            void** sp = (void**)top;
-            *--sp = nullptr;                              // fake return address of the trampoline
-            *--sp = (void*)hipemu_trampoline;             // popped by hipemu_switch's `ret`
-            for (int r = 0; r < 6; ++r) *--sp = nullptr;  // rbp rbx r12 r13 r14 r15
-            f.sp = (void*)sp;
-        }
-        unsigned remaining = nt;
-        while (remaining) {
-            remaining = 0;
-            for (unsigned t = 0; t < nt; ++t) {
-                Fiber& f = s.fibers[t];
-                if (f.done) continue;
-                s.cur = t;
-                threadIdx.x = t % block.x;
-                threadIdx.y = (t / block.x) % block.y;
-                threadIdx.z = t / (block.x * block.y);
-                blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
-                hipemu_switch(&s.sched_sp, f.sp);
-                if (!f.done) remaining++;
-            }
+            if (f.done) continue;
+            s.cur = t;
+            threadIdx.x = t % block.x;
+            threadIdx.y = (t / block.x) % block.y;
+            threadIdx.z = t / (block.x * block.y);
+            blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
+            hipemu_switch(&s.sched_sp, f.sp);
+            if (!f.done) remaining++;
         }
     }
+}
+
+template <typename F>
+inline void run_grid(dim3 grid, dim3 block, size_t shmem, F body) {
+    const unsigned nt = block.x * block.y * block.z;
+    if (nt > 1024) { fprintf(stderr, "hipemu: block too large\n"); abort(); }
+    if (shmem > 160 * 1024) { fprintf(stderr, "hipemu: %zu B of dynamic LDS exceeds the 160 KiB of a gfx950 CU\n", shmem); abort(); }
+    Thunk<F>::f = &body;                                  // (launches are serialised by the caller: one at a time)
+    void (*entry)() = &Thunk<F>::run;
+    const unsigned long long nblk = (unsigned long long)grid.x * grid.y * grid.z;
+    auto block_at = [&](unsigned long long b) {
+        const unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y), bz = (unsigned)(b / ((unsigned long long)grid.x * grid.y));
+        run_block(grid, block, shmem, entry, bx, by, bz);
+    };
+    unsigned nw = host_threads();
+    if (nw > nblk) nw = (unsigned)nblk;
+    if (nw <= 1) {
+        for (unsigned long long b = 0; b < nblk; ++b) block_at(b);
+        return;
+    }
+    std::atomic<unsigned long long> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const unsigned long long b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblk) break;
+            block_at(b);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(nw - 1);
+    for (unsigned i = 1; i < nw; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
 }
 
 }  // namespace hipemu

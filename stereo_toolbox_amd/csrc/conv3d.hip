@@ -1508,7 +1508,9 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
 
 // (GPU call P of round 3, 32 -> 32 L0 / 64 -> 32 L0, 4 x 16-voxel tiles with eight waves = 0.800 / 1.575 ms: 8 x 16-voxel tiles
 //  0.839 / 1.652; four waves, one per SIMD with seven taps each, 0.915 / 1.805 (4 x 16) and 0.883 / 1.743 (8 x 16).  Fewer
-//  barriers per MFMA do not help and one wave per SIMD hurts: the variants were removed again.)
+//  barriers per MFMA do not help and one wave per SIMD hurts: the variants were removed again.  GPU call S: TWO tiles in LDS --
+//  tile i+1 written to the other buffer behind the first operand reads of tile i, one barrier per tile instead of "barrier,
+//  store, barrier" -- 0.801 -> 0.845 / 1.568 -> 1.654 ms (250 instead of 187 VGPRs): removed as well.)
 // Weight gradient: spatial tile (coarse voxels), whether tile staging is software-pipelined, workgroups along split-K.
 // 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 voxels when the narrower tile wastes fewer columns (W' = 240 = 15 x 16 =
 // 7.5 x 32: 6 % fewer MFMAs); the pipelined staging pays for stride 2 and for the one- or two-pair L0 layers (measured: the
@@ -1522,6 +1524,8 @@ static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
     int c = (pipe ? 256 : 512) / npairs;                            // workgroups in total
     if (c < 1) c = 1;
     if (c > ntiles) c = ntiles;
+    const int forced = stx_tune(STX_TUNE_WGRAD_GRID);
+    if (forced > 0 && forced < c) c = forced;
     return c;
 }
 

@@ -452,6 +452,21 @@ def test_conv3d_wgrad(be, case):
     _close(run_wgrad(be, x, gy, ks, s).view_as(w), w.grad)
 
 
+def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune):
+    """The weight-gradient kernels' tile loop with several tiles per workgroup (STX_WGRAD_GRID caps the split-K workgroups; at
+    the small test shapes every workgroup otherwise gets one tile): odd and even tile counts, stride 1 and 2."""
+    torch.manual_seed(8)
+    for grid, (B, Cin, Cout, D, H, W, s) in ((1, (1, 32, 32, 3, 5, 37, 1)), (4, (2, 32, 64, 2, 9, 21, 1)), (5, (1, 64, 32, 3, 7, 40, 1)),
+                                             (3, (1, 32, 64, 4, 6, 40, 2))):
+        tune("STX_WGRAD_GRID", grid)
+        x = torch.randn(B, Cin, D, H, W)
+        w = (torch.randn(Cout, Cin, 3, 3, 3) * 0.1).requires_grad_()
+        y = F.conv3d(x, w, None, s, 1)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        _close(run_wgrad(be, x, gy, 3, s).view_as(w), w.grad)
+
+
 def test_deconv3d_wgrad(be):
     torch.manual_seed(9)
     x = torch.randn(1, 64, 2, 3, 20)

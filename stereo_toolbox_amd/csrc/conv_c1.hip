@@ -230,6 +230,69 @@ __global__ __launch_bounds__(C1_THREADS) void conv_c1_dgrad_kernel(const float* 
 }
 
 
+// Data gradient on the matrix cores (Cin = 32): gx[v][c] = sum_tap gy[v - (tap - 1)] * w[c][tap] is a GEMM with M = voxels,
+// N = 32 channels, K = 27 taps padded to 28 = 14 x v_mfma_f32_32x32x2f32 per 32 voxels.  A = the 1-channel gy at the tap's
+// shifted voxel (lane (voxel i, half) reads tap 2 j + half from the small LDS halo of gy: 14 fixed offsets per lane), B = the
+// weights (14 registers per lane, loaded once).  The accumulator holds one channel of 16 voxels per lane, so every store
+// instruction writes two whole 128-byte voxels; rows go through a descriptor of the output plane (voxels outside the volume get
+// the out-of-range offset).  The VALU kernel above needs 27 x 32 FMAs per voxel on the vector pipe (0.109 ms = 0.25 of the HBM
+// rate for the 212 MB it writes); here the matrix pipe does them in 896 cycles per 4 KiB of output and wave.
+// A workgroup = 4 waves = 4 rows x 32 columns of one plane; tiles are dealt round-robin.
+__global__ __launch_bounds__(C1_THREADS) void conv_c1_dgrad_mfma_kernel(const float* __restrict__ gy,
+                                                                        const float* __restrict__ w, float* __restrict__ gx,
+                                                                        int B, int D, int H, int W, int nHt, int nWt, int ntiles) {
+    __shared__ float gys[3 * C1D_EH * C1D_EW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    float wreg[14];
+    int aoff[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+        const int tap = 2 * j + half;
+        const int tp = tap < 27 ? tap : 26;
+        const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+        wreg[j] = tap < 27 ? w[(size_t)i * 27 + tap] : 0.f;
+        // output voxel (d, h, w) meets gy(d + 1 - kd, h + 1 - kh, w + 1 - kw); the halo starts at (d - 1, h0 - 1, w0 - 1)
+        aoff[j] = ((2 - kd) * C1D_EH + (wave + 2 - kh)) * C1D_EW + i + 2 - kw;
+    }
+    const unsigned plane_bytes = (unsigned)H * (unsigned)W * 128u;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int r_ = tile;
+        const int wt = r_ % nWt; r_ /= nWt;
+        const int ht = r_ % nHt; r_ /= nHt;
+        const int d = r_ % D;
+        const int b = r_ / D;
+        const int h0 = ht * C1D_TH, w0 = wt * C1D_TW;
+        __syncthreads();                                       // the previous tile's halo has been read
+        for (int idx = tid; idx < 3 * C1D_EH * C1D_EW; idx += C1_THREADS) {
+            const int wx = idx % C1D_EW, hy = (idx / C1D_EW) % C1D_EH, dz = idx / (C1D_EW * C1D_EH);
+            const int gd = d - 1 + dz, gh = h0 - 1 + hy, gw = w0 - 1 + wx;
+            gys[idx] = (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                           ? gy[(((size_t)b * D + gd) * H + gh) * W + gw] : 0.f;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float av[14];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) av[j] = gys[aoff[j]];
+#pragma unroll
+        for (int j = 0; j < 14; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wreg[j], acc, 0, 0, 0);
+        // acc[r] = gx[voxel (r & 3) + 8 (r >> 2) + 4 half of the row][channel i]
+        const int oh = h0 + wave;
+        const stx_bufrsrc ors = stx_make_rsrc(gx + ((size_t)b * D + d) * H * W * 32, plane_bytes);
+        const unsigned vbase = (unsigned)((((oh < H ? oh : 0) * W + w0 + 4 * half) * 32 + i) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2);
+            const bool ok = oh < H && w0 + 4 * half + m < W;
+            stx_buf_st1(ors, ok ? vbase : STX_BUF_OOB, (unsigned)(m * 128), acc[r]);
+        }
+    }
+}
+
+
 // Weight gradient on the matrix cores (Cin a multiple of 32).  Re-indexed over INPUT voxels v:
 //   dW[c][tap] = sum_v x[v][c] * gy[v - (tap - 1)]          (gy = 0 outside the volume)
 // is a GEMM with M = 32 channels, N = 27 taps (padded to 32), K = voxels.  v_mfma_f32_32x32x2f32 takes two
@@ -531,6 +594,13 @@ extern "C" int stx_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, i
     STX_REQUIRE(gy && w && gx && B > 0 && D > 0 && H > 0 && W > 0, "conv3d_c1_dgrad: bad shape");
     STX_REQUIRE(Cin % 4 == 0 && Cin <= 64, "conv3d_c1_dgrad: Cin=%d must be a multiple of 4, <= 64", Cin);
     const int nHt = stx_cdiv(H, C1D_TH), nWt = stx_cdiv(W, C1D_TW);
+    const long long nt = (long long)B * D * nHt * nWt;
+    if (Cin == 32 && (long long)H * W * 128 < (1ll << 31) && nt < (1ll << 31)) {   // (other widths: the VALU kernel below)
+        const long long g = nt < 256 * 8 ? nt : 256 * 8;
+        hipLaunchKernelGGL(conv_c1_dgrad_mfma_kernel, dim3((unsigned)g), dim3(C1_THREADS), 0, (hipStream_t)stream, gy, w, gx, B, D,
+                           H, W, nHt, nWt, (int)nt);
+        return stx_check_launch("conv3d_c1_dgrad(mfma)");
+    }
     hipLaunchKernelGGL(conv_c1_dgrad_kernel, dim3((unsigned)((size_t)B * D * nHt * nWt)), dim3(C1_THREADS), 0,
                        (hipStream_t)stream, gy, w, gx, B, D, H, W, Cin, nHt, nWt);
     return stx_check_launch("conv3d_c1_dgrad");

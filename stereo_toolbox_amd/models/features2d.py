@@ -24,7 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..aggregation import _bn_state
+from ..aggregation import _bn_state, _fold
 
 
 def channels_last_weights_(module):
@@ -40,12 +40,18 @@ def channels_last_weights_(module):
 
 def fused_glue(x, *bns):
     """Whether the BatchNorm2d / ReLU / add glue runs on the in-house kernels for this call: fp32 on a ROCm device (or
-    the emulator in tests), every BatchNorm involved in train mode."""
+    the emulator in tests) and either every BatchNorm involved in train mode (batch statistics, autograd) or -- inference --
+    every one in eval mode with autograd off (running statistics folded into one scale / shift pass per block)."""
     if os.environ.get("STX_FEAT2D_FUSED", "1") == "0":
         return False
     if x.dtype != torch.float32 or not (x.is_cuda or ops._EMULATED):
         return False
-    return all(isinstance(b, nn.modules.batchnorm._BatchNorm) and b.training for b in bns)
+    if not all(isinstance(b, nn.modules.batchnorm._BatchNorm) for b in bns):
+        return False
+    if all(b.training for b in bns):
+        return True
+    return (not torch.is_grad_enabled() and not any(b.training for b in bns)
+            and all(b.track_running_stats and b.running_mean is not None for b in bns))
 
 
 class view_groups:
@@ -75,12 +81,21 @@ def _nhwc(t):
 
 
 def conv_bn_act(x, conv, bn, relu=False, residual=None, second=None):
-    """act(BN(conv(x)) [+ residual | + BN2(z2)]) for a train-mode BatchNorm2d: MIOpen convolution (channels-last), one
-    statistics pass, one fused normalise / add / ReLU pass.  x / residual: NCHW-logical; second = (z2, bn2) with z2 the raw
+    """act(BN(conv(x)) [+ residual | + BN2(z2)]): MIOpen convolution (channels-last), then for a train-mode BatchNorm2d one
+    statistics pass and one fused normalise / add / ReLU pass, for an eval-mode one (inference) the fused pass alone.  x / residual: NCHW-logical; second = (z2, bn2) with z2 the raw
     output of the other branch's convolution.  Returns an NCHW-logical channels_last tensor."""
     G = view_groups.n
     z = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     zl = _nhwc(z)
+    if not bn.training:
+        # inference: running statistics folded into (scale, shift), cached per module like the 3-D path's
+        sc, sh = _fold(bn)
+        if second is not None:
+            sc2, sh2 = _fold(second[1])
+            y = ops.bn_apply(zl, sc, sh, _nhwc(second[0]), sc2, sh2, relu)
+        else:
+            y = ops.bn_apply(zl, sc, sh, None if residual is None else _nhwc(residual), None, None, relu)
+        return y.permute(0, 3, 1, 2)
     st = _bn_state(bn, ops.bn_stats(zl.detach(), G), zl.numel() // zl.shape[-1] // G, steps=G)
     if second is not None:
         z2l = _nhwc(second[0])

@@ -326,8 +326,10 @@ def test_full_size_eval_parity(tag, parity_log):
       (3) the whole model against the fp32 CPU oracle: 1e-3 where the stock 2-D CNN's rounding leaves room for it, never
           above 1e-3 + the distance the MIOpen features ALONE move the oracle's own 3-D path (row B, measured here; GPU
           calls A/F: 7.4e-4 .. 8.9e-4 px for a feature perturbation of 7e-7 relative rms -- the random-weight D=192
-          network amplifies one-ulp input noise to that level, so (3) cannot be flat for ANY fp32 implementation that does
-          not reproduce MKL-DNN's rounding; the reference's own fp32 run is 6.7e-4 .. 7.2e-4 px from its fp64 run)."""
+          network amplifies one-ulp input noise to that level; the reference's own fp32 run is 6.7e-4 .. 7.2e-4 px from its
+          fp64 run).  Achieved since the inference 2-D glue folds BatchNorm into one scale / shift pass (GPU call T of round
+          3): 8.0e-4 / 9.1e-4 / 2.9e-4 px -- `branch: "flat 1e-3"` in the parity report for all three shapes; the row-B
+          allowance stays as the assertion because MIOpen may pick other convolution algorithms on another box."""
     from stereo_toolbox_amd.models import ACVNet, GwcNet_GC
     from stereo_toolbox_amd.models.features2d import run_pair
     if not torch.cuda.is_available():
@@ -366,7 +368,8 @@ def test_full_size_eval_parity(tag, parity_log):
     e_ref32 = float(gold[tag + "_e32"])                                    # reference fp32 vs fp64 (all pixels)
     e_full = (got - ref).abs().max().item()                                # product vs oracle, all pixels
     e_mean = (got - ref).abs().mean().item()
-    parity_log(f"full_size_eval[{tag}]", max_abs_vs_oracle_all_px=e_full, mean_abs_vs_oracle=e_mean,
+    parity_log(f"full_size_eval[{tag}]", branch="flat 1e-3" if e_full < 1e-3 else "1e-3 + row B",
+               max_abs_vs_oracle_all_px=e_full, mean_abs_vs_oracle=e_mean,
                max_abs_vs_reference_fp64_sampled=e_prod64, oracle_vs_reference_fp64_sampled=e_orc64,
                reference_fp32_vs_fp64_all_px=e_ref32, **rec)
     assert e_orc64 < max(1e-3, 2 * e_ref32), "oracle on this box disagrees with the reference fixture"

@@ -106,12 +106,50 @@ struct HaloMap {
 // (host side: the descriptor range of a batch item plus the low-edge overhang of one plane must stay below 2 GiB)
 static bool halo_range_ok(int Di, int Hi, int Wi, int Cin) { return (long long)(Di + 2) * Hi * Wi * Cin * 4 < (1ll << 31); }
 
-// Fused epilogue for one 32x32 accumulator block. `vox` = linear output voxel index of row 0 of
-// the block (rows are consecutive voxels when `rstride`==1), nrows_valid = rows that exist.
+// Fused epilogue for one 32x32 accumulator block. `vox0` = linear output voxel index of row 0 of the block (rows are voxels
+// vox0 + row * rstride of ONE output row of the volume), nvalid_rows = rows that exist.
+// Straight-line form (every activation code but Mish): the block's voxels go through a buffer descriptor that starts at row 0
+// (wave-uniform base), one per-lane byte offset, the row's offset in the instruction's scalar offset; rows that do not exist
+// get the out-of-range offset (store dropped, residual read as zero) and contribute zeros to the BN sums.  The residual rows
+// are requested up front.  (The first version: a 64-bit address, a bounds branch, a residual branch and the activation switch
+// per row -- for the transposed convolution, whose waves own 64-128 rows per 432-1728 MFMAs, a tenth to a quarter of the
+// kernel.)
 __device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32x16& acc, size_t vox0, int rstride,
                                                     int nvalid_rows, int n, float sc, float bs, int lane,
                                                     float& s1, float& s2) {
     const int half = lane >> 5;
+    if (a.relu != 2) {
+        const unsigned rowb = (unsigned)rstride * (unsigned)a.Cout * 4u;          // bytes between two rows of the block
+        const unsigned span = 32u * rowb;                                          // (row 31 ends inside: n < Cout)
+        const stx_bufrsrc ors = stx_make_rsrc(a.out + vox0 * a.Cout, span);
+        const unsigned vb = (unsigned)(4 * half) * rowb + (unsigned)n * 4u;
+        const bool nok = n < a.Cout;
+        const bool relu_on = a.relu == 1, has_res = a.residual != nullptr;
+        // (an empty descriptor without a residual: its loads return zeros without touching memory)
+        const stx_bufrsrc rrs = stx_make_rsrc(has_res ? a.residual + vox0 * a.Cout : a.out, has_res ? span : 0u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                              // four rows at a time: residuals requested, then used
+            float res[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row0 = q + 8 * g;
+                res[q] = stx_buf_ld1(rrs, (nok && row0 + 4 * half < nvalid_rows) ? vb : STX_BUF_OOB, (unsigned)row0 * rowb);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * g + q, row0 = q + 8 * g;
+                const bool ok = nok && row0 + 4 * half < nvalid_rows;
+                float v = ok ? acc[r] : 0.f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+                v = fmaf(v, sc, bs) + res[q];
+                const float vr = fmaxf(v, 0.f);
+                v = relu_on ? vr : v;
+                stx_buf_st1(ors, ok ? vb : STX_BUF_OOB, (unsigned)row0 * rowb, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -898,7 +936,7 @@ __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const floa
 }
 
 template <int NT, int CK>
-__global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 4 : 2) void deconv3d_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 3 : 2) void deconv3d_igemm_kernel(ConvArgs a) {
     constexpr int TH = 2;
     constexpr int ED = 2, EH = TH + 1, EW = 33;
     constexpr int VS = CK + 4, NF4 = CK / 4;

@@ -1548,7 +1548,9 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
 //  0.839 / 1.652; four waves, one per SIMD with seven taps each, 0.915 / 1.805 (4 x 16) and 0.883 / 1.743 (8 x 16).  Fewer
 //  barriers per MFMA do not help and one wave per SIMD hurts: the variants were removed again.  GPU call S: TWO tiles in LDS --
 //  tile i+1 written to the other buffer behind the first operand reads of tile i, one barrier per tile instead of "barrier,
-//  store, barrier" -- 0.801 -> 0.845 / 1.568 -> 1.654 ms (250 instead of 187 VGPRs): removed as well.)
+//  store, barrier" -- 0.801 -> 0.845 / 1.568 -> 1.654 ms (250 instead of 187 VGPRs): removed as well.  GPU call W: the 128-VGPR
+//  form (pair loop rolled, no spills) with TWO workgroups per CU, un-pipelined or pipelined staging: 0.800 -> 0.828 / 0.834 ms,
+//  1.571 -> 1.637 ms -- four fp32-MFMA waves per SIMD run the matrix pipe slower than two, as round 1 measured: removed.)
 // Weight gradient: spatial tile (coarse voxels), whether tile staging is software-pipelined, workgroups along split-K.
 // 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 voxels when the narrower tile wastes fewer columns (W' = 240 = 15 x 16 =
 // 7.5 x 32: 6 % fewer MFMAs); the pipelined staging pays for stride 2 and for the one- or two-pair L0 layers (measured: the

@@ -228,6 +228,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--buckets", type=int, default=2, help="ranges of the flat gradient buffer (overlapped all-reduce)")
     ap.add_argument("--no-overlap", action="store_true", help="one all-reduce after backward() instead")
+    ap.add_argument("--fused-adam", type=int, default=1, help="torch.optim.Adam(fused=True) (default) / 0 = the multi-tensor form")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+bwd+all-reduce+Adam) in one hipGraph and replay it")
     return ap.parse_args(argv)
@@ -355,7 +356,12 @@ def main(argv=None):
             model.train()
             overlap = not args.no_overlap and not args.graph
             gsync = FlatGradSync(model, buckets=args.buckets if overlap else 1, overlap=overlap)
-            opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
+            # the reference's optimizer (tests/train_torchrun.py:57: optim.Adam(model.parameters(), lr)), torch's single-kernel
+            # implementation of it (fused=True: same update rule, one launch instead of ~12 multi-tensor launches)
+            try:
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph, fused=args.fused_adam and dev.type == "cuda")
+            except (RuntimeError, TypeError):
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
             gt = 190.0 * torch.rand(B, H, W, device=dev, generator=g)
 
             sync_events = []                       # (before, after) finish(): what the gradient exchange adds to the stream
@@ -500,6 +506,7 @@ def main(argv=None):
                                      f"flat fp32 buffer, {gsync.nb} overlapped all-reduce range(s)" if gsync.overlap else
                                      "flat fp32 buffer, 1 all-reduce after backward"),
                        "launch": "hipGraph replay" if args.graph else "eager",
+                       **({"optimizer": "torch.optim.Adam(fused=True)" if args.fused_adam else "torch.optim.Adam"} if mode == "train" else {}),
                        "miopen_user_db": (os.path.relpath(tuning_db, ROOT) if tuning_db and tuning_db.startswith(ROOT)
                                           else tuning_db)},
             "roofline": roof,

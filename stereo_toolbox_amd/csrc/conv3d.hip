@@ -523,6 +523,9 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
     if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.x);
 }
 
+// (1x1x1 convolutions -- the hourglass `redir` layers, HBM-bound -- go through the implicit-GEMM kernel with 32-channel chunks.
+//  A persistent streaming form for 32 -> 32 channels without an LDS tile -- a wave owns 32 consecutive voxels per step, A operands
+//  straight from memory one step ahead of the 16 MFMAs -- measured 0.117 ms against 0.108-0.112 ms, GPU call Y of round 3: removed.)
 struct MarchArgs {
     ConvArgs c;
     int ncols;           // B * nHt * nWt workgroup columns; the (column, d) plane list is split evenly over the grid

@@ -328,6 +328,8 @@ CONV_CASES = [
     (1, 40, 32, 2, 2, 20, 3, 1),     # ACVNet dres1_att_ (Cin=40 -> 8-channel K chunks)
     (1, 32, 1, 2, 4, 35, 3, 1),      # classifier tail Conv3d(32->1)
     (1, 64, 64, 3, 4, 34, 1, 1),     # redir 1x1x1
+    (2, 32, 32, 3, 5, 37, 1, 1),     # redir 1x1x1 at 32 channels (hourglass redir1)
+    (1, 32, 24, 2, 4, 21, 1, 1),     # ... with 24 output channels
     (1, 64, 64, 3, 5, 37, 3, 1),     # hourglass conv2
     (1, 64, 128, 4, 4, 24, 3, 2),
     (2, 32, 64, 7, 6, 40, 3, 1),     # march kernel, 2 column blocks (NT=2), ragged H/W, several D segments

@@ -1553,7 +1553,13 @@ extern "C" int stx_deconv3d_fwd(const float* x, const float* wp, float* out, con
 //  tile i+1 written to the other buffer behind the first operand reads of tile i, one barrier per tile instead of "barrier,
 //  store, barrier" -- 0.801 -> 0.845 / 1.568 -> 1.654 ms (250 instead of 187 VGPRs): removed as well.  GPU call W: the 128-VGPR
 //  form (pair loop rolled, no spills) with TWO workgroups per CU, un-pipelined or pipelined staging: 0.800 -> 0.828 / 0.834 ms,
-//  1.571 -> 1.637 ms -- four fp32-MFMA waves per SIMD run the matrix pipe slower than two, as round 1 measured: removed.)
+//  1.571 -> 1.637 ms -- four fp32-MFMA waves per SIMD run the matrix pipe slower than two, as round 1 measured: removed.
+//  Counters (profiles/r03_pmc_instruction_mix.txt): 3.4 scalar instructions and 0.7 branches per MFMA (the exec-mask save /
+//  restore around the fourth tap of three of the eight waves), SIMDs loaded 7 / 7 / 7 / 6 taps.  A BALANCED split -- every wave
+//  three whole taps plus three of the 24 (tap 24-26, pair mod 8) combinations, walked in a per-wave rotated pair order so that
+//  all waves run the same mask-free code, 27 MFMAs per eight pairs each -- removed both, but pays for the rotation with vector
+//  address arithmetic: 3.4 VALU per MFMA 0.802 -> 0.887 ms, 1.6 VALU per MFMA 0.870 ms (all six shapes 8-15 % slower, GPU calls
+//  BAL / BAL2): in this loop a VALU instruction costs far more than a scalar one.  Removed; the record stays.)
 // Weight gradient: spatial tile (coarse voxels), whether tile staging is software-pipelined, workgroups along split-K.
 // 3x3x3 stride 1 takes 4 x 16 instead of 2 x 32 voxels when the narrower tile wastes fewer columns (W' = 240 = 15 x 16 =
 // 7.5 x 32: 6 % fewer MFMAs); the pipelined staging pays for stride 2 and for the one- or two-pair L0 layers (measured: the

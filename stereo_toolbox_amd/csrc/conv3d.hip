@@ -124,6 +124,19 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32
         const stx_bufrsrc ors = stx_make_rsrc(a.out + vox0 * a.Cout, span);
         const unsigned vb = (unsigned)(4 * half) * rowb + (unsigned)n * 4u;
         const bool nok = n < a.Cout;
+        if (a.relu == 0 && !a.scale && !a.bias && !a.residual && nok && nvalid_rows >= 32) {
+            // raw output of a whole block (every training-mode launch away from the volume's edges): two vector instructions
+            // per row for the BN sums, the store takes the accumulator register itself -- in these kernels' instruction mix a
+            // VALU instruction is what an epilogue costs (the transposed convolution owns 16 rows per 27 MFMAs)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row0 = (r & 3) + 8 * (r >> 2);
+                s1 += acc[r];
+                s2 = fmaf(acc[r], acc[r], s2);
+                stx_buf_st1(ors, vb, (unsigned)row0 * rowb, acc[r]);
+            }
+            return;
+        }
         const bool relu_on = a.relu == 1, has_res = a.residual != nullptr;
         // (an empty descriptor without a residual: its loads return zeros without touching memory)
         const stx_bufrsrc rrs = stx_make_rsrc(has_res ? a.residual + vox0 * a.Cout : a.out, has_res ? span : 0u);

@@ -911,7 +911,9 @@ constexpr DcEntries dc_entries(int cset) {
 // before its first MFMA, an L2 round trip per 16 MFMAs: 0.45 / 0.33 of the fp32-MFMA peak for the two GwcNet shapes, GPU
 // call O of round 2.  Prefetching the LDS operands too, and dealing the loads between the MFMAs, measured 0-4 % slower:
 // calls Q-T of round 2, call G of round 3; the weights SIX entries ahead in a ring of seven register sets that runs on
-// across the K chunks: 0.138 / 0.245 -> 0.141 / 0.252 ms, call R of round 3 -- no gain, removed.)
+// across the K chunks: 0.138 / 0.245 -> 0.141 / 0.252 ms, call R of round 3 -- no gain, removed.  16-channel K chunks with the
+// chunk prefetch in place: 0.140 / 0.253 vs 0.140 / 0.250 ms; the raw whole-block epilogue (two vector instructions per row
+// instead of nine): no change.  Neither the weight latency, nor the barriers per chunk, nor the epilogue bound this kernel.)
 template <int CSET, int NT, int CK>
 __device__ __forceinline__ void deconv_chunk_taps(const float* atile, const float* wq, int NQ, f32x16 (&acc)[4][NT]) {
     constexpr DcEntries E = dc_entries(CSET);

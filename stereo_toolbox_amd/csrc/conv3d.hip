@@ -720,7 +720,9 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
 
     // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
     // (the finished output plane dprev) interleaved with the MFMA groups
-    auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool with_epi, const f32x16& done0, const f32x16& done1,
+    // fresh: the accumulator starts here -- the first MFMA takes a zero C operand (an inline constant) instead of a register
+    // set that 16 vector moves zeroed beforehand
+    auto tap_plane = [&](const float* pbuf, int kd, f32x16& acc, bool fresh, bool with_epi, const f32x16& done0, const f32x16& done1,
                          const f32x16& done, int dprev, int epi0, unsigned vmask, const stx_bufrsrc& ors) {
         float4 av[2][4], bv[2][4];
         auto load_tap = [&](int t9, int buf) {
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
             const int cb = t9 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].x, bv[cb][q].x, (fresh && t9 == 0 && q == 0) ? zero16() : acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].y, bv[cb][q].y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].z, bv[cb][q].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][q].w, bv[cb][q].w, acc, 0, 0, 0);
@@ -768,8 +770,6 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     // output p = pD (plane p-1) + pE (this plane), output p+1 = pF (this plane); pC, pE, pF start from zero here.
     auto step = [&](int p, int d_lo, int d_hi, const float* pbuf, float* nbuf, bool stage, f32x16& pA, f32x16& pB,
                     f32x16& pC, f32x16& pD, f32x16& pE, f32x16& pF) {
-        pF = zero16();
-        if (BS) { pC = zero16(); pE = zero16(); }
         const bool live = p >= 0 && p < a.Di;                        // planes outside the volume are zero padding
         const bool vOld = p - 1 >= d_lo && p - 1 < d_hi, vMid = p >= d_lo && p < d_hi, vNew = p + 1 >= d_lo && p + 1 < d_hi;
         const bool st_on = vOld && ma.ablate != 2;
@@ -780,13 +780,15 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         if (EPI == 3)
             load_partials(vmask, stx_make_rsrc(a.residual + ((size_t)b * a.Do + (st_on ? p - 1 : 0)) * a.Ho * a.Wo * ma.os,
                                                st_on ? oplane_bytes : 0u));
-        if (live && vOld) tap_plane(pbuf, 2, pC, false, pA, pB, pC, 0, -1, 0u, ors);
+        if (live && vOld) tap_plane(pbuf, 2, pC, BS != 0, false, pA, pB, pC, 0, -1, 0u, ors);
+        else if (BS) pC = zero16();
         // the next plane (in flight since the start of the step) goes into the other buffer now: that buffer has been
         // free since the barrier that ended the previous step, and the remaining 18 taps cover the LDS writes
         if (stage) store_plane(nbuf);
         // output p-1 is complete: its 16 rows leave in the shadow of the next 18 taps (or on their own at the edges)
-        if (live && vMid) tap_plane(pbuf, 1, pE, vOld, pA, pB, pC, p - 1, 0, vmask, ors);
-        else if (vOld) {
+        if (live && vMid) tap_plane(pbuf, 1, pE, BS != 0, vOld, pA, pB, pC, p - 1, 0, vmask, ors);
+        else if (BS) pE = zero16();
+        if (!(live && vMid) && vOld) {
             // no MFMAs to hide behind: plain epilogue of rows 0..8
 #pragma unroll
             for (int r = 0; r < 9; ++r) {
@@ -794,8 +796,9 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
                 else emit_row(pA, pB, pC, r, p - 1);
             }
         }
-        if (live && vNew) tap_plane(pbuf, 0, pF, vOld, pA, pB, pC, p - 1, 9, vmask, ors);
-        else if (vOld) {
+        if (live && vNew) tap_plane(pbuf, 0, pF, true, vOld, pA, pB, pC, p - 1, 9, vmask, ors);
+        else pF = zero16();
+        if (!(live && vNew) && vOld) {
 #pragma unroll
             for (int r = 9; r < 16; ++r) {
                 if (EPI != 1) emit_row_plain(pA, pB, pC, r, vmask, ors);

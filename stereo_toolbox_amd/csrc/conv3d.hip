@@ -600,7 +600,8 @@ constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed we
 // layer: its 16 values per lane are loaded through the same descriptor at the START of the step, nine taps before the first
 // is needed -- the general epilogue waited for each of them with s_waitcnt vmcnt(0): 1.10 vs 0.70 ms per launch in the
 // step trace of GPU call N); EPI = 3 the same with a residual added behind the affine (inference: dres1's second conv).
-// EPI = 1 is the general epilogue (partial sums AND residual, Mish).  The plane staging loads go through a descriptor of the input
+// EPI = 4: EPI = 0 for raw outputs (no affine, no activation: every training-mode launch) -- three vector instructions per
+// row less.  EPI = 1 is the general epilogue (partial sums AND residual, Mish).  The plane staging loads go through a descriptor of the input
 // plane the same way for both (offsets precomputed per column; halo voxels outside the volume and planes outside [0, Di)
 // read zeros through the bounds check: no address clamps, no branches).
 template <int BS, int EPI = 1>
@@ -711,10 +712,12 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
         v = ok ? v : 0.f;
         s1 += v;
         s2 = fmaf(v, v, s2);
-        v = fmaf(v, sc, bs);
-        if (EPI == 3) v += accp[r];
-        const float vr = fmaxf(v, 0.f);
-        v = relu_on ? vr : v;
+        if (EPI != 4) {                                              // (EPI = 4: raw output -- no affine, no activation)
+            v = fmaf(v, sc, bs);
+            if (EPI == 3) v += accp[r];
+            const float vr = fmaxf(v, 0.f);
+            v = relu_on ? vr : v;
+        }
         stx_buf_st1(ors, ok ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4), v);
     };
 
@@ -1483,6 +1486,8 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
             void (*mk_plain)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 0> : conv3d_marchw_kernel<0, 0>;
             void (*mk_acc)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 2> : conv3d_marchw_kernel<0, 2>;
             void (*mk_res)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 3> : conv3d_marchw_kernel<0, 3>;
+            void (*mk_raw)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 4> : conv3d_marchw_kernel<0, 4>;
+            hipFuncSetAttribute((const void*)mk_raw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_acc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1501,8 +1506,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     }
                     // (the straight-line epilogues read the partial sums through the OUTPUT descriptor: acc_in is `out`)
                     const bool plain = epi_fast && !(m.c.residual && m.acc_in) && m.c.relu != 2;
-                    hipLaunchKernelGGL(plain ? (m.acc_in ? mk_acc : (m.c.residual ? mk_res : mk_plain)) : mk, dim3(nb2), dim3(256),
-                                       lds2, st, m);
+                    const bool raw = !m.acc_in && !m.c.residual && !m.c.scale && !m.c.bias && m.c.relu == 0;
+                    hipLaunchKernelGGL(plain ? (raw ? mk_raw : m.acc_in ? mk_acc : (m.c.residual ? mk_res : mk_plain)) : mk, dim3(nb2),
+                                       dim3(256), lds2, st, m);
                 }
             return stx_check_launch("conv3d_fwd(march)");
         }

@@ -601,7 +601,8 @@ constexpr int MW2_WFLOATS = 27 * 4 * 256;                           // packed we
 // is needed -- the general epilogue waited for each of them with s_waitcnt vmcnt(0): 1.10 vs 0.70 ms per launch in the
 // step trace of GPU call N); EPI = 3 the same with a residual added behind the affine (inference: dres1's second conv).
 // EPI = 4: EPI = 0 for raw outputs (no affine, no activation: every training-mode launch) -- three vector instructions per
-// row less.  EPI = 1 is the general epilogue (partial sums AND residual, Mish).  The plane staging loads go through a descriptor of the input
+// row less; EPI = 5: the same for whole tiles and 32 output channels (no per-row validity: three more).  EPI = 1 is the general
+// epilogue (partial sums AND residual, Mish).  The plane staging loads go through a descriptor of the input
 // plane the same way for both (offsets precomputed per column; halo voxels outside the volume and planes outside [0, Di)
 // read zeros through the bounds check: no address clamps, no branches).
 template <int BS, int EPI = 1>
@@ -706,19 +707,21 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     auto emit_row_plain = [&](const f32x16& done0, const f32x16& done1, const f32x16& done, int r, unsigned vmask,
                               const stx_bufrsrc& ors) {
         const int c = (r & 3) + 8 * ((r >> 2) & 1), dh = r >> 3;
-        const bool ok = (vmask >> r) & 1u;
+        // EPI = 5 (raw output, whole tiles, 32 output channels): every row exists; without a finished plane (vmask = 0, wave-
+        // uniform) the descriptor is empty, so the store needs no per-lane select and the sums one select on a scalar condition
+        const bool ok = EPI == 5 ? vmask != 0u : (bool)((vmask >> r) & 1u);
         float v = BS ? (done0[r] + done1[r]) + done[r] : done[r];
         if (EPI == 2) v += accp[r];
         v = ok ? v : 0.f;
         s1 += v;
         s2 = fmaf(v, v, s2);
-        if (EPI != 4) {                                              // (EPI = 4: raw output -- no affine, no activation)
+        if (EPI != 4 && EPI != 5) {                                  // (EPI = 4 / 5: raw output -- no affine, no activation)
             v = fmaf(v, sc, bs);
             if (EPI == 3) v += accp[r];
             const float vr = fmaxf(v, 0.f);
             v = relu_on ? vr : v;
         }
-        stx_buf_st1(ors, ok ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4), v);
+        stx_buf_st1(ors, (EPI == 5 || ok) ? ovoff : STX_BUF_OOB, (unsigned)((dh * a.Wo + c) * ma.os * 4), v);
     };
 
     // 9 taps of one kd plane into `acc`; operands one tap ahead (registers), optional epilogue slices of `done`
@@ -1487,6 +1490,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
             void (*mk_acc)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 2> : conv3d_marchw_kernel<0, 2>;
             void (*mk_res)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 3> : conv3d_marchw_kernel<0, 3>;
             void (*mk_raw)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 4> : conv3d_marchw_kernel<0, 4>;
+            void (*mk_rawf)(MarchArgs) = bs ? conv3d_marchw_kernel<1, 5> : conv3d_marchw_kernel<0, 5>;
+            hipFuncSetAttribute((const void*)mk_rawf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            const bool whole = a.Ho % MW2_TH == 0 && a.Wo % MW2_MW == 0;
             hipFuncSetAttribute((const void*)mk_raw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipFuncSetAttribute((const void*)mk_plain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -1507,8 +1513,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                     // (the straight-line epilogues read the partial sums through the OUTPUT descriptor: acc_in is `out`)
                     const bool plain = epi_fast && !(m.c.residual && m.acc_in) && m.c.relu != 2;
                     const bool raw = !m.acc_in && !m.c.residual && !m.c.scale && !m.c.bias && m.c.relu == 0;
-                    hipLaunchKernelGGL(plain ? (raw ? mk_raw : m.acc_in ? mk_acc : (m.c.residual ? mk_res : mk_plain)) : mk, dim3(nb2),
-                                       dim3(256), lds2, st, m);
+                    hipLaunchKernelGGL(plain ? (raw ? (whole && m.ncout == 32 ? mk_rawf : mk_raw) : m.acc_in ? mk_acc
+                                                        : (m.c.residual ? mk_res : mk_plain)) : mk,
+                                       dim3(nb2), dim3(256), lds2, st, m);
                 }
             return stx_check_launch("conv3d_fwd(march)");
         }

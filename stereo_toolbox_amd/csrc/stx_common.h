@@ -51,7 +51,7 @@ static inline float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsigned soff) {
 // Store through a descriptor: lanes with voff = STX_BUF_OOB are dropped.  (The hardware checks voff only, not voff + soff:
 // an in-range voff with an out-of-range sum would corrupt memory on the chip -- the emulator aborts on it.)
 static inline void stx_buf_st1(stx_bufrsrc r, unsigned voff, unsigned soff, float v) {
-    if (voff >= STX_BUF_OOB) return;
+    if (voff >= STX_BUF_OOB || voff >= r.bytes) return;            // (what the hardware's range check drops)
     const unsigned long long off = (unsigned long long)voff + soff;
     if (off + 4 > r.bytes) abort();
     *reinterpret_cast<float*>(const_cast<char*>(r.base) + off) = v;

@@ -337,6 +337,7 @@ CONV_CASES = [
     (1, 32, 32, 3, 9, 60, 3, 1),     # march kernel, 4 x 32 columns (W = 60 wastes the same either way), ragged H
     (2, 32, 64, 4, 6, 64, 3, 1),     # march kernel, 4 x 32 columns, NT=2
     (2, 32, 24, 5, 11, 21, 3, 1),    # march kernel, 24 of a slice's 32 output channels, ragged H / W, two batch items
+    (2, 32, 64, 5, 16, 32, 3, 1),    # march kernel, whole 8 x 16 tiles (the raw whole-tile epilogue), two N slices
 ]
 
 
@@ -856,7 +857,8 @@ def test_conv3d_march_epilogues_agree(be, tune):
     for launches without partial sums / residual / Mish) and the general one produce the same bits: outputs, BN partial
     sums, affine + ReLU; ragged tiles, sliced channels, several runs per workgroup."""
     torch.manual_seed(6)
-    for B, Cin, Cout, D, H, W in ((1, 32, 32, 7, 9, 37), (2, 32, 64, 5, 6, 40), (1, 64, 32, 4, 8, 33), (2, 32, 24, 3, 11, 21)):
+    for B, Cin, Cout, D, H, W in ((1, 32, 32, 7, 9, 37), (2, 32, 64, 5, 6, 40), (1, 64, 32, 4, 8, 33), (2, 32, 24, 3, 11, 21),
+                                  (1, 32, 32, 6, 8, 48)):
         x = torch.randn(B, Cin, D, H, W)
         w = torch.randn(Cout, Cin, 3, 3, 3) * 0.1
         sc, bs = torch.rand(Cout) + 0.5, torch.randn(Cout)

@@ -242,6 +242,17 @@ def run_table(a, only_arg, only_exact=False):
                                      a.H, a.W, stream()), it)
         report("head_bwd", ms, nbytes=(cost.numel() * 2 + disp.numel() * 4) * 4)
 
+    if want("dwconv"):
+        # ACVNet patch convolutions (acv.py:183-187): 40-channel attention volume, dilations 1 / 2 / 3 per channel slice
+        D0, H0, W0 = L[0]
+        C = 40
+        x = torch.randn(B, D0, H0, W0, C, device=dev)
+        y = torch.empty_like(x)
+        w = torch.randn(C, 9, device=dev)
+        dil = torch.tensor([1, 1, 2, 2, 2, 2, 3, 3, 3, 3], dtype=torch.int32, device=dev)
+        ms = timeit(lambda: lib.call("stx_dwconv_hw_fwd", P(x), P(w), P(dil), P(y), B, D0, H0, W0, C, 0, stream()), it)
+        report("dwconv_hw_acv_patch_fwd", ms, nbytes=x.numel() * 8)
+
     if want("mish"):
         D0, H0, W0 = L[0]
         x = torch.randn(B, D0, H0, W0, 32, device=dev)

@@ -145,6 +145,12 @@ int stx_cost_volume_scale_bwd(const float* gvol, const float* Lc, const float* R
                               int W, int D, int mask_left, void* stream);
 /* out[v][c] = x[v][c] * s[v] over [nvox][C] */
 int stx_scale_channels(const float* x, const float* s, float* out, long long nvox, int C, void* stream);
+/* Backward of the attention concat volume vol = prob * concat(L, R shifted) (models/ACVNet/acv.py:196 with
+ * ACVNet/submodule.py:180-191) in one pass over gvol [B][D][H][W][2 Cc]: gL, gR [B][Cc][H][W], gprob [B][D][H][W].
+ * D * W * 4 bytes must fit in 150 KiB of LDS (else: bad-argument error; use stx_cost_volume_scale_bwd +
+ * stx_scale_channels + stx_cost_volume_bwd). */
+int stx_ac_volume_bwd(const float* gvol, const float* Lc, const float* Rc, const float* prob, float* gL, float* gR,
+                      float* gprob, int B, int Cc, int H, int W, int D, int mask_left, void* stream);
 
 /* ---- train-mode BatchNorm3d (+ReLU / residual) around the convolutions ---------------------------------
  * nn.BatchNorm3d of convbn_3d (models/GwcNet/submodule.py:17-20) in train() mode and the adds/ReLUs that follow it

@@ -64,6 +64,7 @@ SIGNATURES = {
     "stx_dwconv_hw_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_cost_volume_scale_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_scale_channels": [_P, _P, _P, _L, _I, _P],
+    "stx_ac_volume_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     # preprocess.hip
     "stx_pad_normalize_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "stx_sampled_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -162,6 +162,71 @@ __global__ __launch_bounds__(ACV_THREADS) void cv_scale_bwd_kernel(const float* 
     gscale[(((size_t)b * D + d) * H + h) * W + w] = acc;
 }
 
+// Backward of the attention concat volume  vol[d][w][c] = prob[d][w] * (c < Cc ? L[c][w] : R[c - Cc][w - d])  in ONE pass over
+// the gradient volume (acv.py:196 + ACVNet/submodule.py:180-191):
+//   gprob[d][w] = sum_c gvol[d][w][c] L[c][w] + gvol[d][w][Cc + c] R[c][w - d],
+//   gL[c][w] = sum_d prob[d][w] gvol[d][w][c],     gR[c][x] = sum_d prob[d][x + d] gvol[d][x + d][Cc + c].
+// A workgroup owns one image row (b, h).  Item (w, channel quad) walks d with its four left features in registers, item
+// (x, quad) walks d along the sheared column x + d with its four right features: every element of the gradient volume is read
+// exactly once, by one lane, as part of a 128-byte run of eight lanes; the two halves of gprob meet in an LDS image [D][W]
+// (ds_add_f32) that is written out coalesced at the end.  The three-kernel form (stx_cost_volume_scale_bwd +
+// stx_scale_channels + stx_cost_volume_bwd on the generic builder backward) read the 850 MB volume of the cfg4 step three
+// times and wrote it once: 1.03 + 0.4 + 0.97 ms.
+__global__ __launch_bounds__(ACV_THREADS) void ac_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ Lc,
+                                                                     const float* __restrict__ Rc, const float* __restrict__ prob,
+                                                                     float* __restrict__ gL, float* __restrict__ gR,
+                                                                     float* __restrict__ gprob, int Cc, int H, int W, int D,
+                                                                     int mask_left) {
+    STX_DYN_SMEM(smem);
+    float* gs = reinterpret_cast<float*>(smem);                       // [D][W]
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x % H, b = blockIdx.x / H;
+    const int CQ = Cc >> 2, CT = 2 * Cc, HW = H * W;
+    for (int k = tid; k < D * W; k += ACV_THREADS) gs[k] = 0.f;
+    __syncthreads();
+    const float* gvrow = gvol + (((size_t)b * D) * H + h) * (size_t)W * CT;      // + d * H * W * CT + w * CT
+    const float* prow = prob + (((size_t)b * D) * H + h) * (size_t)W;            // + d * H * W + w
+    const size_t dstride = (size_t)H * W * CT, pstride = (size_t)H * W;
+    for (int it = tid; it < W * CQ; it += ACV_THREADS) {
+        const int q = it % CQ, w = it / CQ;
+        const size_t fo = ((size_t)b * Cc + 4 * q) * HW + (size_t)h * W + w;
+        // left half: voxel (d, w), channels 4q..4q+3
+        {
+            const float l0 = Lc[fo], l1 = Lc[fo + HW], l2 = Lc[fo + 2 * (size_t)HW], l3 = Lc[fo + 3 * (size_t)HW];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int d0 = 0, d1 = mask_left ? (w + 1 < D ? w + 1 : D) : D;       // (masked left half: only d <= w)
+#pragma unroll 4
+            for (int d = d0; d < d1; ++d) {
+                const float4 g = stx_ld4(gvrow + d * dstride + (size_t)w * CT + 4 * q);
+                const float p = prow[d * pstride + w];
+                atomicAdd(&gs[d * W + w], fmaf(g.x, l0, fmaf(g.y, l1, fmaf(g.z, l2, g.w * l3))));
+                acc.x = fmaf(g.x, p, acc.x); acc.y = fmaf(g.y, p, acc.y); acc.z = fmaf(g.z, p, acc.z); acc.w = fmaf(g.w, p, acc.w);
+            }
+            gL[fo] = acc.x; gL[fo + HW] = acc.y; gL[fo + 2 * (size_t)HW] = acc.z; gL[fo + 3 * (size_t)HW] = acc.w;
+        }
+        // right half: voxel (d, x + d), channels Cc + 4q.. ; x = the item's column
+        {
+            const int x = w;
+            const float r0 = Rc[fo], r1 = Rc[fo + HW], r2 = Rc[fo + 2 * (size_t)HW], r3 = Rc[fo + 3 * (size_t)HW];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int d1 = W - x < D ? W - x : D;
+#pragma unroll 4
+            for (int d = 0; d < d1; ++d) {
+                const float4 g = stx_ld4(gvrow + d * dstride + (size_t)(x + d) * CT + Cc + 4 * q);
+                const float p = prow[d * pstride + x + d];
+                atomicAdd(&gs[d * W + x + d], fmaf(g.x, r0, fmaf(g.y, r1, fmaf(g.z, r2, g.w * r3))));
+                acc.x = fmaf(g.x, p, acc.x); acc.y = fmaf(g.y, p, acc.y); acc.z = fmaf(g.z, p, acc.z); acc.w = fmaf(g.w, p, acc.w);
+            }
+            gR[fo] = acc.x; gR[fo + HW] = acc.y; gR[fo + 2 * (size_t)HW] = acc.z; gR[fo + 3 * (size_t)HW] = acc.w;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < D * W; k += ACV_THREADS) {
+        const int d = k / W, w = k - d * W;
+        gprob[(((size_t)b * D + d) * H + h) * W + w] = gs[k];
+    }
+}
+
 // out = a * s (s broadcast over the channel axis): gvol * prob, the feature-gradient input of the ac-volume
 __global__ __launch_bounds__(ACV_THREADS) void scale_channels_kernel(const float* __restrict__ x,
                                                                       const float* __restrict__ s,
@@ -220,6 +285,20 @@ extern "C" int stx_cost_volume_scale_bwd(const float* gvol, const float* Lc, con
     hipLaunchKernelGGL(cv_scale_bwd_kernel, grid, dim3(ACV_THREADS), 0, (hipStream_t)stream, gvol, Lc, Rc, gscale, D, H,
                        W, Cc, mask_left);
     return stx_check_launch("cost_volume_scale_bwd");
+}
+
+// (the LDS image [D][W] must fit: D * W * 4 <= 150 KiB; larger rows take the three-kernel form)
+extern "C" int stx_ac_volume_bwd(const float* gvol, const float* Lc, const float* Rc, const float* prob, float* gL, float* gR,
+                                 float* gprob, int B, int Cc, int H, int W, int D, int mask_left, void* stream) {
+    stx_begin();
+    STX_REQUIRE(gvol && Lc && Rc && prob && gL && gR && gprob && Cc > 0 && Cc % 4 == 0 && B > 0 && H > 0 && W > 0 && D > 0,
+                "ac_volume_bwd: bad args");
+    const size_t lds = (size_t)D * W * 4;
+    STX_REQUIRE(lds <= 150 * 1024, "ac_volume_bwd: D * W = %d x %d does not fit the LDS image (use the three-kernel form)", D, W);
+    hipFuncSetAttribute((const void*)ac_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ac_volume_bwd_kernel, dim3((unsigned)(B * H)), dim3(ACV_THREADS), lds, (hipStream_t)stream, gvol, Lc, Rc, prob,
+                       gL, gR, gprob, Cc, H, W, D, mask_left);
+    return stx_check_launch("ac_volume_bwd");
 }
 
 extern "C" int stx_scale_channels(const float* x, const float* s, float* out, long long nvox, int C, void* stream) {

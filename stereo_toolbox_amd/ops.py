@@ -661,10 +661,14 @@ class AcVolumeFn(torch.autograd.Function):
         B, D, H, W, CT = gvol.shape
         Cc = Lc.shape[1]
         gprob = torch.empty_like(prob)
+        gL, gR = torch.empty_like(Lc), torch.empty_like(Rc)
+        if D * W * 4 <= 150 * 1024:
+            # one pass over the gradient volume (the [D][W] image of gprob lives in LDS)
+            _call("stx_ac_volume_bwd", _p(gvol), _p(Lc), _p(Rc), _p(prob), _p(gL), _p(gR), _p(gprob), B, Cc, H, W, D, 0)
+            return gL, gR, gprob, None
         _call("stx_cost_volume_scale_bwd", _p(gvol), _p(Lc), _p(Rc), _p(gprob), B, Cc, H, W, D, 0)
         scaled = torch.empty_like(gvol)
         _call("stx_scale_channels", _p(gvol), _p(prob), _p(scaled), B * D * H * W, CT)
-        gL, gR = torch.empty_like(Lc), torch.empty_like(Rc)
         _call("stx_cost_volume_bwd", _p(scaled), None, None, 0, 0, Cc, None, None, _p(gL), _p(gR), B, H, W, D, 0)
         return gL, gR, gprob, None
 

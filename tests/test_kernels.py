@@ -598,6 +598,20 @@ def test_ac_volume_backward(be):
     be.call("stx_cost_volume_bwd", ptr(scaled), None, None, 0, 0, Cc, None, None, ptr(gL), ptr(gR), B, H, W, D, 0)
     _close(gL, Lc.grad, rtol=1e-5)
     _close(gR, Rc.grad, rtol=1e-5)
+    # the same three gradients from ONE pass over the gradient volume (several shapes: batch 2, W < D, 32 channels)
+    for B, Cc, H, W, D in ((1, 8, 3, 21, 9), (2, 32, 2, 37, 12), (1, 4, 2, 7, 10)):
+        Lc = torch.randn(B, Cc, H, W, requires_grad=True)
+        Rc = torch.randn(B, Cc, H, W, requires_grad=True)
+        prob = torch.rand(B, D, H, W, requires_grad=True)
+        ref = prob.unsqueeze(1) * O.build_concat_volume(Lc, Rc, D, mask_left=False)
+        gv = torch.randn(B, D, H, W, 2 * Cc)
+        ref.backward(ncdhw(gv))
+        g1, g2, g3 = be.empty(B, Cc, H, W), be.empty(B, Cc, H, W), be.empty(B, D, H, W)
+        be.call("stx_ac_volume_bwd", ptr(be.dev(gv)), ptr(be.dev(Lc.detach())), ptr(be.dev(Rc.detach())), ptr(be.dev(prob.detach())),
+                ptr(g1), ptr(g2), ptr(g3), B, Cc, H, W, D, 0)
+        _close(g1, Lc.grad, rtol=1e-5)
+        _close(g2, Rc.grad, rtol=1e-5)
+        _close(g3, prob.grad, rtol=1e-5)
 
 
 # ------------------------------------------------------------------------------ CFNet sampled (cascade) volume

@@ -57,6 +57,69 @@ def smooth_l1_multi(preds, gt, maxdisp):
     return masked_smooth_l1_multi(preds, gt, maxdisp, LOSS_W)
 
 
+class PathSplit:
+    """Where a step's GPU time goes, by HIP events on the launching stream (reference template:
+    evaluation/speed_and_memory_test.py:57-75 times the whole forward; here the forward and the backward are cut at the
+    boundary between the stock 2-D feature CNN (MIOpen convolutions, not hand-written) and the
+    hand-written hot path behind it).  Forward: events around `model.aggregate`; backward: a tensor hook on every feature
+    map handed to `aggregate` fires when its gradient exists, i.e. when the hot path's backward is done and the 2-D
+    CNN's is about to start -- the last such event of a step is the cut."""
+    KEYS = ("feature_cnn_fwd", "hot_path_fwd", "loss", "hot_path_bwd", "feature_cnn_bwd", "grad_sync_optimizer")
+
+    def __init__(self, model):
+        self.enabled = False
+        self.steps = []
+        self.cur = None
+        self.model = model
+        orig = model.aggregate
+        split = self
+
+        def aggregate(fl, fr, *a, **k):
+            if not split.enabled:
+                return orig(fl, fr, *a, **k)
+            split.mark("feat_fwd_end")
+            for feats in (fl, fr):
+                for t in (feats.values() if isinstance(feats, dict) else [feats]):
+                    if isinstance(t, torch.Tensor) and t.requires_grad:
+                        t.register_hook(lambda g: (split.mark("hot_bwd_end"), None)[1])
+            out = orig(fl, fr, *a, **k)
+            split.mark("hot_fwd_end")
+            return out
+        model.aggregate = aggregate
+
+    def mark(self, name):
+        if self.enabled and self.cur is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.cur[name] = e                      # (a later mark of the same name replaces the earlier one)
+
+    def begin(self):
+        if self.enabled:
+            self.cur = {}
+            self.mark("start")
+
+    def end(self):
+        if self.enabled and self.cur is not None:
+            self.mark("end")
+            self.steps.append(self.cur)
+            self.cur = None
+
+    def summary(self):
+        order = ("start", "feat_fwd_end", "hot_fwd_end", "loss_end", "hot_bwd_end", "bwd_end", "end")
+        steps = [st for st in self.steps if all(k in st for k in order)]
+        if not steps:
+            return None
+        n = len(steps)
+        out = {}
+        for key, (a, b) in zip(self.KEYS, zip(order[:-1], order[1:])):
+            out[key + "_ms"] = round(sum(st[a].elapsed_time(st[b]) for st in steps) / n, 3)
+        out["feature_cnn_ms"] = round(out["feature_cnn_fwd_ms"] + out["feature_cnn_bwd_ms"], 3)
+        out["hot_path_ms"] = round(out["hot_path_fwd_ms"] + out["hot_path_bwd_ms"], 3)
+        out["method"] = ("HIP events on the launching stream, mean over the timed steps; the backward cut is the last "
+                         "feature-gradient hook of the step (gradient of the cost-volume builder's inputs ready)")
+        return out
+
+
 class KernelTimer:
     """HIP-event timing of selected C-ABI launches on the stream they are issued on (torch's current stream is the
     stream every stx_* entry point is given, stereo_toolbox_amd/ops.py:_stream)."""
@@ -151,7 +214,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, maxdisp, full_cap_s=180.0):
+def cpu_baseline(cfg, maxdisp, full_cap_s=90.0):
     """Oracle (torch-op restatement of the reference path) on the host cores.  First a BOUNDED sample of the config's
     workload (1 warm-up + 1 timed run of one pair at reduced resolution); if the sample says the config's TRUE shape fits
     into `full_cap_s` seconds, one pair at the true shape is run once and `value` is that measurement
@@ -205,10 +268,12 @@ def cpu_baseline(cfg, maxdisp, full_cap_s=180.0):
     what = f"oracle {model_name} {'fwd+bwd' if mode == 'train' else 'eval fwd'}, 1 pair, D={maxdisp}"
     base = {"unit": "pairs/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port"}
     if ts / frac <= full_cap_s:
-        tf = timed(make(Hc, Wc))                       # the config's true shape, once
-        return dict(base, value=round(1.0 / tf, 5), extrapolated=False, sample_s=[round(tf, 2)],
-                    sample=f"{what} at the config's true shape {Hc}x{Wc}: one timed run ({tf:.1f} s) after a warm-up and a "
-                           f"timed run at {Hs}x{Ws} ({ts:.1f} s, which predicted {ts / frac:.0f} s by pixel count)")
+        tfs = [timed(make(Hc, Wc)) for _ in range(2)]  # the config's true shape, twice (the first run also pays the page faults)
+        tf = min(tfs)
+        return dict(base, value=round(1.0 / tf, 5), extrapolated=False, sample_s=[round(t, 2) for t in tfs],
+                    sample=f"{what} at the config's true shape {Hc}x{Wc}: two timed runs ({tfs[0]:.1f} s, {tfs[1]:.1f} s; value "
+                           f"from the faster) after a warm-up and a timed run at {Hs}x{Ws} ({ts:.1f} s, which predicted "
+                           f"{ts / frac:.0f} s by pixel count)")
     return dict(base, value=round(frac / ts, 5), extrapolated=True, sample_s=[round(ts, 2)],
                 sample=f"{what} at {Hs}x{Ws}; 1 warm-up + 1 timed run ({ts:.2f} s); value = measured rate x pixel ratio "
                        f"{frac:.4f} to the {Hc}x{Wc} pair (an extrapolation: the true shape was predicted to take "
@@ -242,20 +307,44 @@ def free_port():
     return p
 
 
-def emulated():
-    """STX_BENCH_EMU=1 (tests only): run the product host code on CPU tensors against the host-emulator build of the
-    kernels with the gloo backend, so that the N > 1 launch path of this file is covered without GPUs."""
-    return os.environ.get("STX_BENCH_EMU") == "1"
+class Platform:
+    """Where the ranks of this benchmark run: one MI355X per rank, RCCL between them.  main() talks to the machine only
+    through this object, so a caller may hand in another one (the launch-path tests do, from the test tree); nothing in
+    this file or in the package knows what such a substitute is made of."""
+    dist_backend = "nccl"
+    script = os.path.abspath(__file__)
+    event_timing = True                      # HIP events per launch inside the timed region
+
+    def device_count(self):
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+    def bind(self, local):
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} device(s) visible")
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def init_process_group(self, dev):
+        dist.init_process_group(self.dist_backend, device_id=dev)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def tuning_db(self):
+        from stereo_toolbox_amd.utils import use_tuning_db
+        return use_tuning_db()               # MIOpen find results of the 2-D CNN's shapes (warm-up time only)
 
 
-def self_spawn(args):
+def self_spawn(args, platform):
     """`python bench.py --gpus N` without a torchrun environment: become the launcher."""
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if not emulated() and have < args.gpus:
+    have = platform.device_count()
+    if have < args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} ROCm device(s) visible on this node; refusing to run "
                          f"{args.gpus} ranks (one process per GPU, no oversubscription)")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), platform.script] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this host driver)
     return subprocess.call(cmd, env=env)
@@ -285,46 +374,30 @@ def pin_host_threads(local, world):
     return info
 
 
-def main(argv=None):
+def main(argv=None, platform=None):
     args = parse_args(argv)
+    platform = platform or Platform()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(self_spawn(args))
+        raise SystemExit(self_spawn(args, platform))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(torch.distributed.run --nproc-per-node {args.gpus})")
-    emu = emulated()
     pin = pin_host_threads(local, world)              # before any thread pool starts
-    if emu:
-        from tests.emu_util import emu_product_path
-        emu_product_path().__enter__()
-        dev = torch.device("cpu")
-    else:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP hot path)")
-        if local >= torch.cuda.device_count():
-            raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} device(s) visible")
-        torch.cuda.set_device(local)
-        dev = torch.device("cuda", local)
+    dev = platform.bind(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if emu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    def sync():
-        if not emu:
-            torch.cuda.synchronize()
+        platform.init_process_group(dev)
+    sync = platform.sync
 
     from stereo_toolbox_amd import models, ops
     from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
-    from stereo_toolbox_amd.utils import fill_state_dict, use_tuning_db
-    tuning_db = None if emu else use_tuning_db()      # MIOpen find results of the 2-D CNN's shapes (warm-up time only)
+    from stereo_toolbox_amd.utils import fill_state_dict
+    tuning_db = platform.tuning_db()
 
     model_name, mode, H, W, B, metric = CONFIGS[args.config]
     H, W, B = args.height or H, args.width or W, args.batch or B
@@ -334,6 +407,7 @@ def main(argv=None):
     g.manual_seed(1000 + rank)                     # every rank draws its own shard (trainer_torchrun.py:88)
     timer = KernelTimer()
 
+    split = None
     if mode == "volume":
         L = torch.randn(B, 32, H // 4, W // 4, device=dev, generator=g)
         R = torch.randn(B, 32, H // 4, W // 4, device=dev, generator=g)
@@ -358,19 +432,29 @@ def main(argv=None):
             gsync = FlatGradSync(model, buckets=args.buckets if overlap else 1, overlap=overlap)
             # the reference's optimizer (tests/train_torchrun.py:57: optim.Adam(model.parameters(), lr)), torch's single-kernel
             # implementation of it (fused=True: same update rule, one launch instead of ~12 multi-tensor launches)
+            want_fused = bool(args.fused_adam) and dev.type == "cuda"
             try:
-                opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph, fused=args.fused_adam and dev.type == "cuda")
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph, fused=want_fused)
+                opt_name = "torch.optim.Adam(fused=True)" if want_fused else "torch.optim.Adam"
             except (RuntimeError, TypeError):
                 opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=args.graph)
+                opt_name = "torch.optim.Adam (fused=True was refused by this build)"
             gt = 190.0 * torch.rand(B, H, W, device=dev, generator=g)
 
             sync_events = []                       # (before, after) finish(): what the gradient exchange adds to the stream
+            split = PathSplit(model) if hasattr(model, "aggregate") and platform.event_timing and not args.graph else None
 
             def step():
                 gsync.detach_grads()
+                if split:
+                    split.begin()
                 preds = model(left, right)
                 loss = smooth_l1_multi(preds, gt, D)
+                if split:
+                    split.mark("loss_end")
                 loss.backward()
+                if split:
+                    split.mark("bwd_end")
                 if timer.enabled and world > 1:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -380,8 +464,11 @@ def main(argv=None):
                 else:
                     gsync.finish()
                 opt.step()
+                if split:
+                    split.end()
         else:
             model.eval()
+            split = None
 
             def step():
                 with torch.no_grad():
@@ -406,7 +493,9 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     sync()
-    timer.enabled = not (args.graph or emu)   # per-launch HIP events cannot be recorded inside a replayed graph
+    if mode == "train" and split:
+        split.enabled = True
+    timer.enabled = platform.event_timing and not args.graph   # per-launch HIP events cannot be recorded inside a replayed graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -420,7 +509,7 @@ def main(argv=None):
         # every rank's own wall time and the time its stream spent in the gradient exchange after backward() (pack + what
         # of the all-reduce did not hide behind the backward pass), gathered for the report; `value` uses the MAX
         exposed = 0.0
-        if mode == "train" and not emu and sync_events:
+        if mode == "train" and platform.event_timing and sync_events:
             exposed = sum(a.elapsed_time(b) for a, b in sync_events) / len(sync_events)
         mine = torch.tensor([dt / args.steps * 1e3, exposed], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -506,12 +595,17 @@ def main(argv=None):
                                      f"flat fp32 buffer, {gsync.nb} overlapped all-reduce range(s)" if gsync.overlap else
                                      "flat fp32 buffer, 1 all-reduce after backward"),
                        "launch": "hipGraph replay" if args.graph else "eager",
-                       **({"optimizer": "torch.optim.Adam(fused=True)" if args.fused_adam else "torch.optim.Adam"} if mode == "train" else {}),
-                       "miopen_user_db": (os.path.relpath(tuning_db, ROOT) if tuning_db and tuning_db.startswith(ROOT)
-                                          else tuning_db)},
+                       **({"optimizer": opt_name} if mode == "train" else {}),
+                       "miopen_user_db": (f"{tuning_db} (private copy of stereo_toolbox_amd/tuning/miopen)" if tuning_db
+                                          else None)},
             "roofline": roof,
         }
         out.update(extra)
+        if mode == "train" and split:
+            ps = split.summary()
+            if ps:
+                out["hot_path_ms"], out["feature_cnn_ms"] = ps["hot_path_ms"], ps["feature_cnn_ms"]
+                out["path_split"] = ps
         if per_rank is not None:
             out["per_rank"] = dict(per_rank, host_threads_per_rank=pin["threads"], host_cores_rank0=pin["cores"])
         if world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,8 @@ Three execution modes of one block  y = act(BN(conv(x)) [+ BN2(conv2(x2))] [+ re
   * training  (train BN): conv emits raw z + batch-stat partials -> bn_finalize -> bn_apply;
   * eval BN with autograd: as training but with the running statistics.
 """
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -90,18 +92,25 @@ class deferred_bn_counters:
     """Context manager for a model forward: the `num_batches_tracked += 1` of every train-mode BatchNorm inside is
     collected and applied as ONE multi-tensor add on exit instead of one 5-us kernel per layer (GwcNet_GC: 26 3-D and
     112 2-D BatchNorm calls per train step = 0.6 ms of serialized launches).  Re-entrant; modules with momentum=None
-    (cumulative average: the factor needs the counter's value) keep the immediate update."""
-    _active = 0
-    _pending = []
+    (cumulative average: the factor needs the counter's value) keep the immediate update.  State is per host thread."""
+    _tls = threading.local()
+
+    @staticmethod
+    def _state():
+        st = deferred_bn_counters._tls
+        if not hasattr(st, "active"):
+            st.active, st.pending = 0, []
+        return st
 
     def __enter__(self):
-        deferred_bn_counters._active += 1
+        self._state().active += 1
         return self
 
     def __exit__(self, *exc):
-        deferred_bn_counters._active -= 1
-        if deferred_bn_counters._active == 0 and deferred_bn_counters._pending:
-            pend, deferred_bn_counters._pending = deferred_bn_counters._pending, []
+        st = self._state()
+        st.active -= 1
+        if st.active == 0 and st.pending:
+            pend, st.pending = st.pending, []
             by_dev = {}
             for t in pend:        # a module that ran twice (left and right view) counts twice: one entry, increment 2
                 d = by_dev.setdefault(t.device, {})
@@ -124,8 +133,9 @@ def _bn_state(bn, partials, count, steps=1):
     if training:
         bn.__dict__.pop("_stx_fold", None)          # the running statistics are about to move
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        if deferred_bn_counters._active and bn.momentum is not None:
-            deferred_bn_counters._pending.extend([bn.num_batches_tracked] * steps)
+        st = deferred_bn_counters._state()
+        if st.active and bn.momentum is not None:
+            st.pending.extend([bn.num_batches_tracked] * steps)
         else:
             bn.num_batches_tracked.add_(steps)
     if bn.momentum is not None:

@@ -169,7 +169,10 @@ __global__ __launch_bounds__(ACV_THREADS) void cv_scale_bwd_kernel(const float* 
 // A workgroup owns one image row (b, h).  Item (w, channel quad) walks d with its four left features in registers, item
 // (x, quad) walks d along the sheared column x + d with its four right features: every element of the gradient volume is read
 // exactly once, by one lane, as part of a 128-byte run of eight lanes; the two halves of gprob meet in an LDS image [D][W]
-// (ds_add_f32) that is written out coalesced at the end.  The three-kernel form (stx_cost_volume_scale_bwd +
+// (ds_add_f32) that is written out coalesced at the end.  The channel quads of a voxel are CQ consecutive lanes with the
+// same trip count: their partial dot products are summed by a fixed-order butterfly (CQ a power of two) and ONE lane adds
+// the half's total, so a cell receives exactly two adds (left + right) into a zero -- commutative, i.e. gprob is bitwise
+// reproducible from run to run.  (Other CQ: one add per quad, order not fixed.)  The three-kernel form (stx_cost_volume_scale_bwd +
 // stx_scale_channels + stx_cost_volume_bwd on the generic builder backward) read the 850 MB volume of the cfg4 step three
 // times and wrote it once: 1.03 + 0.4 + 0.97 ms.
 __global__ __launch_bounds__(ACV_THREADS) void ac_volume_bwd_kernel(const float* __restrict__ gvol, const float* __restrict__ Lc,
@@ -184,40 +187,69 @@ __global__ __launch_bounds__(ACV_THREADS) void ac_volume_bwd_kernel(const float*
     const int CQ = Cc >> 2, CT = 2 * Cc, HW = H * W;
     for (int k = tid; k < D * W; k += ACV_THREADS) gs[k] = 0.f;
     __syncthreads();
+    const bool tree = (CQ & (CQ - 1)) == 0 && CQ <= 64;                          // (ACV_THREADS and 64 are multiples of CQ then)
     const float* gvrow = gvol + (((size_t)b * D) * H + h) * (size_t)W * CT;      // + d * H * W * CT + w * CT
     const float* prow = prob + (((size_t)b * D) * H + h) * (size_t)W;            // + d * H * W + w
     const size_t dstride = (size_t)H * W * CT, pstride = (size_t)H * W;
-    for (int it = tid; it < W * CQ; it += ACV_THREADS) {
-        const int q = it % CQ, w = it / CQ;
+    // (wave-uniform trip counts: the butterfly below needs every lane of a quad group -- and, on the host emulator, of the
+    //  wave -- at the shuffle; lanes beyond their range run predicated)
+    for (int it0 = 0; it0 < W * CQ; it0 += ACV_THREADS) {
+        const int it = it0 + tid;
+        const bool valid = it < W * CQ;
+        const int q = it % CQ, w = valid ? it / CQ : 0;
         const size_t fo = ((size_t)b * Cc + 4 * q) * HW + (size_t)h * W + w;
         // left half: voxel (d, w), channels 4q..4q+3
         {
-            const float l0 = Lc[fo], l1 = Lc[fo + HW], l2 = Lc[fo + 2 * (size_t)HW], l3 = Lc[fo + 3 * (size_t)HW];
+            float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+            if (valid) { l0 = Lc[fo]; l1 = Lc[fo + HW]; l2 = Lc[fo + 2 * (size_t)HW]; l3 = Lc[fo + 3 * (size_t)HW]; }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int d0 = 0, d1 = mask_left ? (w + 1 < D ? w + 1 : D) : D;       // (masked left half: only d <= w)
+            const int d1 = !valid ? 0 : (mask_left ? (w + 1 < D ? w + 1 : D) : D);       // (masked left half: only d <= w)
 #pragma unroll 4
-            for (int d = d0; d < d1; ++d) {
-                const float4 g = stx_ld4(gvrow + d * dstride + (size_t)w * CT + 4 * q);
-                const float p = prow[d * pstride + w];
-                atomicAdd(&gs[d * W + w], fmaf(g.x, l0, fmaf(g.y, l1, fmaf(g.z, l2, g.w * l3))));
+            for (int d = 0; d < D; ++d) {
+                const bool on = d < d1;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                float p = 0.f;
+                if (on) {
+                    g = stx_ld4(gvrow + d * dstride + (size_t)w * CT + 4 * q);
+                    p = prow[d * pstride + w];
+                }
+                float dot = fmaf(g.x, l0, fmaf(g.y, l1, fmaf(g.z, l2, g.w * l3)));
+                if (tree) {
+                    for (int m = 1; m < CQ; m <<= 1) dot += __shfl_xor(dot, m);
+                    if (on && q == 0) atomicAdd(&gs[d * W + w], dot);
+                } else if (on) {
+                    atomicAdd(&gs[d * W + w], dot);
+                }
                 acc.x = fmaf(g.x, p, acc.x); acc.y = fmaf(g.y, p, acc.y); acc.z = fmaf(g.z, p, acc.z); acc.w = fmaf(g.w, p, acc.w);
             }
-            gL[fo] = acc.x; gL[fo + HW] = acc.y; gL[fo + 2 * (size_t)HW] = acc.z; gL[fo + 3 * (size_t)HW] = acc.w;
+            if (valid) { gL[fo] = acc.x; gL[fo + HW] = acc.y; gL[fo + 2 * (size_t)HW] = acc.z; gL[fo + 3 * (size_t)HW] = acc.w; }
         }
         // right half: voxel (d, x + d), channels Cc + 4q.. ; x = the item's column
         {
             const int x = w;
-            const float r0 = Rc[fo], r1 = Rc[fo + HW], r2 = Rc[fo + 2 * (size_t)HW], r3 = Rc[fo + 3 * (size_t)HW];
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            if (valid) { r0 = Rc[fo]; r1 = Rc[fo + HW]; r2 = Rc[fo + 2 * (size_t)HW]; r3 = Rc[fo + 3 * (size_t)HW]; }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int d1 = W - x < D ? W - x : D;
+            const int d1 = !valid ? 0 : (W - x < D ? W - x : D);
 #pragma unroll 4
-            for (int d = 0; d < d1; ++d) {
-                const float4 g = stx_ld4(gvrow + d * dstride + (size_t)(x + d) * CT + Cc + 4 * q);
-                const float p = prow[d * pstride + x + d];
-                atomicAdd(&gs[d * W + x + d], fmaf(g.x, r0, fmaf(g.y, r1, fmaf(g.z, r2, g.w * r3))));
+            for (int d = 0; d < D; ++d) {
+                const bool on = d < d1;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                float p = 0.f;
+                if (on) {
+                    g = stx_ld4(gvrow + d * dstride + (size_t)(x + d) * CT + Cc + 4 * q);
+                    p = prow[d * pstride + x + d];
+                }
+                float dot = fmaf(g.x, r0, fmaf(g.y, r1, fmaf(g.z, r2, g.w * r3)));
+                if (tree) {
+                    for (int m = 1; m < CQ; m <<= 1) dot += __shfl_xor(dot, m);
+                    if (on && q == 0) atomicAdd(&gs[d * W + x + d], dot);
+                } else if (on) {
+                    atomicAdd(&gs[d * W + x + d], dot);
+                }
                 acc.x = fmaf(g.x, p, acc.x); acc.y = fmaf(g.y, p, acc.y); acc.z = fmaf(g.z, p, acc.z); acc.w = fmaf(g.w, p, acc.w);
             }
-            gR[fo] = acc.x; gR[fo + HW] = acc.y; gR[fo + 2 * (size_t)HW] = acc.z; gR[fo + 3 * (size_t)HW] = acc.w;
+            if (valid) { gR[fo] = acc.x; gR[fo + HW] = acc.y; gR[fo + 2 * (size_t)HW] = acc.z; gR[fo + 3 * (size_t)HW] = acc.w; }
         }
     }
     __syncthreads();
@@ -295,7 +327,9 @@ extern "C" int stx_ac_volume_bwd(const float* gvol, const float* Lc, const float
                 "ac_volume_bwd: bad args");
     const size_t lds = (size_t)D * W * 4;
     STX_REQUIRE(lds <= 150 * 1024, "ac_volume_bwd: D * W = %d x %d does not fit the LDS image (use the three-kernel form)", D, W);
-    hipFuncSetAttribute((const void*)ac_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipFuncSetAttribute((const void*)ac_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return stx_set_error(STX_ERR_LAUNCH, "ac_volume_bwd: %d bytes of dynamic LDS refused by this device (the library is "
+                                             "built for the 160 KiB LDS of gfx950)", (int)lds);
     hipLaunchKernelGGL(ac_volume_bwd_kernel, dim3((unsigned)(B * H)), dim3(ACV_THREADS), lds, (hipStream_t)stream, gvol, Lc, Rc, prob,
                        gL, gR, gprob, Cc, H, W, D, mask_left);
     return stx_check_launch("ac_volume_bwd");

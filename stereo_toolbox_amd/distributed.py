@@ -31,7 +31,10 @@ class _Scaled:
 
 
 class FlatGradSync:
-    def __init__(self, model, process_group=None, buckets=1, overlap=False):
+    def __init__(self, model, process_group=None, buckets=1, overlap=False, collective_at_world_1=False):
+        """`collective_at_world_1`: issue the collectives even in a 1-rank group (a world-size-1 RCCL communicator is a
+        real communicator on a real stream) -- lets the hook -> async all-reduce -> finish() ordering be exercised on a
+        single-GPU box; off by default (a lone rank has nothing to exchange)."""
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = process_group
         n = sum(p.numel() for p in self.params)
@@ -62,7 +65,8 @@ class FlatGradSync:
                 self.ranges.append((start, end))
                 start, b = end, b + 1
         self.nb = len(self.ranges)
-        self.overlap = bool(overlap) and self.world > 1
+        self.exchange = self.world > 1 or (bool(collective_at_world_1) and dist.is_available() and dist.is_initialized())
+        self.overlap = bool(overlap) and self.exchange
         self._pending = [0] * self.nb
         self._launched = [False] * self.nb
         self._works = []
@@ -144,7 +148,7 @@ class FlatGradSync:
 
     def all_reduce(self, async_op=False):
         """Average the whole buffer over ranks with a single collective; returns the work handle if async."""
-        if self.world == 1:
+        if not self.exchange:
             return None
         return self._reduce(self.flat, async_op)
 
@@ -176,8 +180,22 @@ class FlatGradSync:
 
 
 def broadcast_parameters(model, src=0, group=None):
-    """Rank-`src` parameters and buffers to all ranks (what the DDP constructor does once)."""
+    """Rank-`src` parameters and buffers to all ranks (what the DDP constructor does once): the floating-point tensors
+    travel packed in ONE flat buffer per dtype (like the gradient buffer above) instead of one collective per tensor
+    (533 for GwcNet_GC); integer buffers (`num_batches_tracked`) in a second one."""
     if not (dist.is_available() and dist.is_initialized()):
         return
+    by_kind = {}
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src, group=group)
+        by_kind.setdefault((t.dtype, t.device), []).append(t.data)
+    for (_, _), ts in by_kind.items():
+        if len(ts) == 1:
+            dist.broadcast(ts[0], src, group=group)
+            continue
+        flat = torch.cat([t.reshape(-1) for t in ts])          # (reshape of a channels_last weight copies in logical order;
+        dist.broadcast(flat, src, group=group)                 #  the copy_ below writes back through the same logical view)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n

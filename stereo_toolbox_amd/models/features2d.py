@@ -18,6 +18,7 @@ Eval mode and CPU tensors keep the stock modules.  STX_FEAT2D_FUSED=0 switches t
 """
 import math
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -39,12 +40,11 @@ def channels_last_weights_(module):
 
 
 def fused_glue(x, *bns):
-    """Whether the BatchNorm2d / ReLU / add glue runs on the in-house kernels for this call: fp32 on a ROCm device (or
-    the emulator in tests) and either every BatchNorm involved in train mode (batch statistics, autograd) or -- inference --
-    every one in eval mode with autograd off (running statistics folded into one scale / shift pass per block)."""
+    """Whether the BatchNorm2d / ReLU / add glue runs on the in-house kernels for this call: fp32 on a ROCm device and
+    either every BatchNorm involved in train mode (batch statistics, autograd) or -- inference -- every one in eval mode with autograd off (running statistics folded into one scale / shift pass per block)."""
     if os.environ.get("STX_FEAT2D_FUSED", "1") == "0":
         return False
-    if x.dtype != torch.float32 or not (x.is_cuda or ops._EMULATED):
+    if x.dtype != torch.float32 or not ops.on_device(x):
         return False
     if not all(isinstance(b, nn.modules.batchnorm._BatchNorm) for b in bns):
         return False
@@ -59,18 +59,23 @@ class view_groups:
     convolutions run on the whole batch, every fused BatchNorm keeps per-view statistics and updates its running
     statistics view after view -- what the reference's separate extractor calls do (gwcnet.py:172-173) -- at half the
     convolution launches and twice the work per launch (the 64-channel layers at 1/4 resolution fill the chip only
-    1.05 times at batch 1)."""
-    n = 1
+    1.05 times at batch 1).  The count is per host thread (two threads running forwards side by side -- DataParallel
+    replicas, an evaluation thread beside training -- must not see each other's grouping)."""
+    _tls = threading.local()
 
     def __init__(self, n):
         self.new = int(n)
 
+    @staticmethod
+    def current():
+        return getattr(view_groups._tls, "n", 1)
+
     def __enter__(self):
-        self.old, view_groups.n = view_groups.n, self.new
+        self.old, view_groups._tls.n = view_groups.current(), self.new
         return self
 
     def __exit__(self, *exc):
-        view_groups.n = self.old
+        view_groups._tls.n = self.old
         return False
 
 
@@ -84,10 +89,13 @@ def conv_bn_act(x, conv, bn, relu=False, residual=None, second=None):
     """act(BN(conv(x)) [+ residual | + BN2(z2)]): MIOpen convolution (channels-last), then for a train-mode BatchNorm2d one
     statistics pass and one fused normalise / add / ReLU pass, for an eval-mode one (inference) the fused pass alone.  x / residual: NCHW-logical; second = (z2, bn2) with z2 the raw
     output of the other branch's convolution.  Returns an NCHW-logical channels_last tensor."""
-    G = view_groups.n
+    G = view_groups.current()
     z = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
     zl = _nhwc(z)
     if not bn.training:
+        if torch.is_grad_enabled() and (z.requires_grad or bn.weight.requires_grad):
+            raise ops.StxError("conv_bn_act: eval-mode BatchNorm under autograd has no fused backward -- gate the call "
+                               "with fused_glue() over every BatchNorm of the block")
         # inference: running statistics folded into (scale, shift), cached per module like the 3-D path's
         sc, sh = _fold(bn)
         if second is not None:
@@ -123,9 +131,15 @@ def convbn_relu_chain(seq, x):
     return x
 
 
+def _chain_bns(seq):
+    """Every BatchNorm of a [convbn, ReLU]* chain: the fused path is taken only when ALL of them agree on the mode (a chain
+    with one frozen BatchNorm under autograd must not take the inference branch of conv_bn_act, which has no backward)."""
+    return [m[1] for m in seq if isinstance(m, nn.Sequential) and len(m) == 2 and isinstance(m[0], nn.Conv2d)]
+
+
 def run_head2d(seq, x):
     """`convbn + ReLU + Conv2d(1x1)` heads (GwcNet lastconv, ACVNet concatconv, PSMNet lastconv)."""
-    if fused_glue(x, seq[0][1]):
+    if fused_glue(x, *_chain_bns(seq)):
         return convbn_relu_chain(seq, x)
     return seq(x)
 
@@ -185,7 +199,7 @@ class ResTrunk(nn.Module):
         return nn.Sequential(*layers)
 
     def trunk(self, x):
-        if fused_glue(x, self.firstconv[0][1]):
+        if fused_glue(x, *_chain_bns(self.firstconv)):
             x = convbn_relu_chain(self.firstconv, x.contiguous(memory_format=torch.channels_last))
         else:
             x = self.firstconv(x)

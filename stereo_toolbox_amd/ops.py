@@ -14,7 +14,6 @@ import torch
 from ._capi import StxError, get_lib
 
 _P = ctypes.c_void_p
-_EMULATED = False      # tests only (tests/emu_util.emu_product_path): CPU tensors are served by the host-emulator build
 
 
 # --------------------------------------------------------------------------------------- plumbing
@@ -34,6 +33,11 @@ def _p(t):
     p = _DevPtr(t.data_ptr())
     p.dev = t.device
     return p
+
+
+def on_device(t):
+    """Whether `t` lives where the kernels of this library run (a ROCm device)."""
+    return t.is_cuda
 
 
 def _chk(t, name, dims=None):

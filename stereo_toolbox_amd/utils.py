@@ -86,18 +86,34 @@ def state_dict_digest(sd):
     return c
 
 
-def use_tuning_db():
-    """Point MIOpen's user find-db / perf-db at the copy shipped in-tree (stereo_toolbox_amd/tuning/miopen: the solver
-    search results of the 2-D feature CNN's convolutions at the benchmarked shapes, recorded on an MI355X with this
-    image's MIOpen), unless MIOPEN_USER_DB_PATH is already set.  With `torch.backends.cudnn.benchmark = True` every
-    process otherwise repeats the exhaustive search (~2.5 GPU-minutes per rank for the GwcNet_GC train step) before its
-    first step; results for shapes the db lacks are searched as usual and appended.  Tuning cache only: it selects among
-    MIOpen's own kernels, the timed region and the numerics contract are unchanged.  Call before the first convolution."""
+def use_tuning_db(cache_root=None):
+    """Point MIOpen's user find-db / perf-db at a private, writable COPY of the one shipped in-tree
+    (stereo_toolbox_amd/tuning/miopen: the solver search results of the 2-D feature CNN's convolutions at the benchmarked
+    shapes, recorded on an MI355X with this image's MIOpen), unless MIOPEN_USER_DB_PATH is already set.  With
+    `torch.backends.cudnn.benchmark = True` every process otherwise repeats the exhaustive search (~2.5 GPU-minutes per
+    rank for the GwcNet_GC train step) before its first step; results for shapes the db lacks are searched as usual and
+    appended -- to the copy (`~/.cache/stereo_toolbox_amd/miopen/rank<LOCAL_RANK>`, one per rank so that concurrent ranks
+    never append to the same file), never to the tracked files: runs do not dirty the source tree and do not depend on
+    what earlier runs appended.  The copy is refreshed whenever the shipped files are newer.  Tuning cache only: it selects
+    among MIOpen's own kernels, the timed region and the numerics contract are unchanged.  Call before the first
+    convolution.  Returns the directory in use (None if nothing could be set up)."""
     import os
+    import shutil
     if os.environ.get("MIOPEN_USER_DB_PATH"):
         return os.environ["MIOPEN_USER_DB_PATH"]
-    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "miopen")
-    if os.path.isdir(d) and os.access(d, os.W_OK):
-        os.environ["MIOPEN_USER_DB_PATH"] = d
-        return d
-    return None
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "miopen")
+    if not os.path.isdir(src):
+        return None
+    root = cache_root or os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
+                                      "stereo_toolbox_amd", "miopen")
+    dst = os.path.join(root, "rank" + os.environ.get("LOCAL_RANK", "0"))
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for name in os.listdir(src):
+            a, b = os.path.join(src, name), os.path.join(dst, name)
+            if os.path.isfile(a) and (not os.path.exists(b) or os.path.getmtime(b) < os.path.getmtime(a)):
+                shutil.copy2(a, b)
+    except OSError:
+        return None
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst

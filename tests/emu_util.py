@@ -40,15 +40,15 @@ def ncdhw(t):
 
 class emu_product_path:
     """Context manager (tests only): run the *product* host code (ops.py / aggregation.py / models)
-    against the host-emulator build of the kernels with CPU tensors, by monkeypatching the three
+    against the host-emulator build of the kernels with CPU tensors, by monkeypatching the four
     device-specific hooks of stereo_toolbox_amd.ops.  Lets the whole autograd wiring be checked
     against the oracle without a GPU.  Nothing in the product references this."""
 
     def __enter__(self):
         from stereo_toolbox_amd import ops
         self.ops = ops
-        self.saved = (ops.get_lib, ops._chk, ops._stream, ops._EMULATED)
-        ops._EMULATED = True
+        self.saved = (ops.get_lib, ops._chk, ops._stream, ops.on_device)
+        ops.on_device = lambda t: True
         lib = emu_lib()
         ops.get_lib = lambda: lib
 
@@ -62,5 +62,5 @@ class emu_product_path:
         return self
 
     def __exit__(self, *exc):
-        self.ops.get_lib, self.ops._chk, self.ops._stream, self.ops._EMULATED = self.saved
+        self.ops.get_lib, self.ops._chk, self.ops._stream, self.ops.on_device = self.saved
         return False

@@ -1,6 +1,6 @@
 """bench.py's launch contract: `--gpus N` spawns N ranks itself when no torchrun environment is present, refuses to
 oversubscribe devices, and rejects a WORLD_SIZE that disagrees with --gpus.  The N = 2 path runs here on CPU: gloo
-backend + the host-emulator build of the kernels (STX_BENCH_EMU=1, a test hook of bench.py), tiny shapes."""
+backend + the host-emulator build of the kernels (tests/bench_emu.py hands bench.main() that platform), tiny shapes."""
 import json
 import os
 import subprocess
@@ -11,12 +11,13 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
+BENCH_EMU = os.path.join(ROOT, "tests", "bench_emu.py")
 
 
-def _run(args, env_extra=None, timeout=900):
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "STX_BENCH_EMU")}
+def _run(args, env_extra=None, timeout=900, script=BENCH):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})
-    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    return subprocess.run([sys.executable, script] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
 
 
 def _json_line(stdout):
@@ -44,7 +45,7 @@ def test_bench_gpus2_spawns_two_gloo_ranks_emulated():
     from tests.emu_util import emu_lib
     emu_lib()                                       # build the emulator library once, before the ranks race for it
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64", "--maxdisp", "32",
-              "--no-cpu-baseline"], {"STX_BENCH_EMU": "1", "OMP_NUM_THREADS": "2"})
+              "--no-cpu-baseline"], {"OMP_NUM_THREADS": "2"}, script=BENCH_EMU)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
@@ -55,7 +56,7 @@ def test_bench_gpus2_spawns_two_gloo_ranks_emulated():
 
 def test_bench_psm_volume_config_emulated():
     r = _run(["--config", "psm_volume", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64", "--maxdisp", "32",
-              "--no-cpu-baseline"], {"STX_BENCH_EMU": "1"})
+              "--no-cpu-baseline"], script=BENCH_EMU)
     assert r.returncode == 0, r.stderr[-3000:]
     out = _json_line(r.stdout)
     assert out["config"]["name"] == "psm_volume" and out["unit"] == "volumes/s" and out["n_gpus"] == 1

@@ -94,6 +94,58 @@ def test_flat_grad_sync_two_ranks_gloo(overlap):
     assert torch.allclose(res[0][1], ref, rtol=1e-5, atol=1e-7)
 
 
+def _cl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
+    model = _net()
+    for m in model:
+        if isinstance(m, nn.Conv2d):
+            m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    if rank != 0:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    broadcast_parameters(model)                    # one flat collective; must restore rank 0's values in logical order
+    sync = FlatGradSync(model, buckets=2, overlap=True)
+    torch.manual_seed(100)
+    data = torch.randn(4, 3, 6, 6)
+    sync.detach_grads()
+    model(data[rank * 2:(rank + 1) * 2]).square().mean().backward()
+    sync.finish()
+    q.put((rank, torch.cat([v.reshape(-1) for v in sync.views]).detach().numpy().copy(),
+           [p.detach().contiguous().numpy().copy() for p in model.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_sync_channels_last_two_ranks_gloo():
+    """CPU twin of the RCCL value test for the layout path: with channels_last conv weights the flat buffer holds each
+    gradient in MEMORY (NHWC) order; values are compared per parameter in logical order against the single-process mean
+    gradient, and the one-collective parameter broadcast must reproduce rank 0's weights."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _net()
+    for got, p in zip(res[1][2], model.parameters()):
+        assert torch.equal(torch.from_numpy(got), p.detach())
+    torch.manual_seed(100)
+    data = torch.randn(4, 3, 6, 6)
+    (0.5 * (model(data[:2]).square().mean() + model(data[2:]).square().mean())).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    for r in range(2):
+        assert torch.allclose(torch.from_numpy(res[r][1]), want, rtol=1e-5, atol=1e-7)
+    assert (res[0][1] == res[1][1]).all()
+
+
 def test_flat_grad_sync_single_process():
     sys.path.insert(0, ROOT)
     from stereo_toolbox_amd.distributed import FlatGradSync
@@ -248,7 +300,8 @@ def _rccl_model_worker(rank, world, port, q):
     O.smooth_l1_multi(preds, gt[rank:rank + 1].to(dev), D, (0.5, 0.5, 0.7, 1.0)).backward()
     sync.finish()
     torch.cuda.synchronize()
-    q.put((rank, sync.flat.detach().cpu().numpy().copy()))
+    # logical (NCHW) element order per parameter: the flat buffer itself holds channels_last parameters in memory order
+    q.put((rank, torch.cat([v.reshape(-1) for v in sync.views]).detach().cpu().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 

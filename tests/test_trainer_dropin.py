@@ -1,0 +1,297 @@
+"""The drop-in modules under the callers SURVEY.md 8(b) names: the reference's own `Trainer.prepare_model`
+(trainer/trainer_torchrun.py:105-123: `SyncBatchNorm.convert_sync_batchnorm` + `DistributedDataParallel`) and torch DDP on a ROCm
+device.
+
+* build container (`-m "not gpu"`): the reference's `Trainer` class is imported from /root/reference (it needs only torch / numpy /
+  tqdm) -- never copied, never shipped; the test skips where that tree does not exist (the GPU box).  Two gloo ranks run the
+  product modules on the host-emulator build of the kernels.  Only `_train_iteration` (trainer_torchrun.py:264-303, the designed
+  extension point: the stock one unpacks IGEV's `(init_disp, disp_preds)`) is overridden.
+* GPU box (`-m gpu`): `init_process_group("nccl", world_size=1)` + `DDP(model.cuda(), device_ids=[0])`, gradients bitwise equal to
+  the un-wrapped module; `find_unused_parameters` for `ACVNet(attn_weights_only=True)`; `FlatGradSync(overlap=True)` with the
+  collectives forced on in the 1-rank RCCL group, so that hook -> async all-reduce (AVG) -> finish() runs on a real stream.
+"""
+import importlib.util
+import os
+import socket
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TRAINER = "/root/reference/stereo_toolbox/trainer/trainer_torchrun.py"
+LOSS_W = (0.5, 0.5, 0.7, 1.0)
+H, W, D = 16, 64, 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _load_reference_trainer():
+    spec = importlib.util.spec_from_file_location("ref_trainer_torchrun", REF_TRAINER)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _filled_model(ctor_name, *a, **k):
+    from stereo_toolbox_amd import models
+    from stereo_toolbox_amd.utils import fill_state_dict
+    m = getattr(models, ctor_name)(*a, **k)
+    sd = m.state_dict()
+    fill_state_dict(sd)
+    m.load_state_dict(sd)
+    return m
+
+
+def _batch(world):
+    from stereo_toolbox_amd.utils import synthetic_tensor
+    return {"left": synthetic_tensor((world, 3, H, W), 1), "right": synthetic_tensor((world, 3, H, W), 2),
+            "gt_disp": synthetic_tensor((world, 1, H, W), 3, lo=0.0, hi=float(D - 2))}
+
+
+def _trainer_worker(rank, world, port, q, sync_bn):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    ref = _load_reference_trainer()
+    from tests.emu_util import emu_product_path
+    from stereo_toolbox_amd.distributed import FlatGradSync, broadcast_parameters
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+
+    class GwcTrainer(ref.Trainer):
+        """The reference trainer with its one designed override: GwcNet returns a list of four predictions."""
+
+        def _train_iteration(self, model, data, optimizer, scheduler, scaler):
+            optimizer.zero_grad()
+            left = data["left"].to(self.device, non_blocking=True)
+            right = data["right"].to(self.device, non_blocking=True)
+            gt = data["gt_disp"].to(self.device, non_blocking=True).squeeze(1)
+            preds = model(left, right)
+            loss = masked_smooth_l1_multi(preds, gt, self.max_disp, LOSS_W)
+            loss.backward()
+            optimizer.step()
+            return loss.item()
+
+    config = types.SimpleNamespace(seed=7, max_disp=D, sync_bn=sync_bn, dist_backend="gloo", amp=False, clip_grad=None,
+                                   find_unused_parameters=False)
+    trainer = GwcTrainer(config)
+    # Without a ROCm device the reference constructor declares the run non-distributed (trainer_torchrun.py:36-41 sets
+    # local_rank = -1).  Put the rank back and run the reference's own set-up methods, so that prepare_model takes its
+    # distributed branch; its `DDP(model, device_ids=[local_rank], ...)` call is handed CPU modules here, for which torch
+    # requires device_ids=None -- the one argument this shim drops.
+    trainer.local_rank = rank
+    trainer.setup_distributed()
+    assert trainer.is_distributed() and trainer.world_size == world and dist.get_backend() == "gloo"
+    real_ddp = ref.DDP
+    ref.DDP = lambda m, device_ids=None, output_device=None, **kw: real_ddp(m, **kw)
+    # torch's DDP constructor also refuses SyncBatchNorm layers inside CPU modules (their stock forward needs a GPU).  The
+    # product never calls that forward (the modules are parameter containers; aggregation._bn_state all-reduces the
+    # statistics itself), so the check -- which only stamps `_specify_ddp_gpu_num(1)` on the layers -- is skipped here.
+    real_ddp._passing_sync_batchnorm_handle = lambda self, module: None
+
+    data = {k: v[rank:rank + 1] for k, v in _batch(world).items()}
+    with emu_product_path():
+        model = _filled_model("GwcNet_GC", D)
+        if rank != 0:                                  # DDP's constructor must restore rank 0's parameters
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.25)
+        model = trainer.prepare_model(model).train()
+        assert isinstance(model, real_ddp)
+        n_sync = sum(isinstance(m, nn.SyncBatchNorm) for m in model.modules())
+        assert (n_sync > 0) == bool(sync_bn)
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)          # (lr 0: the gradients are what is compared)
+        loss = trainer._train_iteration(model, data, opt, None, None)
+        ddp_grads = [p.grad.clone() for p in model.module.parameters()]
+        ddp_stats = {k: v.clone() for k, v in model.module.state_dict().items() if "running" in k or "num_batches" in k}
+
+        # the lean path of bench.py on the same shard: flat buffer + one averaged all-reduce
+        twin = _filled_model("GwcNet_GC", D)
+        if sync_bn:
+            twin = nn.SyncBatchNorm.convert_sync_batchnorm(twin)
+        twin.train()
+        broadcast_parameters(twin)
+        gs = FlatGradSync(twin)
+        gs.detach_grads()
+        preds = twin(data["left"], data["right"])
+        loss2 = masked_smooth_l1_multi(preds, data["gt_disp"].squeeze(1), D, LOSS_W)
+        loss2.backward()
+        gs.finish()
+    worst = 0.0
+    for (name, p), g in zip(twin.named_parameters(), ddp_grads):
+        assert p.grad is not None and g is not None, name
+        err = (p.grad - g).abs().max().item()
+        worst = max(worst, err / (g.abs().max().item() + 1e-12))
+        # same kernels, same shard; DDP averages as (g0/2 + g1/2), the flat path as (g0 + g1)/2: equal up to one rounding
+        assert err <= 1e-6 * g.abs().max().item() + 1e-12, (name, err)
+    tsd = twin.state_dict()
+    for k, v in ddp_stats.items():
+        assert torch.equal(tsd[k], v), k
+    assert int(tsd["dres0.0.1.num_batches_tracked"]) == 1
+    assert abs(loss - loss2.item()) <= 1e-6 * max(1.0, abs(loss))
+    q.put((rank, float(loss), worst, [g.numpy().copy() for g in ddp_grads[:4] + ddp_grads[-4:]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TRAINER), reason="the reference tree exists only in the build container")
+@pytest.mark.parametrize("sync_bn", [False, True], ids=["per_replica_bn", "sync_bn"])
+def test_reference_trainer_prepare_model_two_ranks(sync_bn):
+    """north_star: "drops in under the existing trainer".  GwcNet_GC through the reference's own Trainer.prepare_model
+    (optionally SyncBatchNorm-converted, then DDP-wrapped) on two gloo ranks, one train iteration: every rank ends with
+    the same gradients, they equal the FlatGradSync path's, BatchNorm running statistics and counters agree."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu_util import emu_lib
+    emu_lib()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    import queue as _queue
+    for _ in range(1500):                               # a rank that dies must fail the test at once, not after a timeout
+        try:
+            res.append(q.get(timeout=1.0))
+        except _queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(res) == len(procs):
+            break
+    assert len(res) == len(procs)
+    res.sort(key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][3], res[1][3]):            # DDP left identical averaged gradients on both ranks
+        assert (torch.from_numpy(a) - torch.from_numpy(b)).abs().max().item() == 0.0
+    assert res[0][1] != res[1][1]                      # ... computed from different shards
+
+
+# ----------------------------------------------------------------------------------------------- GPU box: 1-rank RCCL group
+def _init_single_rank_nccl():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+
+
+@pytest.fixture
+def nccl_world1():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    _init_single_rank_nccl()
+    yield
+    dist.destroy_process_group()
+
+
+def _gpu_step(model, Hh=64, Ww=128, Dd=64, B=1):
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    from stereo_toolbox_amd.utils import synthetic_tensor
+    left, right = synthetic_tensor((B, 3, Hh, Ww), 1).cuda(), synthetic_tensor((B, 3, Hh, Ww), 2).cuda()
+    gt = synthetic_tensor((B, Hh, Ww), 3, lo=0.0, hi=float(Dd - 2)).cuda()
+    preds = model(left, right)
+    loss = masked_smooth_l1_multi(preds, gt, Dd, LOSS_W[-len(preds):])
+    loss.backward()
+    return loss
+
+
+@pytest.mark.gpu
+def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1):
+    """`DDP(model.cuda(), device_ids=[0])` over a 1-rank RCCL group (what Trainer.prepare_model builds, :116-121): the
+    reducer's hooks see the ctypes-backed autograd Functions, the deferred BatchNorm counters and the channels_last 2-D
+    weights; gradients must equal the un-wrapped module's bit for bit (deterministic kernels; a 1-rank AVG is the
+    identity), the wrapped module must keep working for a second step, and SyncBatchNorm conversion must not change a
+    1-rank result."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    torch.backends.cudnn.benchmark = False             # same MIOpen algorithm in the three runs below
+    plain = _filled_model("GwcNet_GC", 64).cuda().train()
+    _gpu_step(plain)
+    want = [p.grad.clone() for p in plain.parameters()]
+    want_stats = {k: v.clone() for k, v in plain.state_dict().items() if "running" in k or "num_batches" in k}
+
+    for convert in (False, True):
+        m = _filled_model("GwcNet_GC", 64).cuda()
+        if convert:
+            m = nn.SyncBatchNorm.convert_sync_batchnorm(m)
+        ddp = DDP(m.train(), device_ids=[0], output_device=0, find_unused_parameters=False)
+        _gpu_step(ddp)
+        torch.cuda.synchronize()
+        for (name, p), g in zip(ddp.module.named_parameters(), want):
+            assert p.grad is not None, name
+            assert torch.equal(p.grad, g), (convert, name, (p.grad - g).abs().max().item())
+        sd = ddp.module.state_dict()
+        for k, v in want_stats.items():
+            assert torch.equal(sd[k], v), (convert, k)
+        ddp.zero_grad(set_to_none=True)
+        _gpu_step(ddp)                                 # the reducer re-arms: a second iteration works
+        assert all(p.grad is not None for p in ddp.module.parameters())
+
+
+@pytest.mark.gpu
+def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1):
+    """ACVNet(attn_weights_only=True) leaves the whole main branch without gradients (reference acv.py:164-176,232-245): under
+    DDP that needs `find_unused_parameters=True` (config.find_unused_parameters, trainer_torchrun.py:120), whose graph walk
+    starts at the outputs of the custom Functions."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    torch.backends.cudnn.benchmark = False
+    plain = _filled_model("ACVNet", 64, attn_weights_only=True).cuda().train()
+    _gpu_step(plain)
+    m = _filled_model("ACVNet", 64, attn_weights_only=True).cuda().train()
+    ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True)
+    _gpu_step(ddp)
+    torch.cuda.synchronize()
+    used = 0
+    for (name, p), q in zip(ddp.module.named_parameters(), plain.parameters()):
+        if q.grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+        else:
+            used += 1
+            assert torch.equal(p.grad, q.grad), name
+    assert 0 < used < sum(1 for _ in plain.parameters())
+
+
+@pytest.mark.gpu
+def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1):
+    """The bench's gradient exchange on a real stream: autograd hooks launch asynchronous RCCL AVG all-reduces of the two
+    ranges while backward() is still running, finish() waits for them.  In a 1-rank group the average is the identity, so
+    the flat buffer must equal the plain gradients bit for bit -- and every range must really have gone through RCCL."""
+    from stereo_toolbox_amd.distributed import FlatGradSync
+    torch.backends.cudnn.benchmark = False
+    plain = _filled_model("GwcNet_GC", 64).cuda().train()
+    _gpu_step(plain)
+    m = _filled_model("GwcNet_GC", 64).cuda().train()
+    gs = FlatGradSync(m, buckets=2, overlap=True, collective_at_world_1=True)
+    assert gs.overlap and gs.exchange and gs.nb == 2
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append((t.numel(), k.get("async_op", False), k.get("op")))
+        return orig(t, *a, **k)
+    dist.all_reduce = counting
+    try:
+        for it in range(2):
+            gs.detach_grads() if it == 0 else gs.zero_grad()
+            _gpu_step(m)
+            assert any(gs._launched), "no range was launched from a hook during backward()"
+            gs.finish()
+            torch.cuda.synchronize()
+            assert gs.views_intact() and all(gs._launched)
+            for (name, p), q in zip(m.named_parameters(), plain.parameters()):
+                assert torch.equal(p.grad, q.grad), (it, name)
+    finally:
+        dist.all_reduce = orig
+    assert len(calls) == 4 and all(c[1] for c in calls) and all(c[2] == dist.ReduceOp.AVG for c in calls)
+    assert sum(c[0] for c in calls[:2]) == gs.flat.numel()

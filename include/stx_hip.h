@@ -81,6 +81,10 @@ int stx_dominant_modal_fwd(const float* x, float* out, int B, int D, int HW, voi
  * stx_modal_bwd turns g [B][HW], out and aux into gx [B][D][HW] (zero outside the support). */
 int stx_modal_fwd(const float* x, float* out, float* aux, int B, int D, int HW, int kind, void* stream);
 int stx_modal_bwd(const float* g, const float* out, const float* aux, float* gx, int B, int D, int HW, void* stream);
+/* split_mode(x, maxdisp) -> (mode, mask)  (loss_functions/split_mode.py:9-35): the modal estimators' support mask of
+ * the RAW volume x [B][D][HW] (arg-max, edges of its mode, symmetrised when the arg-max sits >= 3 bins off centre):
+ * mask [B][D][HW] bytes (0 / 1 = the storage of a torch.bool tensor), mode = x * mask (fp32, same shape). */
+int stx_split_mode(const float* x, float* mode, unsigned char* mask, int B, int D, int HW, void* stream);
 /* F.softmax over the disparity axis of [B][D][HW] (ACVNet attention weights, acv.py:196) */
 int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stream);
 

@@ -124,6 +124,13 @@ def _modal_mask(x):
     return torch.where(centred, m1, m2)
 
 
+def split_mode(x, maxdisp=192):
+    """loss_functions/split_mode.py:9-35: (mode, mask) -- the modal mask of the RAW volume and x * mask."""
+    assert x.shape[1] == maxdisp
+    mask = _modal_mask(x)
+    return x * mask, mask
+
+
 def dominant_modal_disparity_estimator(x, maxdisp=192):
     """disparity_estimators/dominant_modal_disparity_estimator.py:35-54: 5-tap box blur along D, the blurred
     volume's main mode and its second mode (main mode removed); keep whichever holds more probability mass."""

@@ -40,6 +40,7 @@ SIGNATURES = {
     "stx_dominant_modal_fwd": [_P, _P, _I, _I, _I, _P],
     "stx_modal_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "stx_modal_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "stx_split_mode": [_P, _P, _P, _I, _I, _I, _P],
     # conv3d.hip
     "stx_conv3d_packed_floats": [_I, _I, _I],
     "stx_conv3d_pack_weight": [_P, _P, _I, _I, _I, _I, _P],

@@ -215,6 +215,54 @@ __global__ __launch_bounds__(ES_WAVE) void dominant_modal_lds_kernel(const float
     if (i < HW) dominant_modal_pixel(col, (size_t)ES_WAVE, out, aux, D, HW, b, i);
 }
 
+// split_mode(x, maxdisp) -> (mode, mask)  (loss_functions/split_mode.py:9-35): the support of modal_mask() taken on the
+// RAW volume (no blur) -- arg-max, outwards to the edges of its mode, symmetrised around the arg-max when it sits 3 or
+// more bins off the centre -- returned as the boolean mask [B][D][HW] and as mode = x * mask.  The column is staged in LDS
+// once; the mask / mode rows are written coalesced (lanes along W).  `x * mask` keeps the reference's arithmetic: x * 1
+// inside, x * 0 outside (a signed zero for negative x, NaN for a non-finite x), bit for bit.
+__device__ __forceinline__ void split_mode_pixel(const float* p, size_t hw, float* __restrict__ mode,
+                                                 unsigned char* __restrict__ mask, int D, int HW, int b, int i) {
+    float best = p[0];
+    int bi = 0;
+    for (int d = 1; d < D; ++d) {
+        const float v = p[(size_t)d * hw];
+        if (v > best) { best = v; bi = d; }
+    }
+    auto f = [&](int d) { return p[(size_t)d * hw]; };
+    const ModeRange m = es_mode_bounds(f, D, bi, best);
+    int c = 2 * m.index - m.hi - m.lo;
+    c = c < 0 ? -c : c;
+    int lo = m.lo, hi = m.hi;
+    if (c >= 3) {
+        const int r = (m.hi - m.index < m.index - m.lo) ? m.hi - m.index : m.index - m.lo;
+        lo = m.index - r; hi = m.index + r;
+    }
+    float* q = mode + (size_t)b * D * HW + i;
+    unsigned char* mk = mask + (size_t)b * D * HW + i;
+    for (int d = 0; d < D; ++d) {
+        const bool in = d >= lo && d <= hi;
+        q[(size_t)d * HW] = p[(size_t)d * hw] * (in ? 1.f : 0.f);
+        mk[(size_t)d * HW] = in ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(ES_THREADS) void split_mode_kernel(const float* __restrict__ x, float* __restrict__ mode,
+                                                               unsigned char* __restrict__ mask, int D, int HW) {
+    const int i = blockIdx.x * ES_THREADS + threadIdx.x, b = blockIdx.y;
+    if (i >= HW) return;
+    split_mode_pixel(x + (size_t)b * D * HW + i, (size_t)HW, mode, mask, D, HW, b, i);
+}
+
+__global__ __launch_bounds__(ES_WAVE) void split_mode_lds_kernel(const float* __restrict__ x, float* __restrict__ mode,
+                                                                unsigned char* __restrict__ mask, int D, int HW) {
+    STX_DYN_SMEM(smem);
+    float* col = reinterpret_cast<float*>(smem) + threadIdx.x;
+    const int i = blockIdx.x * ES_WAVE + threadIdx.x, b = blockIdx.y;
+    const int ic = i < HW ? i : HW - 1;
+    es_stage_column(x + (size_t)b * D * HW + ic, (size_t)HW, D, col);
+    if (i < HW) split_mode_pixel(col, (size_t)ES_WAVE, mode, mask, D, HW, b, i);
+}
+
 // Backward of both estimators.  The support mask is a constant of the graph (`x * mask.data`,
 // unimodal_disparity_estimator.py:20; boolean masks in dominant_modal_disparity_estimator.py:45-49), so with
 // out = sum_d d x_d m_d / S, S = sum_d x_d m_d:   d out / d x_k = m_k (k - out) / S.
@@ -287,4 +335,21 @@ extern "C" int stx_modal_bwd(const float* g, const float* out, const float* aux,
     hipLaunchKernelGGL(modal_bwd_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0, (hipStream_t)stream, g,
                        out, aux, gx, D, HW);
     return stx_check_launch("modal_bwd");
+}
+
+// split_mode (loss_functions/split_mode.py:9-35): mode [B][D][HW] fp32 and mask [B][D][HW] bytes (0 / 1; torch.bool storage)
+extern "C" int stx_split_mode(const float* x, float* mode, unsigned char* mask, int B, int D, int HW, void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && mode && mask && B > 0 && D > 0 && HW > 0, "split_mode: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (D <= ES_LDS_MAX_D) {
+        const size_t lds = (size_t)D * ES_WAVE * sizeof(float);
+        if (lds > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)split_mode_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return stx_set_error(STX_ERR_LAUNCH, "split_mode: %d bytes of dynamic LDS refused by this device", (int)lds);
+        hipLaunchKernelGGL(split_mode_lds_kernel, dim3(stx_cdiv(HW, ES_WAVE), B), dim3(ES_WAVE), lds, st, x, mode, mask, D, HW);
+    } else {
+        hipLaunchKernelGGL(split_mode_kernel, dim3(stx_cdiv(HW, ES_THREADS), B), dim3(ES_THREADS), 0, st, x, mode, mask, D, HW);
+    }
+    return stx_check_launch("split_mode");
 }

@@ -7,7 +7,8 @@ identical state-dict keys.  Four fused gwc+concat volumes (1/4, 1/8, 1/16, 1/32 
 as GwcNet), `hourglassup` (multi-scale fusion) + three hourglasses with Mish activations, classifier tails and the
 trilinear(align_corners=True) + softmax + regression head run in stereo_toolbox_amd/csrc; the 2-D feature CNN and
 the 2-D refinement network (warp, +-24 correlation, dilated residual blocks) stay stock PyTorch-ROCm.
-Status: validated against the oracle on the host emulator; GPU parity tests and timings are next round's work.
+Validated against the oracle on the host emulator and on the GPU (eval parity, full train step: tests/test_models.py
+`test_pcwnet_gc_*`).  PCWNet_G constructs (state-dict compatible) but, as in the reference, cannot run (see forward()).
 """
 import torch
 import torch.nn as nn
@@ -195,9 +196,6 @@ class PCWNet(nn.Module):
 
     def _refine(self, fl, fr, pred3, H, W):
         """reference pcwnet.py:472-485 / 500-512 (2-D, stock torch)."""
-        if "finetune_feature" not in fl:
-            raise ops.StxError("PCWNet without the concat branch has no `finetune_feature` (the reference's PCWNet_G "
-                               "fails at the same place, pcwnet.py:473); use PCWNet_GC")
         pred3 = pred3.unsqueeze(1)
         left = F.interpolate(fl["finetune_feature"], [H, W], mode="bilinear", align_corners=True)
         right = F.interpolate(fr["finetune_feature"], [H, W], mode="bilinear", align_corners=True)
@@ -207,6 +205,14 @@ class PCWNet(nn.Module):
         return self.refinenet3(x, pred3).squeeze(1)
 
     def forward(self, left, right):
+        if not self.use_concat_volume:
+            # PCWNet_G constructs with the reference's parameters (state-dict compatible) but the reference cannot run it:
+            # hourglassup.conv1 is built for 64 + 40 + 24 channels (pcwnet.py:399-406 concatenate gwc + concat volumes) and
+            # `finetune_feature` only exists with the concat branch (:473) -- its own forward raises a channel-mismatch
+            # RuntimeError (tests/golden/state_dict_keys_pcwnet.json records it).  Same contract here, said plainly.
+            raise ops.StxError("PCWNet_G (use_concat_volume=False) cannot run: the reference's architecture needs the concat "
+                               "branch (hourglassup expects 128 = 64 + 40 + 24 input channels, pcwnet.py:399-406; "
+                               "finetune_feature, :473) and its own forward fails the same way; use PCWNet_GC")
         fl, fr = run_pair(self.feature_extraction, left, right, self.training)
         v1 = self._volume(fl, fr, 1, self.maxdisp // 4)
         v2 = self._volume(fl, fr, 2, self.maxdisp // 8)

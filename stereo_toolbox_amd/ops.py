@@ -866,6 +866,42 @@ def dominant_modal_disparity(x, maxdisp):
     return _modal_estimator(1, x, maxdisp)
 
 
+class _SplitModeFn(torch.autograd.Function):
+    """mode = x * mask with the mask a constant of the graph (boolean in the reference): d mode / d x = mask."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, D, H, W = x.shape
+        mode = torch.empty_like(x)
+        mask = torch.empty(B, D, H, W, dtype=torch.bool, device=x.device)
+        _call("stx_split_mode", _p(x), _p(mode), _p(mask), B, D, H * W)
+        ctx.save_for_backward(mask)
+        ctx.mark_non_differentiable(mask)
+        return mode, mask
+
+    @staticmethod
+    def backward(ctx, g, _gmask):
+        (mask,) = ctx.saved_tensors
+        return g * mask
+
+
+def split_mode(x, maxdisp=192):
+    """(mode, mask) of loss_functions/split_mode.py:9-35: the support of the mode around the per-pixel arg-max of the
+    probability volume x [B, D, H, W] (twin of the modal estimators' mask, on the raw volume) as a bool tensor, and
+    mode = x * mask.  One kernel, the volume read once (the reference builds ~12 full-volume temporaries)."""
+    assert len(x.shape) == 4
+    x = x.contiguous()
+    _chk(x, "x", 4)
+    N, D, H, W = x.shape
+    assert D == maxdisp
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SplitModeFn.apply(x)
+    mode = torch.empty_like(x)
+    mask = torch.empty(N, D, H, W, dtype=torch.bool, device=x.device)
+    _call("stx_split_mode", _p(x), _p(mode), _p(mask), N, D, H * W)
+    return mode, mask
+
+
 def softmax_over_d(x):
     """x [B, D, H, W] -> softmax over D."""
     _chk(x, "x", 4)

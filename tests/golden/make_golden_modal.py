@@ -17,6 +17,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference/stereo_toolbox")
 
 import disparity_estimators as ref_est  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("ref_split_mode", "/root/reference/stereo_toolbox/loss_functions/split_mode.py")
+ref_split = importlib.util.module_from_spec(_spec)       # (the package __init__ imports losses that need absent dependencies)
+_spec.loader.exec_module(ref_split)
 
 from stereo_toolbox_amd.utils import synthetic_modal_volume, synthetic_tensor  # noqa: E402
 
@@ -42,6 +47,15 @@ def main():
             gy = synthetic_tensor((B, 1, H, W), 40 + seed)
             fn(x, D).backward(gy)
             out[f"{name}_grad_{tag}"] = x.grad.numpy()
+    # split_mode (loss_functions/split_mode.py:9-35): mode and mask of the raw volume, bit-packed mask
+    for tag, (B, D, H, W, seed) in CASES.items():
+        x = synthetic_modal_volume(B, D, H, W, seed)
+        mode, mask = ref_split.split_mode(x, D)
+        assert mask.dtype == torch.bool
+        out[f"split_mode_{tag}"] = mode.numpy()
+        out[f"split_mask_{tag}"] = np.packbits(mask.numpy().reshape(-1))
+    mode, mask = ref_split.split_mode(peaky, 16)
+    out["split_mode_peaky"], out["split_mask_peaky"] = mode.numpy(), np.packbits(mask.numpy().reshape(-1))
     np.savez_compressed(os.path.join(HERE, "estimators_modal.npz"), **out)
     print("wrote estimators_modal.npz", {k: v.shape for k, v in out.items()})
 

@@ -269,6 +269,23 @@ def test_modal_estimators(be, case):
         assert bad <= (0 if entry == "stx_unimodal_fwd" else B * H * W // 100), f"{entry}: {bad} pixels differ"
 
 
+@pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22), (1, 192, 6, 40, 31), (2, 16, 6, 10, 0),
+                                  (1, 608, 2, 5, 3)])
+def test_split_mode(be, case):
+    """stx_split_mode vs the oracle's split_mode (pinned bitwise to loss_functions/split_mode.py:9-35 by
+    tests/golden/estimators_modal.npz): the boolean mask and mode = x * mask, both exact (comparisons + one multiply)."""
+    from stereo_toolbox_amd.utils import synthetic_modal_volume, synthetic_tensor
+    B, D, H, W, seed = case
+    x = synthetic_modal_volume(B, D, H, W, seed) if seed else torch.softmax(synthetic_tensor((B, D, H, W), 13) * 4, 1)
+    mode = be.empty(B, D, H * W)
+    mask = be.empty(B, D, H * W, dtype=torch.uint8)
+    mask.fill_(7)
+    be.call("stx_split_mode", ptr(be.dev(x)), ptr(mode), ptr(mask), B, D, H * W)
+    want_mode, want_mask = O.split_mode(x, D)
+    assert torch.equal(mask.cpu().view(B, D, H, W), want_mask.to(torch.uint8))
+    assert torch.equal(mode.cpu().view(B, D, H, W), want_mode)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22)])
 def test_modal_estimators_backward(be, case):
     """stx_modal_fwd (+aux) / stx_modal_bwd vs autograd through the oracle (whose gradients are pinned to the

@@ -295,6 +295,24 @@ def test_functional_api(env):
     with pytest.raises(AssertionError):
         with env.ctx():
             build_gwc_volume(da, db, 6, 5)      # C % num_groups != 0 (reference submodule.py:46)
+    # split_mode (loss_functions/split_mode.py:9-35): (mode, mask), differentiable through mode like the reference's x * mask
+    from stereo_toolbox_amd.loss_functions import split_mode
+    xr = xm.clone().requires_grad_()
+    rm, rk = O.split_mode(xr, 32)
+    gy = synthetic_tensor(tuple(xm.shape), 10)
+    rm.backward(gy)
+    xd = xm.to(env.device).requires_grad_()
+    with env.ctx():
+        mode, mask = split_mode(xd, 32)
+        mode.backward(gy.to(env.device))
+        mode2, mask2 = split_mode(xm.to(env.device), 32)        # no-grad path
+    assert mask.dtype == torch.bool and not mask.requires_grad and mode.shape == mask.shape == xm.shape
+    assert torch.equal(mask.cpu(), rk) and torch.equal(mode.detach().cpu(), rm.detach())
+    assert torch.equal(mask2.cpu(), rk) and torch.equal(mode2.cpu(), rm.detach())
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+    with pytest.raises(AssertionError):
+        with env.ctx():
+            split_mode(xm.to(env.device), 31)   # D != maxdisp (reference split_mode.py:11)
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -43,9 +43,26 @@ def test_state_dict_keys_match_reference():
     with open(os.path.join(G, "state_dict_keys_pcwnet.json")) as f:
         ref.update(json.load(f))
     ctors["PCWNet_GC"] = lambda: models.PCWNet_GC(64)
+    ctors["PCWNet_G"] = lambda: models.PCWNet_G(64)            # (pcwnet.py:513; constructs, see test_pcwnet_g_contract)
+    ref.pop("PCWNet_G_reference_forward_error")
     for name, ctor in ctors.items():
         mine = [[k, list(v.shape)] for k, v in ctor().state_dict().items()]
         assert mine == ref[name], name
+
+
+def test_pcwnet_g_contract():
+    """PCWNet_G (reference pcwnet.py:513): state-dict compatible (above) and, like the reference -- whose own forward raises
+    a channel-mismatch RuntimeError, recorded in the fixture by make_golden_pcwnet.py -- not runnable; the drop-in says so
+    with an StxError (a RuntimeError subclass, as in the reference) before launching anything."""
+    from stereo_toolbox_amd import models
+    from stereo_toolbox_amd._capi import StxError
+    with open(os.path.join(G, "state_dict_keys_pcwnet.json")) as f:
+        rec = json.load(f)
+    assert rec["PCWNet_G_reference_forward_error"].startswith("RuntimeError")
+    m = models.PCWNet_G(64).eval()
+    assert issubclass(StxError, RuntimeError)
+    with pytest.raises(StxError, match="PCWNet_G"):
+        m(synthetic_tensor((1, 3, 64, 128), 1), synthetic_tensor((1, 3, 64, 128), 2))
 
 
 def test_builders_bitwise():
@@ -87,6 +104,17 @@ def test_modal_estimators():
     peaky = torch.softmax(synthetic_tensor((2, 16, 6, 10), 13) * 4, 1)
     assert torch.equal(O.unimodal_disparity_estimator(peaky, 16), g["uni_peaky"])
     assert torch.equal(O.dominant_modal_disparity_estimator(peaky, 16), g["dom_peaky"])
+    # split_mode (loss_functions/split_mode.py): mode and boolean mask, bitwise
+    import numpy as np
+    cases = {"a": (2, 32, 5, 9, 21), "b": (1, 48, 4, 7, 22), "c": (1, 192, 3, 5, 23)}
+    for tag, (B, D, H, W, seed) in cases.items():
+        mode, mask = O.split_mode(synthetic_modal_volume(B, D, H, W, seed), D)
+        assert mask.dtype == torch.bool and torch.equal(mode, g[f"split_mode_{tag}"])
+        want = np.unpackbits(g[f"split_mask_{tag}"].numpy())[:mask.numel()].reshape(mask.shape)
+        assert np.array_equal(mask.numpy(), want.astype(bool))
+    mode, mask = O.split_mode(peaky, 16)
+    assert torch.equal(mode, g["split_mode_peaky"])
+    assert np.array_equal(mask.numpy(), np.unpackbits(g["split_mask_peaky"].numpy())[:mask.numel()].reshape(mask.shape).astype(bool))
     # gradients w.r.t. the volume (constant mode mask): oracle autograd vs the reference's
     for tag, (B, D, H, W, seed) in {"a": (2, 32, 5, 9, 21), "b": (1, 48, 4, 7, 22)}.items():
         for name, fn in (("uni", O.unimodal_disparity_estimator), ("dom", O.dominant_modal_disparity_estimator)):

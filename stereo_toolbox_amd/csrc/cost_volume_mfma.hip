@@ -54,6 +54,7 @@ struct CvmArgs {
     float* vol;
     int B, H, W, D, G, Cc, mask_left;
     int nd, nt, macros;             // d-chunks per macro-unit, w-tiles per row, B*H*nt
+    int by_units;                   // work split at unit granularity (a workgroup's run may begin / end inside a macro-unit)
     unsigned magic_rowq, magic_q;   // ceil(2^32 / (16 Q)), ceil(2^32 / Q)
     unsigned magic_tc;              // ceil(2^32 / table columns)
     int nontemporal;
@@ -63,6 +64,8 @@ __device__ __forceinline__ int cvm_xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, k = bid >> 3;
     return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+
+template <int V> struct cvm_int { static constexpr int value = V; };
 
 __device__ __forceinline__ f32x4 cvm_zero4() {
     f32x4 z;
@@ -74,8 +77,15 @@ __device__ __forceinline__ f32x4 cvm_zero4() {
 // dword writes of consecutive columns spread over 8 bank groups
 __host__ __device__ inline int cvm_cs(int Cc) { return ((Cc / 4) & 1) ? Cc + 8 : Cc + 4; }
 
-// ND = compile-time bound of nd (register ring of ND + 1 right tiles)
-template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE>
+// ND = compile-time bound of nd (register ring of ND + 1 right tiles).
+// PF = feature prefetch scheme.  1: the tiles of macro-unit m + 1 are requested during m.  A 16-column tile is one 64-byte
+//      piece of each channel row, i.e. HALF a 128-byte cache line; its other half belongs to the neighbouring tile, which the
+//      same workgroup requests one macro-unit (~10 us, ~40 KB of other lines per CU, a whole L2 turn-over of streamed volume
+//      per XCD) later -- by then the line is gone and is fetched again: FETCH_SIZE 1.76 x the feature bytes (round 3).
+//   2: tiles are requested in PAIRS, both halves of every line back to back (even macro index = even global tile index when
+//      W % 32 == 0 or rows are 64-byte-phase aligned; other shapes only lose the pairing), at the start of every odd
+//      macro-unit for the following two.
+template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE, int PF>
 __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(CvmArgs a) {
     constexpr int NCTHR = NCW * 64, NSTHR = NSW * 64;
     constexpr int KK = CPG / 4;                                   // MFMA K steps per group
@@ -90,12 +100,22 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     const int TC = CVM_T * (nd + 2);                               // table columns in use
     // LDS: two images [16 dd][DS] (double buffer over units) | two table sets [TC cols][CS] (double buffer over macros)
     const int IMG = G ? CVM_T * DS : 0, TAB = Cc ? TC * CS : 0;
-    float* lds = reinterpret_cast<float*>(smem);
+    // (PF = 2: the compute waves' LDS-DMA slots come first -- the DMA destination base travels in M0 -- then images, tables)
+    float* lds = reinterpret_cast<float*>(smem) + (PF == 2 ? NCW * QPW * 8 * KK * 64 : 0);
     float* tabs = lds + 2 * IMG;
 
+    // The workgroup's run: units [u0, u1) of the launch's macros * nd units in (macro, k) order; whole macro-units unless
+    // by_units (2160 macro-units over 256 workgroups = 8 or 9 each: 6.6 % of the chip idles through the last one; 6480 units
+    // = 25 or 26 each: 2.7 %).  A run that begins inside a macro-unit builds the ring like any first macro-unit and skips
+    // the units in front of its range.
     const long long wg = cvm_xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * wg / gridDim.x));
-    const int m1 = __builtin_amdgcn_readfirstlane((int)((long long)a.macros * (wg + 1) / gridDim.x));
+    const long long units = (long long)a.macros * nd;
+    const int u0 = __builtin_amdgcn_readfirstlane(a.by_units ? (int)(units * wg / gridDim.x)
+                                                             : nd * (int)((long long)a.macros * wg / gridDim.x));
+    const int u1 = __builtin_amdgcn_readfirstlane(a.by_units ? (int)(units * (wg + 1) / gridDim.x)
+                                                             : nd * (int)((long long)a.macros * (wg + 1) / gridDim.x));
+    const int m0 = u0 / nd, m1 = u1 > u0 ? (u1 + nd - 1) / nd : m0;   // macro-units touched
+    const int kfirst = u0 - m0 * nd, klast = u1 - (m1 - 1) * nd;  // unit range inside the first / last one
     auto decode = [&](int m, int& b, int& h, int& t) {
         t = m % a.nt;
         const int r = m / a.nt;
@@ -135,8 +155,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
             decode(m, b, h, t);
             const int w0 = t * CVM_T;
             const float* tab = tabs + ((m - m0) & 1) * TAB;          // left table at column 0, right table from column 16
-            for (int k = 0; k < nd; ++k, ++ui) {
-                __syncthreads();                                       // image ui & 1 is complete
+            const int kb = m == m0 ? kfirst : 0, ke = m == m1 - 1 ? klast : nd;
+            for (int k = kb; k < ke; ++k, ++ui) {
+                STX_BARRIER_LDS();                                       // image ui & 1 is complete
                 const int d0 = k * CVM_T;
                 const float* stage = lds + (ui & 1) * IMG;
                 const float* tabr = tab + (CVM_T + CVM_T * (nd - k)) * CS;   // right-table column of x = w0 - d0
@@ -191,11 +212,21 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     // ================= compute waves
     const int xl = lane & 15, kq = lane >> 4;
     const float inv = 1.0f / (float)CPG;
-    // operands of my quads: A = left tile t, Rt[j] = right tile t - j (register ring), nA / nR = prefetched tile t + 1
+    // operands of my quads: A = left tile t, Rt[j] = right tile t - j (register ring), nA / nR = the prefetched tile of the
+    // next macro-unit.  PF = 2: at every odd macro-unit the tiles of the NEXT TWO are requested together -- the even one
+    // into nA / nR, its odd partner (the other half of the same cache lines) by LDS-DMA into this wave's private slot
+    // (2 views x 4 groups x KK dwords x 64 lanes per quad; no second register set: with four waves per SIMD the kernel has 128 VGPRs), from where the
+    // partner's macro-unit reads it back one macro-unit later.
     float A[QPW][4][KK], Rt[ND + 1][QPW][4][KK], nA[QPW][4][KK], nR[QPW][4][KK];
     float ct[NCL];
     unsigned ctok = 0;                                             // validity bits of ct[]
-    bool n_okw = false, n_okx = false;                             // validity of the prefetched tiles' columns
+    bool n_ok = false, d_ok = false;                               // validity of the prefetched tiles' columns (registers / slot)
+    float* dslot = reinterpret_cast<float*>(smem) + wave * (QPW * 8 * KK * 64);        // (PF = 2 only; the host sizes the LDS for it)
+    // (element offsets in 32 bits from the wave-uniform tensor base: one address register per load instead of a pair; the
+    //  host checks that a feature tensor has fewer than 2^30 elements)
+    auto tile_off = [&](int b, int h, int cc, int q) {
+        return (unsigned)(((b * Cg + 4 * q * CPG + kq) * H + h) * W + cc);
+    };
     // one 16-column tile of the gwc features for my quads, branch-free: out-of-image columns read a clamped address and
     // are zeroed by a select where the values are consumed (a select here would make the wave wait for its own prefetch)
     auto load_tile = [&](const float* __restrict__ F, int b, int h, int c0, float (&dst)[QPW][4][KK], bool& ok) {
@@ -206,13 +237,45 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
         for (int j = 0; j < QPW; ++j) {
             const int q = wave + j * NCW;
             if (q < GQ) {                                          // wave-uniform
-                const float* p = F + ((size_t)(b * Cg + 4 * q * CPG + kq) * H + h) * W + cc;
+                const unsigned p = tile_off(b, h, cc, q);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int kk = 0; kk < KK; ++kk) dst[j][g][kk] = p[(size_t)(g * CPG + 4 * kk) * HW];
+                    for (int kk = 0; kk < KK; ++kk) dst[j][g][kk] = (F + (size_t)(g * CPG + 4 * kk) * HW)[p];
             }
         }
+    };
+    // both views of macro-unit m -> nA / nR and, if dma, of macro-unit m + 1 -> the wave's LDS slot: every channel row's
+    // two 64-byte pieces are requested back to back
+    auto load_next = [&](int m, bool dma) {
+        int b0, h0, t0, b1, h1, t1;
+        decode(m, b0, h0, t0);
+        decode(dma ? m + 1 : m, b1, h1, t1);
+        const int col0 = t0 * CVM_T + xl, col1 = t1 * CVM_T + xl;
+        const bool ok0 = col0 < W, ok1 = col1 < W;
+#pragma unroll
+        for (int j = 0; j < QPW; ++j) {
+            const int q = wave + j * NCW;
+            if (q < GQ) {
+                const unsigned p0 = tile_off(b0, h0, ok0 ? col0 : 0, q), p1 = tile_off(b1, h1, ok1 ? col1 : 0, q);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const float* __restrict__ F = v ? a.Rg : a.Lg;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int kk = 0; kk < KK; ++kk) {
+                            const float* __restrict__ Fc = F + (size_t)(g * CPG + 4 * kk) * HW;    // (wave-uniform base)
+                            (v ? nR : nA)[j][g][kk] = Fc[p0];
+                            if (PF == 2) {
+                                if (dma) STX_GLDS4(Fc, p1, dslot + (((j * 2 + v) * 4 + g) * KK + kk) * 64);   // (wave-uniform branch)
+                            }
+                        }
+                }
+            }
+        }
+        n_ok = ok0;
+        if (PF == 2 && dma) d_ok = ok1;
     };
     auto mask_tile = [&](float (&dst)[QPW][4][KK], const float (&src)[QPW][4][KK], bool ok) {
 #pragma unroll
@@ -221,6 +284,21 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) dst[j][g][kk] = ok ? src[j][g][kk] : 0.f;
+    };
+    // the slot's tile -> A / Rt[0] (the LDS-DMA of one macro-unit ago has long landed)
+    auto take_slot = [&]() {
+        STX_GLDS_WAIT();
+#pragma unroll
+        for (int j = 0; j < QPW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const float l = dslot[(((j * 2 + 0) * 4 + g) * KK + kk) * 64 + lane];
+                    const float r = dslot[(((j * 2 + 1) * 4 + g) * KK + kk) * 64 + lane];
+                    A[j][g][kk] = d_ok ? l : 0.f;
+                    Rt[0][j][g][kk] = d_ok ? r : 0.f;
+                }
     };
     // concat features of a macro-unit -> registers: columns [w0, w0+16) of Lc and [w0 - 16 nd, w0 + 16) of Rc
     auto load_tables = [&](int b, int h, int w0) {
@@ -257,14 +335,16 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                 load_tile(a.Rg, b, h, w0 - CVM_T * j, Rt[j], ok);
                 mask_tile(Rt[j], Rt[j], ok);
             }
-            load_tile(a.Lg, b, h, w0, nA, n_okw);
-            load_tile(a.Rg, b, h, w0, nR, n_okx);
+            // the first macro-unit's own tile (registers) and, PF = 2 with an even index, its partner's (slot)
+            load_next(m0, PF == 2 && (m0 & 1) == 0 && m0 + 1 < m1);
         }
         if (Cc) load_tables(b, h, w0);
     }
 
     int ui = 0;
-    for (int m = m0; m < m1; ++m) {
+    // one macro-unit; from_slot (wave-uniform) = its own tiles arrive in the wave's LDS slot instead of nA / nR.  (ONE
+    // instantiation of this body inside the loop: with one per source behind an if / else hipcc spilled 94 registers.)
+    auto macro = [&](int m, bool from_slot) {
         int b, h, t;
         decode(m, b, h, t);
         if (G) {
@@ -273,65 +353,79 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
 #pragma unroll
                 for (int j = ND; j >= 1; --j) mask_tile(Rt[j], Rt[j - 1], t != 0);
             }
-            mask_tile(A, nA, n_okw);
-            mask_tile(Rt[0], nR, n_okx);
+            if (PF == 2 && from_slot) {
+                take_slot();
+            } else {
+                mask_tile(A, nA, n_ok);
+                mask_tile(Rt[0], nR, n_ok);
+            }
         }
         if (Cc) store_tables(tabs + ((m - m0) & 1) * TAB);   // free: the store waves finished macro m-2 before barrier ui-1
-        if (m + 1 < m1) {                                    // tiles of the next macro-unit: in flight during the nd units of this one
+        if (m + 1 < m1) {                                    // tiles of the next macro-unit(s): in flight during the units of this one
             int nb, nh, ntl;
             decode(m + 1, nb, nh, ntl);
             if (G) {
-                load_tile(a.Lg, nb, nh, ntl * CVM_T, nA, n_okw);
-                load_tile(a.Rg, nb, nh, ntl * CVM_T, nR, n_okx);
+                if (PF != 2) load_next(m + 1, false);
+                else if (m & 1) load_next(m + 1, m + 2 < m1);      // registers and slot are free now: the next pair (even, odd)
             }
             if (Cc) load_tables(nb, nh, ntl * CVM_T);
         }
+        const int kb = m == m0 ? kfirst : 0, ke = m == m1 - 1 ? klast : nd;
 #pragma unroll
         for (int k = 0; k < ND; ++k) {
-            if (k < nd) {
+            if (k >= kb && k < ke) {
                 float* stage = lds + (ui & 1) * IMG;           // free: the store waves passed barrier ui-1 after flushing it
                 if (G) {
 #pragma unroll
                     for (int j = 0; j < QPW; ++j) {
                         const int q = wave + j * NCW;
                         if (q < GQ) {
-                            f32x4 acc0[4], acc1[4];
+                            // two groups at a time: 16 accumulator registers live instead of 32 (with four waves per SIMD the
+                            // kernel has 128 VGPRs; the second prefetch slot of PF = 2 needs the room)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) { acc0[g] = cvm_zero4(); acc1[g] = cvm_zero4(); }
+                            for (int gh = 0; gh < 2; ++gh) {
+                                f32x4 acc0[2], acc1[2];
 #pragma unroll
-                            for (int kk = 0; kk < KK; ++kk)
+                                for (int g = 0; g < 2; ++g) { acc0[g] = cvm_zero4(); acc1[g] = cvm_zero4(); }
 #pragma unroll
-                                for (int g = 0; g < 4; ++g) {
-                                    acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], Rt[k][j][g][kk], acc0[g], 0, 0, 0);
-                                    acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][g][kk], Rt[k + 1][j][g][kk], acc1[g], 0, 0, 0);
+                                for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                                    for (int g = 0; g < 2; ++g) {
+                                        acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][2 * gh + g][kk], Rt[k][j][2 * gh + g][kk], acc0[g], 0, 0, 0);
+                                        acc1[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[j][2 * gh + g][kk], Rt[k + 1][j][2 * gh + g][kk], acc1[g], 0, 0, 0);
+                                    }
+                                // lane holds C[w_l = 4 kq + r][x_l = xl] of both tiles: d - 16k = w_l - x_l (tile t-k) or + 16 (tile t-k-1)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int wl = 4 * kq + r;
+                                    const int dd = (wl - xl) & (CVM_T - 1);
+                                    const bool t0 = wl >= xl;
+                                    float2 v;
+                                    v.x = (t0 ? acc0[0][r] : acc1[0][r]) * inv;
+                                    v.y = (t0 ? acc0[1][r] : acc1[1][r]) * inv;
+                                    *reinterpret_cast<float2*>(stage + dd * DS + wl * VS + 4 * q + 2 * gh) = v;
                                 }
-                            // lane holds C[w_l = 4 kq + r][x_l = xl] of both tiles: d - 16k = w_l - x_l (tile t-k) or + 16 (tile t-k-1)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int wl = 4 * kq + r;
-                                const int dd = (wl - xl) & (CVM_T - 1);
-                                const bool t0 = wl >= xl;
-                                float4 v;
-                                v.x = (t0 ? acc0[0][r] : acc1[0][r]) * inv;
-                                v.y = (t0 ? acc0[1][r] : acc1[1][r]) * inv;
-                                v.z = (t0 ? acc0[2][r] : acc1[2][r]) * inv;
-                                v.w = (t0 ? acc0[3][r] : acc1[3][r]) * inv;
-                                stx_st4(stage + dd * DS + wl * VS + 4 * q, v);
                             }
                         }
                     }
                 }
-                __syncthreads();                                   // image ui & 1 handed to the store waves
+                STX_BARRIER_LDS();                                   // image ui & 1 handed to the store waves
                 ++ui;
             }
         }
-    }
+    };
+    // the run's first macro-unit always arrives in registers; after it (PF = 2) even ones do, odd ones come from the slot
+    for (int m = m0; m < m1; ++m) macro(m, PF == 2 && m != m0 && (m & 1));
 }
 
-template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE = false>
+constexpr int CVM_PF_DEFAULT = 2;      // (STX_CV_PF = 1 selects the one-tile-ahead scheme)
+
+template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE = false, int PF = 1>
 int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {
-    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND, SCALE>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = cost_volume_fwd_mfma_kernel<CPG, QPW, NCW, NSW, ND, SCALE, PF>;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return stx_set_error(STX_ERR_LAUNCH, "cost_volume_fwd: %d bytes of dynamic LDS refused by this device", (int)lds);
     int grid = 256 * wgs_per_cu;
     if (stx_tune(STX_TUNE_CV_GRID) > 0) grid = stx_tune(STX_TUNE_CV_GRID);            // tests: force multi-unit runs
     if (grid > a.macros) grid = a.macros;
@@ -353,14 +447,14 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     const int nd = stx_cdiv(D, CVM_T);
     if (nd > 6) return -1;
     const int VS = G + 4, DS = CVM_T * VS + 4, CS = cvm_cs(Cc), TC = CVM_T * (nd + 2);
-    const size_t lds = 2 * ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? TC * CS : 0)) * 4;      // double-buffered image + tables
+    size_t lds = 2 * ((size_t)(G ? CVM_T * DS : 0) + (size_t)(Cc ? TC * CS : 0)) * 4;      // double-buffered image + tables
     if (lds > 160 * 1024) return -1;
     CvmArgs a;
     a.Lg = Lg; a.Rg = Rg; a.Lc = Lc; a.Rc = Rc; a.scale = scale; a.vol = vol;
     a.B = B; a.H = H; a.W = W; a.D = D; a.G = G; a.Cc = Cc; a.mask_left = mask_left;
     a.nd = nd; a.nt = stx_cdiv(W, CVM_T);
     const long long macros = (long long)B * H * a.nt;
-    if (macros >= (1ll << 31) || (long long)B * (Cg > Cc ? Cg : Cc) * H * W >= (1ll << 31)) return -1;
+    if (macros >= (1ll << 31) || (long long)B * (Cg > Cc ? Cg : Cc) * H * W >= (1ll << 30)) return -1;
     if (16ll * H * W * CT >= (1ll << 32)) return -1;      // 32-bit offsets inside a unit's 16 d-planes
     a.macros = (int)macros;
     a.magic_rowq = (unsigned)(0x100000000ULL / (unsigned)(CVM_T * Q) + 1);
@@ -369,19 +463,30 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     // non-temporal stores keep the streamed volume from evicting the (small, re-read) feature rows from L2:
     // measured 0.173 -> 0.141 ms on the GwcNet_GC build
     a.nontemporal = 1;
+    a.by_units = stx_tune(STX_TUNE_CV_UNITS) != 0;
+    int pf = stx_tune(STX_TUNE_CV_PF) == 1 || stx_tune(STX_TUNE_CV_PF) == 2 ? stx_tune(STX_TUNE_CV_PF) : CVM_PF_DEFAULT;
+    // PF = 2 keeps one tile per compute wave in an LDS slot (2 KiB per quad and 4 channels of a group): taken when it fits beside the images
+    const int ncw = GQ <= 4 ? 4 : (GQ <= 10 ? 10 : 8), qpw = GQ <= 10 ? 1 : 2;
+    const size_t slots = (size_t)ncw * qpw * 8 * (cpg / 4) * 64 * 4;
+    if (pf == 2 && GQ > 0 && lds + slots <= 160 * 1024) lds += slots; else pf = 1;
     // workgroups per CU: what the LDS images admit, at most 2; the wave layouts below are sized for <= 16 waves per workgroup
     int wgs = (int)((160 * 1024) / (lds + 1024));
     wgs = wgs < 1 ? 1 : (wgs > 2 ? 2 : wgs);
     hipStream_t st = (hipStream_t)stream;
     // wave layouts <channels per group, quads per compute wave, compute waves, store waves, ring bound> (measured in round 2:
     // fewer store waves are much slower -- 4 instead of 6: 0.21 vs 0.104 ms; two quads per compute wave: no gain)
+#define CVM_GWC(CPG_, ND_, QPW_, NCW_, NSW_)                                                                 \
+    {                                                                                                        \
+        if (pf == 2) return cvm_launch<CPG_, QPW_, NCW_, NSW_, ND_, false, 2>(a, wgs, lds, st);              \
+        return cvm_launch<CPG_, QPW_, NCW_, NSW_, ND_, false, 1>(a, wgs, lds, st);                           \
+    }
 #define CVM_LAYOUT(CPG_, ND_)                                                                        \
     {                                                                                                \
         if (GQ == 0 && scale) return cvm_launch<CPG_, 1, 4, 8, ND_, true>(a, wgs, lds, st);          \
         if (GQ == 0) return cvm_launch<CPG_, 1, 4, 8, ND_>(a, wgs, lds, st);                         \
-        if (GQ <= 4) return cvm_launch<CPG_, 1, 4, 4, ND_>(a, wgs, lds, st);                         \
-        if (GQ <= 10) return cvm_launch<CPG_, 1, 10, 6, ND_>(a, wgs, lds, st);                       \
-        if (GQ <= 16) return cvm_launch<CPG_, 2, 8, 8, ND_>(a, wgs, lds, st);                        \
+        if (GQ <= 4) CVM_GWC(CPG_, ND_, 1, 4, 4)                                                     \
+        if (GQ <= 10) CVM_GWC(CPG_, ND_, 1, 10, 6)                                                   \
+        if (GQ <= 16) CVM_GWC(CPG_, ND_, 2, 8, 8)                                                    \
         return -1;                                                                                   \
     }
 #define CVM_CASE(CPG_)                                          \
@@ -391,5 +496,6 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     CVM_CASE(4) CVM_CASE(8) CVM_CASE(12) CVM_CASE(16)
 #undef CVM_CASE
 #undef CVM_LAYOUT
+#undef CVM_GWC
     return -1;
 }

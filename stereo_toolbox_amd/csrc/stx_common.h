@@ -15,6 +15,9 @@
 #define STX_SCHED_GROUP(mask, n) ((void)0)
 #define STX_OPAQUE_VGPR(x) ((void)0)
 #define STX_TIE3(a, b, c) ((void)0)
+#define STX_BARRIER_LDS() __syncthreads()
+#define STX_GLDS4(base, off, ldsptr) ((void)(((float*)(ldsptr))[threadIdx.x & 63u] = (base)[(off)]))
+#define STX_GLDS_WAIT() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
@@ -30,6 +33,28 @@
 // Orders three VGPR values at this point of the program: everything that produces a, b, c is issued before anything that
 // consumes them afterwards (keeps a prefetched value's s_waitcnt BEHIND the arithmetic it is meant to overlap with).
 #define STX_TIE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+// Workgroup barrier that publishes this wave's LDS reads / writes only (lgkmcnt): __syncthreads() also drains vmcnt whenever
+// an LDS-DMA is in flight (guide 5.4: "the workgroup release inside __syncthreads carries a vmcnt(0)"), which would make a
+// wave wait for its own prefetch at the next barrier.  For kernels whose barriers hand over LDS data written with ds_write.
+#define STX_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// LDS-DMA, one dword per lane: LDS[ldsptr + 4 * lane] = base[off] (ldsptr and base wave-uniform, off = the lane's element
+// index).  Asynchronous, counted by vmcnt.  Written as an asm statement because hipcc treats the builtin's destination as
+// aliasing every other LDS access of the kernel: it then drains vmcnt in front of each ds_write and between the DMAs
+// themselves, i.e. the wave waits for its own prefetch.  The CALLER orders the accesses: STX_GLDS_WAIT() before reading the
+// destination back, and no ds access to it while a DMA is in flight.  M0 (destination base) is saved and restored inside
+// the statement (guide 5.7: the compiler owns M0 and does not preserve it around asm).
+__device__ __forceinline__ void stx_glds4(const float* base, unsigned off, const float* ldsptr) {
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(const __attribute__((address_space(3))) void*)ldsptr);
+    const unsigned boff = off * 4u;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(boff), "s"(base), "s"(dst)
+                 : "memory");
+}
+#define STX_GLDS4(base, off, ldsptr) stx_glds4((base), (off), (ldsptr))
+#define STX_GLDS_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 // Buffer loads through a resource descriptor (wave-uniform base + 32-bit lane offset + wave-uniform offset): lanes whose
 // offset lies outside [0, bytes) read zeros without touching memory -- the bounds check replaces address clamps and
@@ -117,6 +142,8 @@ enum StxTune {
     STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)
     STX_TUNE_CV_OLD,         // STX_CV_OLD         0  cost volume forward: first-generation builders (fallback path) for every shape
     STX_TUNE_CV_GRID,        // STX_CV_GRID        0  cost volume forward: workgroups (tests: multi-unit runs)
+    STX_TUNE_CV_PF,          // STX_CV_PF          0  cost volume forward: feature prefetch, 0 = default (2: line pairs), 1 = one tile ahead
+    STX_TUNE_CV_UNITS,       // STX_CV_UNITS       1  cost volume forward: workgroup runs cut at units (0: at whole macro-units)
     STX_TUNE_CVB_OLD,        // STX_CVB_OLD        0  cost volume backward: first-generation kernels for every shape
     STX_TUNE_CVB_TEAM,       // STX_CVB_TEAM       0  cost volume backward: row-team schedule (one HBM pass, lock-step)
     STX_TUNE_CVB_GRID,       // STX_CVB_GRID       0  cost volume backward: workgroups (tests)

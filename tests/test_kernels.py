@@ -61,12 +61,18 @@ def _cv_inputs(case):
     return Lg, Rg, Lc, Rc, torch.cat(parts, 1)
 
 
-@pytest.mark.parametrize("grid", [2, 3])
-def test_cost_volume_fwd_launch_variants(be, grid, tune):
+@pytest.mark.parametrize("sched", ["pairs_units", "one_ahead_units", "pairs_macros", "one_ahead_macros"])
+@pytest.mark.parametrize("grid", [2, 3, 5])
+def test_cost_volume_fwd_launch_variants(be, grid, sched, tune):
     """The default grid gives small test volumes one unit per workgroup; STX_CV_GRID forces runs of several units per
     workgroup (register rotation of the right-feature tiles along a row, row / chunk changes inside a run, double-buffered
-    LDS image).  All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
+    LDS image).  `sched`: the feature prefetch scheme (line pairs requested every other macro-unit, the odd partner parked
+    in the wave's LDS slot by LDS-DMA / one tile ahead) and runs cut at units (they begin / end INSIDE a macro-unit: with 5
+    workgroups every multi-unit case has such a cut) or at whole macro-units.
+    All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
     tune("STX_CV_GRID", grid)
+    tune("STX_CV_PF", 1 if sched.startswith("one_ahead") else 2)
+    tune("STX_CV_UNITS", 0 if sched.endswith("macros") else 1)
     for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
         B, Cg, G, Cc, H, W, D, ml = case
         Lg, Rg, Lc, Rc, ref = _cv_inputs(case)

@@ -29,21 +29,43 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+COLD = False
+_FLUSH = None
+
+
 def timeit(fn, iters):
+    """Mean launch time.  Default: back-to-back launches (operands up to the 256 MiB Infinity Cache stay resident between
+    iterations: streaming kernels then report more than the HBM rate).  --cold: a 512 MiB fill between iterations evicts the
+    operands from L2 and the Infinity Cache, every launch is timed by its own event pair -- the number a kernel sees inside
+    a train step, where hundreds of MB of other tensors pass between two uses of anything."""
+    global _FLUSH
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    if not COLD:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    if _FLUSH is None:
+        _FLUSH = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
+    evs = []
+    for i in range(iters):
+        _FLUSH.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
+        evs.append((e0, e1))
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return sum(a.elapsed_time(b) for a, b in evs) / iters
 
 
 def report(name, ms, flops=None, nbytes=None):
-    r = {"kernel": name, "ms": round(ms, 4)}
+    r = {"kernel": name, "ms": round(ms, 4), "cache": "cold" if COLD else "warm"}
     if flops:
         r["TFLOPs"] = round(flops / ms / 1e9, 2)
         r["mfma_frac"] = round(flops / ms / 1e9 / 157.3, 3)
@@ -74,6 +96,9 @@ AB_SETS = [
     ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),
     ("cost volume fwd: first-generation fallback kernel", "cost_volume_fwd", {"STX_CV_OLD": 1}),
+    ("cost volume fwd: one tile ahead (half-line requests)", "cost_volume_fwd", {"STX_CV_PF": 1}),
+    ("cost volume fwd: runs cut at whole macro-units", "cost_volume_fwd", {"STX_CV_UNITS": 0}),
+    ("cost volume fwd: one tile ahead + whole macro-units (round 3)", "cost_volume_fwd", {"STX_CV_PF": 1, "STX_CV_UNITS": 0}),
     ("cost volume bwd: first-generation fallback kernel", "cost_volume_bwd", {"STX_CVB_OLD": 1}),
     ("cost volume bwd: team schedule", "cost_volume_bwd", {"STX_CVB_TEAM": 1}),
     ("cost volume bwd: 2 chunk sets in flight", "cost_volume_bwd", {"STX_CVB_NSET": 2}),
@@ -84,6 +109,8 @@ AB_SETS = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ab", action="store_true", help="after the table: re-time the kernels of AB_SETS under their switch")
+    ap.add_argument("--ab-filter", default="", help="substring filter on the A/B set labels")
+    ap.add_argument("--cold", action="store_true", help="cold-cache timing: 512 MiB fill between iterations (see timeit)")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="", help="substring filter(s) on kernel names, comma separated")
     ap.add_argument("--skip-wgrad", action="store_true")
@@ -91,9 +118,13 @@ def main():
     ap.add_argument("--W", type=int, default=960)
     ap.add_argument("--D", type=int, default=192)
     a = ap.parse_args()
+    global COLD
+    COLD = a.cold
     run_table(a, a.only)
     if a.ab:
         for label, flt, env in AB_SETS:
+            if a.ab_filter and a.ab_filter not in label:
+                continue
             print(json.dumps({"ab": label, "tuning": env}), flush=True)
             old = {k: lib.set_tuning(k, v) for k, v in env.items()}
             try:

@@ -97,7 +97,7 @@ int stx_softmax_d_fwd(const float* x, float* y, int B, int D, int HW, void* stre
  *   mode 2: ConvTranspose forward (w = [Cin][Cout][T]) and stride-2 conv dgrad. */
 long long stx_conv3d_packed_floats(int K, int N, int T);
 int stx_conv3d_pack_weight(const float* w, float* wp, int A, int B, int T, int mode, void* stream);
-/* out = act(conv(x) * scale[c] + bias[c] + residual); `relu` is the activation code: 0 none, 1 ReLU, 2 Mish
+/* out = act(conv(x) * scale[c] + bias[c] + residual); `relu` is the activation code: 0 none, 1 ReLU, 2 Mish, 3 LeakyReLU(0.01)
  * (x * tanh(softplus(x)), models/PCWNet/submodule.py:11-18); scale/bias/residual may be NULL; if `stats` != NULL the
  * per-workgroup (sum, sum of squares) of the RAW conv output are written to stats[rows][2][Cout] for train-mode
  * BatchNorm: rows = stx_conv3d_fwd_stat_rows(same shape arguments) -- every one of these rows is written, nothing beyond
@@ -134,6 +134,18 @@ int stx_conv3d_c1_dgrad(const float* gy, const float* w, float* gx, int B, int D
  * backward gx = gy * mish'(x) with x the activation input. */
 int stx_mish_fwd(const float* x, float* y, long long n, void* stream);
 int stx_mish_bwd(const float* gy, const float* x, float* gx, long long n, void* stream);
+/* IGEV-family cost aggregation (models/IGEVStereo/igev_stereo.py:23-100).
+ * stx_depth_to_space: the interleave of ConvTranspose3d(k=4, s=2, p=1)'s eight output-parity classes (igev_stereo.py:44-51):
+ * the transposed convolution runs as ONE 3x3x3 stride-1 convolution with 8*C class-major output channels on stx_conv3d_fwd
+ * (each class: its 8 taps in a zero-filled 27-tap set); y [B][D][H][W][8C] -> out [B][2D][2H][2W][C],
+ * out[2d+pd][2h+ph][2w+pw][c] = y[d][h][w][(4pd+2ph+pw)C + c]; inverse != 0 maps the other way (its backward).  C % 4 == 0. */
+int stx_depth_to_space(const float* y, float* out, int B, int D, int H, int W, int C, int inverse, void* stream);
+/* FeatureAtt (models/IGEVStereo/submodule.py:228-241): out = cv * sigmoid(att), the gate att [B][HW][C] broadcast over the
+ * disparity axis of cv / out [B][D][HW][C]; backward: gcv = g * sigmoid(att), gatt = sum_d g * cv * s (1 - s) (either may be
+ * NULL).  C % 4 == 0. */
+int stx_gate_fwd(const float* cv, const float* att, float* out, int B, int D, long long HW, int C, void* stream);
+int stx_gate_bwd(const float* g, const float* cv, const float* att, float* gcv, float* gatt, int B, int D, long long HW,
+                 int C, void* stream);
 
 /* ---- ACVNet extras (models/ACVNet/acv.py) --------------------------------------------------------------
  * Depth-wise nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d)) (acv.py:109-112,183-187) on a channels-last
@@ -183,7 +195,7 @@ int stx_bn_finalize_groups(const float* partials, int nrows, int C, double count
                            float* running_mean, float* running_var, float momentum, float eps, float* out, int groups,
                            void* stream);
 /* out = act(z1*scale1+shift1 [+ z2*scale2+shift2 | + z2 when scale2 == NULL]) over [nvox][C]; `relu` = activation code
- * (0 none, 1 ReLU, 2 Mish) here and in the backward passes below; Mish is differentiated at the pre-activation value,
+ * (0 none, 1 ReLU, 2 Mish, 3 LeakyReLU(0.01)) here and in the backward passes below; Mish is differentiated at the pre-activation value,
  * which stx_bn_bwd_reduce2 / _apply2 recompute from z and the scale / shift vectors (y = NULL) */
 int stx_bn_apply(const float* z1, const float* scale1, const float* shift1, const float* z2, const float* scale2,
                  const float* shift2, float* out, long long nvox, int C, int relu, int groups, void* stream);

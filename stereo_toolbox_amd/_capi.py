@@ -59,6 +59,9 @@ SIGNATURES = {
     # act.hip
     "stx_mish_fwd": [_P, _P, _L, _P],
     "stx_mish_bwd": [_P, _P, _P, _L, _P],
+    "stx_depth_to_space": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "stx_gate_fwd": [_P, _P, _P, _I, _I, _L, _I, _P],
+    "stx_gate_bwd": [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
     # acv.hip
     "stx_dwconv_hw_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_dwconv_hw_wgrad_workspace_floats": [_I],

@@ -1,4 +1,5 @@
-// Mish activation for gfx950: y = x * tanh(softplus(x)), softplus with torch's threshold of 20
+// Elementwise passes for gfx950: Mish, and the two IGEV-family passes (depth_to_space, FeatureAtt gate) further down.
+// Mish activation: y = x * tanh(softplus(x)), softplus with torch's threshold of 20
 // (reference models/PCWNet/submodule.py:11-18 `Mish`, :178-190 `FMish`; models/CFNet/submodule.py likewise).
 // The PCWNet / CFNet family uses it wherever GwcNet uses ReLU.  First version: a separate
 // streaming pass after the BatchNorm apply (float4 per lane, HBM-bound: read x, write y; backward reads gy and x,
@@ -34,6 +35,78 @@ __global__ __launch_bounds__(ACT_THREADS) void mish_bwd_kernel(const float* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// IGEV-family cost aggregation (models/IGEVStereo/igev_stereo.py:23-100, submodule.py:228-241).
+//
+// depth_to_space: ConvTranspose3d(k = 4, s = 2, p = 1) is eight output-parity classes of 2 x 2 x 2 taps each
+//   out[2j + p] = x[j] w[1 + p] + x[j - 1 + 2p] w[3 - 3p]                       (per axis, p = 0 / 1)
+// and runs on the 3 x 3 x 3 stride-1 MFMA kernels as ONE convolution with 8 x C class-major output channels (the class's
+// 8 taps in a zero-filled 27-tap set, built on the host); this pass interleaves the classes:
+//   out[b][2d + pd][2h + ph][2w + pw][c] = y[b][d][h][w][(4 pd + 2 ph + pw) C + c],
+// optionally as act(y * scale[col] + shift[col]) (eval-mode BatchNorm folded, applied here so that the convolution's own
+// epilogue stays the raw straight-line one).  inverse = 1: space_to_depth, the backward of the same map.
+__global__ __launch_bounds__(ACT_THREADS) void depth_to_space_kernel(const float* __restrict__ y, float* __restrict__ out,
+                                                                    int D, int H, int W, int CQ, size_t nquads, int inverse) {
+    // one float4 of the FINE tensor per item: index (b, dd, hh, ww, cq)
+    for (size_t i = (size_t)blockIdx.x * ACT_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * ACT_THREADS) {
+        size_t r = i;
+        const int cq = (int)(r % CQ); r /= CQ;
+        const int ww = (int)(r % (2 * W)); r /= (2 * W);
+        const int hh = (int)(r % (2 * H)); r /= (2 * H);
+        const int dd = (int)(r % (2 * D));
+        const size_t b = r / (2 * D);
+        const int cls = ((dd & 1) << 2) | ((hh & 1) << 1) | (ww & 1);
+        const size_t coarse = ((((b * D + (dd >> 1)) * H + (hh >> 1)) * W + (ww >> 1)) * 8 + cls) * CQ + cq;
+        if (inverse) stx_st4(out + coarse * 4, stx_ld4(y + i * 4));
+        else stx_st4(out + i * 4, stx_ld4(y + coarse * 4));
+    }
+}
+
+// FeatureAtt (submodule.py:228-241): cv[b][d][h][w][c] * sigmoid(att[b][h][w][c]) -- the gate is broadcast over the
+// disparity axis.  One item = (b, hw, channel quad) walking d: the gate is computed once per item, the gate's gradient
+// sum_d g * cv * s (1 - s) is a sequential (deterministic) sum in registers.
+__device__ __forceinline__ float gate_sigmoid(float x) { return 1.f / (1.f + stx_exp(-x)); }
+
+__global__ __launch_bounds__(ACT_THREADS) void gate_fwd_kernel(const float* __restrict__ cv, const float* __restrict__ att,
+                                                              float* __restrict__ out, int D, size_t HW, int CQ, size_t nitems) {
+    for (size_t i = (size_t)blockIdx.x * ACT_THREADS + threadIdx.x; i < nitems; i += (size_t)gridDim.x * ACT_THREADS) {
+        const size_t hwq = i % (HW * CQ), b = i / (HW * CQ);
+        const float4 a = stx_ld4(att + i * 4);
+        float4 s;
+        s.x = gate_sigmoid(a.x); s.y = gate_sigmoid(a.y); s.z = gate_sigmoid(a.z); s.w = gate_sigmoid(a.w);
+        const size_t base = b * D * HW * CQ + hwq;
+        for (int d = 0; d < D; ++d) {
+            const size_t o = (base + (size_t)d * HW * CQ) * 4;
+            float4 v = stx_ld4(cv + o);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            stx_st4(out + o, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(ACT_THREADS) void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ cv,
+                                                              const float* __restrict__ att, float* __restrict__ gcv,
+                                                              float* __restrict__ gatt, int D, size_t HW, int CQ,
+                                                              size_t nitems) {
+    for (size_t i = (size_t)blockIdx.x * ACT_THREADS + threadIdx.x; i < nitems; i += (size_t)gridDim.x * ACT_THREADS) {
+        const size_t hwq = i % (HW * CQ), b = i / (HW * CQ);
+        const float4 a = stx_ld4(att + i * 4);
+        float4 s;
+        s.x = gate_sigmoid(a.x); s.y = gate_sigmoid(a.y); s.z = gate_sigmoid(a.z); s.w = gate_sigmoid(a.w);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t base = b * D * HW * CQ + hwq;
+        for (int d = 0; d < D; ++d) {
+            const size_t o = (base + (size_t)d * HW * CQ) * 4;
+            const float4 gg = stx_ld4(g + o), v = stx_ld4(cv + o);
+            acc.x = fmaf(gg.x, v.x, acc.x); acc.y = fmaf(gg.y, v.y, acc.y);
+            acc.z = fmaf(gg.z, v.z, acc.z); acc.w = fmaf(gg.w, v.w, acc.w);
+            if (gcv) stx_st4(gcv + o, make_float4(gg.x * s.x, gg.y * s.y, gg.z * s.z, gg.w * s.w));
+        }
+        if (gatt) stx_st4(gatt + i * 4, make_float4(acc.x * s.x * (1.f - s.x), acc.y * s.y * (1.f - s.y),
+                                                     acc.z * s.z * (1.f - s.z), acc.w * s.w * (1.f - s.w)));
+    }
+}
+
 int act_grid(size_t nquads) {
     const size_t g = (nquads + ACT_THREADS - 1) / ACT_THREADS;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -57,4 +130,37 @@ extern "C" int stx_mish_bwd(const float* gy, const float* x, float* gx, long lon
     hipLaunchKernelGGL(mish_bwd_kernel, dim3(act_grid((size_t)n / 4)), dim3(ACT_THREADS), 0, (hipStream_t)stream, gy, x,
                        gx, (size_t)n / 4);
     return stx_check_launch("mish_bwd");
+}
+
+// y [B][D][H][W][8 C] (class-major channels) -> out [B][2D][2H][2W][C]; inverse != 0: the other way (out is the coarse
+// tensor).  C % 4 == 0.  See depth_to_space_kernel: the interleave of ConvTranspose3d(k4, s2, p1)'s parity classes.
+extern "C" int stx_depth_to_space(const float* y, float* out, int B, int D, int H, int W, int C, int inverse, void* stream) {
+    stx_begin();
+    STX_REQUIRE(y && out && B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "depth_to_space: bad arguments (C=%d)", C);
+    const size_t nquads = (size_t)B * D * H * W * 8 * (C / 4);
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(act_grid(nquads)), dim3(ACT_THREADS), 0, (hipStream_t)stream, y, out, D, H,
+                       W, C / 4, nquads, inverse);
+    return stx_check_launch("depth_to_space");
+}
+
+// FeatureAtt gate (IGEVStereo/submodule.py:228-241): out = cv * sigmoid(att), cv / out [B][D][HW][C], att [B][HW][C]
+extern "C" int stx_gate_fwd(const float* cv, const float* att, float* out, int B, int D, long long HW, int C, void* stream) {
+    stx_begin();
+    STX_REQUIRE(cv && att && out && B > 0 && D > 0 && HW > 0 && C > 0 && C % 4 == 0, "gate_fwd: bad arguments (C=%d)", C);
+    const size_t nitems = (size_t)B * HW * (C / 4);
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(act_grid(nitems)), dim3(ACT_THREADS), 0, (hipStream_t)stream, cv, att, out, D,
+                       (size_t)HW, C / 4, nitems);
+    return stx_check_launch("gate_fwd");
+}
+
+// gcv = g * sigmoid(att) (may be NULL), gatt = sum_d g * cv * s (1 - s) (may be NULL); cv = the gate's INPUT volume
+extern "C" int stx_gate_bwd(const float* g, const float* cv, const float* att, float* gcv, float* gatt, int B, int D,
+                            long long HW, int C, void* stream) {
+    stx_begin();
+    STX_REQUIRE(g && cv && att && (gcv || gatt) && B > 0 && D > 0 && HW > 0 && C > 0 && C % 4 == 0,
+                "gate_bwd: bad arguments (C=%d)", C);
+    const size_t nitems = (size_t)B * HW * (C / 4);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(act_grid(nitems)), dim3(ACT_THREADS), 0, (hipStream_t)stream, g, cv, att, gcv,
+                       gatt, D, (size_t)HW, C / 4, nitems);
+    return stx_check_launch("gate_bwd");
 }

@@ -219,12 +219,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
             } else {
                 yy = stx_ld4(y + o);
             }
-            if (relu == 2) {                                    // Mish: yy is the pre-activation value (remask path only)
-                g.x *= stx_mish_grad(yy.x); g.y *= stx_mish_grad(yy.y); g.z *= stx_mish_grad(yy.z); g.w *= stx_mish_grad(yy.w);
-            } else {
-                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-            }
+            // (Mish: yy is the pre-activation value, remask path only; ReLU / LeakyReLU: either value has the sign)
+            g.x = stx_act_bwd(g.x, yy.x, relu); g.y = stx_act_bwd(g.y, yy.y, relu);
+            g.z = stx_act_bwd(g.z, yy.z, relu); g.w = stx_act_bwd(g.w, yy.w, relu);
         }
         s[0] += g.x; s[1] += g.y; s[2] += g.z; s[3] += g.w;
         s[4] = fmaf(g.x, (a.x - m1.x) * i1.x, s[4]); s[5] = fmaf(g.y, (a.y - m1.y) * i1.y, s[5]);
@@ -343,12 +340,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
             } else {
                 yy = stx_ld4(y + i * 4);
             }
-            if (relu == 2) {                                    // Mish: yy is the pre-activation value (remask path only)
-                g.x *= stx_mish_grad(yy.x); g.y *= stx_mish_grad(yy.y); g.z *= stx_mish_grad(yy.z); g.w *= stx_mish_grad(yy.w);
-            } else {
-                g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-                g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
-            }
+            // (Mish: yy is the pre-activation value, remask path only; ReLU / LeakyReLU: either value has the sign)
+            g.x = stx_act_bwd(g.x, yy.x, relu); g.y = stx_act_bwd(g.y, yy.y, relu);
+            g.z = stx_act_bwd(g.z, yy.z, relu); g.w = stx_act_bwd(g.w, yy.w, relu);
         }
         if (gout) stx_st4(gout + i * 4, g);
         const float4 sg = stx_ld4(sums + c);

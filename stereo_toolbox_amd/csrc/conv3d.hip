@@ -44,7 +44,7 @@ struct ConvArgs {
     float* stats;           // [nblocks][2][Cout] partial sums of raw output, or null
     int Di, Hi, Wi, Cin;
     int Do, Ho, Wo, Cout;
-    int relu;               // activation code: 0 none, 1 ReLU, 2 Mish (stx_act)
+    int relu;               // activation code: 0 none, 1 ReLU, 2 Mish, 3 LeakyReLU (stx_act)
     int nDt, nHt, nWt;
 };
 
@@ -118,7 +118,7 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32
                                                     int nvalid_rows, int n, float sc, float bs, int lane,
                                                     float& s1, float& s2) {
     const int half = lane >> 5;
-    if (a.relu != 2) {
+    if (a.relu < 2) {                             // (Mish / LeakyReLU: the general form below)
         const unsigned rowb = (unsigned)rstride * (unsigned)a.Cout * 4u;          // bytes between two rows of the block
         const unsigned span = 32u * rowb;                                          // (row 31 ends inside: n < Cout)
         const stx_bufrsrc ors = stx_make_rsrc(a.out + vox0 * a.Cout, span);
@@ -1511,7 +1511,7 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
                         m.c.scale = nullptr; m.c.bias = nullptr; m.c.residual = nullptr; m.c.stats = nullptr; m.c.relu = 0;
                     }
                     // (the straight-line epilogues read the partial sums through the OUTPUT descriptor: acc_in is `out`)
-                    const bool plain = epi_fast && !(m.c.residual && m.acc_in) && m.c.relu != 2;
+                    const bool plain = epi_fast && !(m.c.residual && m.acc_in) && m.c.relu < 2;
                     const bool raw = !m.acc_in && !m.c.residual && !m.c.scale && !m.c.bias && m.c.relu == 0;
                     hipLaunchKernelGGL(plain ? (raw ? (whole && m.ncout == 32 ? mk_rawf : mk_raw) : m.acc_in ? mk_acc
                                                         : (m.c.residual ? mk_res : mk_plain)) : mk,

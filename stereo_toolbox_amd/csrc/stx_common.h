@@ -153,7 +153,8 @@ enum StxTune {
 };
 int stx_tune(StxTune id);
 
-// Activation code of the conv / BN-apply epilogues (the C-ABI's `relu` argument): 0 none, 1 ReLU, 2 Mish.
+// Activation code of the conv / BN-apply epilogues (the C-ABI's `relu` argument): 0 none, 1 ReLU, 2 Mish,
+// 3 LeakyReLU(0.01) (IGEV-family `BasicConv`, models/IGEVStereo/submodule.py:32-37: `nn.LeakyReLU()`, torch's default slope).
 // Mish (reference models/PCWNet/submodule.py:11-18): x * tanh(softplus(x)) with tanh(log(1 + e^x)) = n / (n + 2),
 // n = e^x (e^x + 2) -- one exp and one division, no cancellation (n >= 0); above torch's softplus threshold of 20 the
 // factor is 1.  `w` returns e^min(x, 20) for the derivative.
@@ -173,8 +174,15 @@ __device__ __forceinline__ float stx_mish_grad(float x) {
     const float ds = x > 20.f ? 1.f : __fdividef(w, 1.f + w);
     return t + x * (1.f - t * t) * ds;
 }
+#define STX_LEAKY_SLOPE 0.01f
 __device__ __forceinline__ float stx_act(float v, int code) {
-    return code == 1 ? (v > 0.f ? v : 0.f) : (code == 2 ? stx_mish(v) : v);
+    return code == 1 ? (v > 0.f ? v : 0.f) : (code == 2 ? stx_mish(v) : (code == 3 ? (v > 0.f ? v : STX_LEAKY_SLOPE * v) : v));
+}
+// gradient through the activation: g * act'(.) with `t` the value the sign is taken from -- for ReLU / LeakyReLU the
+// activated OR the pre-activation value (same sign; torch differentiates both as `x > 0 ? g : slope * g`), for Mish the
+// pre-activation value
+__device__ __forceinline__ float stx_act_bwd(float g, float t, int code) {
+    return code == 2 ? g * stx_mish_grad(t) : (code == 3 ? (t > 0.f ? g : STX_LEAKY_SLOPE * g) : (t > 0.f ? g : 0.f));
 }
 
 __device__ __forceinline__ float4 stx_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

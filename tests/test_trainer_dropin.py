@@ -196,6 +196,30 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
+def _same_grads(named_params, want, what, parity_log=None):
+    """Gradients of two runs of the same step.  The hand-written kernels are deterministic, so every parameter behind the 2-D
+    feature CNN must agree BIT FOR BIT; the 2-D CNN's own parameters go through MIOpen's backward-weights kernels (split-K
+    with atomics: run-to-run differences of a few ulp), for them a tight tolerance."""
+    worst2d, n_exact, n = 0.0, 0, 0
+    for (name, p), g in zip(named_params, want):
+        if g is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, (what, name)
+            continue
+        assert p.grad is not None, (what, name)
+        n += 1
+        if torch.equal(p.grad, g):
+            n_exact += 1
+            continue
+        err = (p.grad - g).abs().max().item()
+        scale = g.abs().max().item()
+        assert name.startswith("feature_extraction."), (what, name, err, scale)
+        worst2d = max(worst2d, err / (scale + 1e-30))
+        assert err <= 1e-4 * scale + 1e-9, (what, name, err, scale)
+    if parity_log is not None:
+        parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst2d)
+    return n_exact, n
+
+
 def _gpu_step(model, Hh=64, Ww=128, Dd=64, B=1):
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi
     from stereo_toolbox_amd.utils import synthetic_tensor
@@ -208,7 +232,7 @@ def _gpu_step(model, Hh=64, Ww=128, Dd=64, B=1):
 
 
 @pytest.mark.gpu
-def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1):
+def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1, parity_log):
     """`DDP(model.cuda(), device_ids=[0])` over a 1-rank RCCL group (what Trainer.prepare_model builds, :116-121): the
     reducer's hooks see the ctypes-backed autograd Functions, the deferred BatchNorm counters and the channels_last 2-D
     weights; gradients must equal the un-wrapped module's bit for bit (deterministic kernels; a 1-rank AVG is the
@@ -228,19 +252,17 @@ def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1):
         ddp = DDP(m.train(), device_ids=[0], output_device=0, find_unused_parameters=False)
         _gpu_step(ddp)
         torch.cuda.synchronize()
-        for (name, p), g in zip(ddp.module.named_parameters(), want):
-            assert p.grad is not None, name
-            assert torch.equal(p.grad, g), (convert, name, (p.grad - g).abs().max().item())
+        _same_grads(ddp.module.named_parameters(), want, f"ddp_world1[sync_bn_converted={convert}]", parity_log)
         sd = ddp.module.state_dict()
         for k, v in want_stats.items():
-            assert torch.equal(sd[k], v), (convert, k)
+            assert torch.equal(sd[k], v) or (sd[k] - v).abs().max().item() <= 1e-6 * (1 + v.abs().max().item()), (convert, k)
         ddp.zero_grad(set_to_none=True)
         _gpu_step(ddp)                                 # the reducer re-arms: a second iteration works
         assert all(p.grad is not None for p in ddp.module.parameters())
 
 
 @pytest.mark.gpu
-def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1):
+def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1, parity_log):
     """ACVNet(attn_weights_only=True) leaves the whole main branch without gradients (reference acv.py:164-176,232-245): under
     DDP that needs `find_unused_parameters=True` (config.find_unused_parameters, trainer_torchrun.py:120), whose graph walk
     starts at the outputs of the custom Functions."""
@@ -252,21 +274,17 @@ def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1):
     ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True)
     _gpu_step(ddp)
     torch.cuda.synchronize()
-    used = 0
-    for (name, p), q in zip(ddp.module.named_parameters(), plain.parameters()):
-        if q.grad is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
-        else:
-            used += 1
-            assert torch.equal(p.grad, q.grad), name
+    _, used = _same_grads(ddp.module.named_parameters(), [q.grad for q in plain.parameters()], "ddp_world1_acv_attention_only",
+                          parity_log)
     assert 0 < used < sum(1 for _ in plain.parameters())
 
 
 @pytest.mark.gpu
-def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1):
+def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
     """The bench's gradient exchange on a real stream: autograd hooks launch asynchronous RCCL AVG all-reduces of the two
     ranges while backward() is still running, finish() waits for them.  In a 1-rank group the average is the identity, so
-    the flat buffer must equal the plain gradients bit for bit -- and every range must really have gone through RCCL."""
+    the flat buffer must equal the plain gradients (bit for bit behind the 2-D CNN) -- and every range must really have gone
+    through RCCL."""
     from stereo_toolbox_amd.distributed import FlatGradSync
     torch.backends.cudnn.benchmark = False
     plain = _filled_model("GwcNet_GC", 64).cuda().train()
@@ -289,8 +307,8 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1):
             gs.finish()
             torch.cuda.synchronize()
             assert gs.views_intact() and all(gs._launched)
-            for (name, p), q in zip(m.named_parameters(), plain.parameters()):
-                assert torch.equal(p.grad, q.grad), (it, name)
+            _same_grads(m.named_parameters(), [q.grad for q in plain.parameters()], f"flat_grad_sync_overlap_world1[step{it}]",
+                        parity_log)
     finally:
         dist.all_reduce = orig
     assert len(calls) == 4 and all(c[1] for c in calls) and all(c[2] == dist.ReduceOp.AVG for c in calls)

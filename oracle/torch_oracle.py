@@ -667,6 +667,61 @@ def igev_init_disparity(cost, maxdisp):
     return disparity_regression(prob, maxdisp // 4, keepdim=True)
 
 
+def igev_basic_conv(cx, x, p, is_3d=True, deconv=False, bn=True, relu=True, stride=1, pad=1):
+    """IGEVStereo/submodule.py:9-38 `BasicConv`: conv / transposed conv (bias=False) [+ BatchNorm] [+ LeakyReLU()].
+    Keys p.conv.weight, p.bn.*; deconv = ConvTranspose3d(k4, s2, p1) (igev_stereo.py:44-51)."""
+    w = cx.sd[p + ".conv.weight"]
+    if is_3d:
+        x = F.conv_transpose3d(x, w, None, stride=2, padding=1) if deconv else F.conv3d(x, w, None, stride, pad)
+    else:
+        x = F.conv2d(x, _w2d(w), None, stride, pad)
+    if bn:
+        x = cx.bn(x, p + ".bn")
+    return F.leaky_relu(x, 0.01) if relu else x
+
+
+def igev_feature_att(cx, cv, feat, p):
+    """IGEVStereo/submodule.py:228-241 `FeatureAtt`: sigmoid(Conv2d(1x1, bias)(BasicConv2d(1x1)(feat))).unsqueeze(2) * cv."""
+    a = igev_basic_conv(cx, feat, p + ".feat_att.0", is_3d=False, pad=0)
+    a = F.conv2d(a, _w2d(cx.sd[p + ".feat_att.1.weight"]), cx.sd[p + ".feat_att.1.bias"])
+    return torch.sigmoid(a.unsqueeze(2)) * cv
+
+
+def igev_hourglass(cx, x, features, p):
+    """IGEVStereo/igev_stereo.py:23-100 `hourglass(in_channels)` forward (:76-100)."""
+    def seq2(t, q, s):
+        t = igev_basic_conv(cx, t, q + ".0", stride=s)
+        return igev_basic_conv(cx, t, q + ".1")
+
+    def agg(t, q):
+        t = igev_basic_conv(cx, t, q + ".0", pad=0)
+        t = igev_basic_conv(cx, t, q + ".1")
+        return igev_basic_conv(cx, t, q + ".2")
+    conv1 = igev_feature_att(cx, seq2(x, p + ".conv1", 2), features[1], p + ".feature_att_8")
+    conv2 = igev_feature_att(cx, seq2(conv1, p + ".conv2", 2), features[2], p + ".feature_att_16")
+    conv3 = igev_feature_att(cx, seq2(conv2, p + ".conv3", 2), features[3], p + ".feature_att_32")
+    conv3_up = igev_basic_conv(cx, conv3, p + ".conv3_up", deconv=True)
+    conv2 = agg(torch.cat((conv3_up, conv2), dim=1), p + ".agg_0")
+    conv2 = igev_feature_att(cx, conv2, features[2], p + ".feature_att_up_16")
+    conv2_up = igev_basic_conv(cx, conv2, p + ".conv2_up", deconv=True)
+    conv1 = agg(torch.cat((conv2_up, conv1), dim=1), p + ".agg_1")
+    conv1 = igev_feature_att(cx, conv1, features[1], p + ".feature_att_up_8")
+    return igev_basic_conv(cx, conv1, p + ".conv1_up", deconv=True, bn=False, relu=False)
+
+
+def igev_cost_aggregation(sd, match_left, match_right, features_left, maxdisp, training=False, return_ctx=False):
+    """IGEVStereo/igev_stereo.py:206-213 with the modules of :148-151 (`corr_stem`, `corr_feature_att`, `cost_agg`,
+    `classifier`): -> (geo_encoding_volume [B,8,D/4,H/4,W/4], init_disp [B,1,H/4,W/4])."""
+    cx = Ctx(sd, training)
+    vol = igev_init_volume(match_left, match_right, maxdisp)
+    vol = igev_basic_conv(cx, vol, "corr_stem")
+    vol = igev_feature_att(cx, vol, features_left[0], "corr_feature_att")
+    geo = igev_hourglass(cx, vol, features_left, "cost_agg")
+    cost = F.conv3d(geo, sd["classifier.weight"], None, 1, 1)
+    out = (geo, igev_init_disparity(cost, maxdisp))
+    return (out, cx) if return_ctx else out
+
+
 # ----------------------------------------------------------------------------- CFNet (SURVEY 8f rank 1)
 def _cf_conv_bn_mish(cx, x, p):
     """CFNet/submodule.py:70-93 `conv2DBatchNormRelu` (1x1 conv, BN, Mish): keys p.cbr_unit.{0,1}."""

@@ -27,8 +27,10 @@ def _conv_cfg(conv):
     ks = conv.kernel_size[0]
     stride = conv.stride[0]
     if _is_transposed(conv):
-        if not (ks == 3 and stride == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 1):
-            raise ops.StxError("only ConvTranspose3d(k=3, s=2, p=1, op=1) is on the hot path")
+        k3 = ks == 3 and stride == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 1      # GwcNet / PSMNet family
+        k4 = ks == 4 and stride == 2 and conv.padding[0] == 1 and conv.output_padding[0] == 0      # IGEV family (out = 2 in)
+        if not (k3 or k4) or len(set(conv.kernel_size)) != 1 or len(set(conv.stride)) != 1:
+            raise ops.StxError("only ConvTranspose3d(k=3, s=2, p=1, op=1) and ConvTranspose3d(k=4, s=2, p=1) are on the hot path")
     else:
         if not ((ks == 3 and conv.padding[0] == 1 and stride in (1, 2)) or (ks == 1 and conv.padding[0] == 0 and stride == 1)):
             raise ops.StxError(f"unsupported Conv3d k={ks} s={stride} p={conv.padding}")
@@ -71,6 +73,10 @@ def _needs_grad(*tensors_and_modules):
 
 def _infer_conv(x, conv, scale, bias, residual, relu):
     ks, stride = _conv_cfg(conv)
+    if _is_transposed(conv) and ks == 4:
+        if residual is not None:
+            raise ops.StxError("ConvTranspose3d(k4) with a fused residual is not wired (no model uses it)")
+        return ops.deconv4_forward(x, conv.weight.detach(), scale, bias, int(relu), owner=conv.weight)
     if _is_transposed(conv):
         wp = ops.pack_weight(conv.weight.detach(), 2, owner=conv.weight)
         return ops.deconv3d_forward(x, wp, conv.weight.shape[1], scale=scale, bias=bias, residual=residual, relu=relu)[0]
@@ -150,14 +156,24 @@ def _bn_state(bn, partials, count, steps=1):
             "running_var": bn.running_var, "momentum": momentum, "eps": bn.eps, "sync": sync}
 
 
-def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False):
+def _raw_conv(x, conv, want):
+    """Raw convolution output + BatchNorm partial rows through autograd (ConvRawFn; ConvTranspose3d(k4) through its
+    parity-class form)."""
+    ks, stride = _conv_cfg(conv)
+    if _is_transposed(conv) and ks == 4:
+        return ops.deconv4_raw(x, conv.weight, want)
+    return ops.ConvRawFn.apply(x, conv.weight, ks, stride, _is_transposed(conv), want)
+
+
+def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False, leaky=False):
     """One fused block on NDHWC tensors.
+    leaky: LeakyReLU(0.01) instead of ReLU (IGEV family, activation code 3 of the kernels).
     second = (x2, conv2, bn2): adds BN2(conv2(x2)) before the activation (hourglass redir path).
     residual: NDHWC tensor added before the activation.
     mish: Mish instead of ReLU (PCWNet / CFNet family): fused into the conv epilogue in inference and into the BatchNorm
     apply / backward passes in training (differentiated at the recomputed pre-activation value)."""
-    if mish and relu:
-        raise ops.StxError("conv_block: relu and mish are mutually exclusive")
+    if (mish and relu) or (leaky and (relu or mish)):
+        raise ops.StxError("conv_block: relu, mish and leaky are mutually exclusive")
     if second is not None and residual is not None:
         raise ops.StxError("conv_block: `second` and `residual` are mutually exclusive")
     mods = [conv, bn] + ([second[1], second[2]] if second is not None else [])
@@ -169,6 +185,8 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     if mish:
         # activation code 2: conv epilogue (inference) / BN apply and the two BN backward passes (train), no extra pass
         relu = 2
+    if leaky:
+        relu = 3
 
     if not grad and not train_bn:   # ---- inference: everything folded into conv epilogues
         if second is not None:
@@ -181,21 +199,21 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
         return _infer_conv(x, conv, s1, b1, residual, relu)
 
     # ---- autograd path
-    ks, stride = _conv_cfg(conv)
     want = bn is not None and bn.training
-    z1, part1 = ops.ConvRawFn.apply(x, conv.weight, ks, stride, _is_transposed(conv), want)
+    z1, part1 = _raw_conv(x, conv, want)
     if bn is None:
         y = z1
         if residual is not None:
             y = y + residual
+        if relu == 3:
+            return torch.nn.functional.leaky_relu(y, 0.01)
         return torch.relu(y) if relu else y
     count1 = z1.numel() // z1.shape[-1]
     st1 = _bn_state(bn, part1 if want else None, count1)
     if second is not None:
         x2, conv2, bn2 = second
-        ks2, stride2 = _conv_cfg(conv2)
         want2 = bn2.training
-        z2, part2 = ops.ConvRawFn.apply(x2, conv2.weight, ks2, stride2, _is_transposed(conv2), want2)
+        z2, part2 = _raw_conv(x2, conv2, want2)
         st2 = _bn_state(bn2, part2 if want2 else None, z2.numel() // z2.shape[-1])
         return ops.BnActFn.apply(z1, bn.weight, bn.bias, z2, bn2.weight, bn2.bias, None, relu, st1, st2)
     return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None)

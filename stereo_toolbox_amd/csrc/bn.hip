@@ -202,7 +202,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     float s[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) s[k] = 0.f;
-    for (size_t v = (size_t)blockIdx.x * VPB + vl; v < nvox; v += (size_t)gridDim.x * VPB) {
+    // (C / 4 need not divide the workgroup: the threads beyond VPB whole voxels idle and contribute zeros)
+    for (size_t v = vl < VPB ? (size_t)blockIdx.x * VPB + vl : nvox; v < nvox; v += (size_t)gridDim.x * VPB) {
         const size_t o = v * C + 4 * cq;
         float4 g = stx_ld4(gy + o);
         const float4 a = stx_ld4(z1 + o);
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] = 0.f;
     const size_t step = (size_t)gridDim.x * VPB;
-    size_t v = (size_t)blockIdx.x * VPB + vl;
+    size_t v = vl < VPB ? (size_t)blockIdx.x * VPB + vl : nvox;  // (threads beyond VPB whole voxels idle: C / 4 need not divide the workgroup)
     for (; v + 3 * step < nvox; v += 4 * step) {                 // four independent 16-byte loads in flight per lane
         float4 a[4];
 #pragma unroll
@@ -414,7 +415,7 @@ extern "C" int stx_bn_finalize_groups(const float* partials, int nrows, int C, d
 
 extern "C" int stx_bn_stats_rows(long long nvox, int C) {
     stx_begin();
-    if (C < 4 || C % 4 != 0 || BN_THREADS % (C / 4) != 0 || nvox < 1) return 0;
+    if (C < 4 || C % 4 != 0 || C / 4 > BN_THREADS || nvox < 1) return 0;
     const long long vpb = BN_THREADS / (C / 4);
     const long long g = (nvox + 4 * vpb - 1) / (4 * vpb);          // >= 4 voxels per lane before another workgroup is added
     // at most 256 rows: the tensors of the 2-D CNN are 4-18 MB, both passes are latency-bound and the finalize pass reads
@@ -425,7 +426,7 @@ extern "C" int stx_bn_stats_rows(long long nvox, int C) {
 extern "C" int stx_bn_stats(const float* z, float* partials, long long nvox, int C, int groups, void* stream) {
     stx_begin();
     STX_REQUIRE(z && partials && nvox > 0 && groups >= 1 && groups <= 65535, "bn_stats: bad args");
-    STX_REQUIRE(C >= 4 && C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_stats: C=%d unsupported (multiple of 4 dividing 1024)", C);
+    STX_REQUIRE(C >= 4 && C % 4 == 0 && C / 4 <= BN_THREADS, "bn_stats: C=%d unsupported (a multiple of 4, at most 1024)", C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(stx_bn_stats_rows(nvox, C), groups), dim3(BN_THREADS), 0, (hipStream_t)stream, z,
                        partials, (size_t)nvox, C);
     return stx_check_launch("bn_stats");
@@ -451,7 +452,7 @@ extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* 
     stx_begin();
     STX_REQUIRE(gy && z1 && mean1 && invstd1 && partials && sums && nvox > 0, "bn_bwd_reduce: null operand");
     STX_REQUIRE(groups >= 1 && groups <= 65535, "bn_bwd_reduce: groups=%d", groups);
-    STX_REQUIRE(C % 4 == 0 && BN_THREADS % (C / 4) == 0, "bn_bwd_reduce: C=%d unsupported", C);
+    STX_REQUIRE(C >= 4 && C % 4 == 0 && C / 4 <= BN_THREADS, "bn_bwd_reduce: C=%d unsupported (a multiple of 4, at most 1024)", C);
     STX_REQUIRE(!relu || y || (scale1 && shift1 && (!(z2 && mean2) || (scale2 && shift2))),
                 "bn_bwd_reduce: the relu mask needs y or the forward pass's scale / shift vectors");
     STX_REQUIRE(relu != 2 || !y, "bn_bwd_reduce: Mish (activation code 2) differentiates the pre-activation value: pass y = NULL and the scale / shift vectors");

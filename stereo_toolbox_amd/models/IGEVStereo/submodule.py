@@ -1,7 +1,8 @@
 """The cost-volume entry of the IGEV family (IGEV-Stereo, and with the same call MonSter / FoundationStereo) on the HIP
 kernels -- drop-in functions of reference models/IGEVStereo/submodule.py plus the two lines of
-`IGEVStereo.forward` that sit on the hot path (igev_stereo.py:206 and :211-212).  The rest of those models (feature
-backbones, GRU updates, 3-D regularisation network) is outside the scope of this package.
+`IGEVStereo.forward` that sit on the hot path (igev_stereo.py:206 and :211-212).  The 3-D regularisation between them
+(`corr_stem`, `corr_feature_att`, `cost_agg` = hourglass(8), `classifier`) is in aggregation.py; the rest of those models
+(feature backbones, GRU updates, geometry encoding) is outside the scope of this package.
 
     gwc_volume = build_gwc_volume(match_left, match_right, max_disp // 4, 8)      # 96 channels -> 8 groups of 12
     prob       = F.softmax(classifier(volume).squeeze(1), dim=1)

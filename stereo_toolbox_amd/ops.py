@@ -347,7 +347,12 @@ class ConvRawFn(torch.autograd.Function):
                     gx = torch.cat(parts, -1)
                 elif stride == 1:
                     gx, _ = conv3d_forward(gz_k, pack_weight(w_k, 1), Ci, ks, 1)
-                else:                     # stride-2 dgrad = transposed conv of gz
+                else:                     # stride-2 dgrad = transposed conv of gz (its kernel takes GEMM-K in steps of 32)
+                    if Co % 32:
+                        Cp = (Co + 31) // 32 * 32
+                        gz_k = _pad_channels(gz, Cp)
+                        w_k = w.new_zeros(Cp, *w.shape[1:])
+                        w_k[:Co] = w
                     gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W))
             if ctx.needs_input_grad[1]:
                 if c1:
@@ -362,6 +367,136 @@ class ConvRawFn(torch.autograd.Function):
             if gw is not None:
                 gw = gw[:, :ctx.cin_true].contiguous()
         return gx, gw, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------- ConvTranspose3d(k4, s2, p1)
+_D4_SEL = ((3, 1, 4), (4, 2, 0))       # per axis and output parity p: the k4 tap at offsets -1, 0, +1 (4 = the zero slice)
+
+
+def embed_deconv4_weight(w):
+    """ConvTranspose3d(k=4, s=2, p=1) weight [Cin, Cout, 4, 4, 4] -> the weight [8 Cout, Cin, 3, 3, 3] of ONE stride-1
+    3x3x3 convolution whose output channel (4 pd + 2 ph + pw) Cout + c is parity class (pd, ph, pw) of output channel c:
+    per axis  out[2j + p] = x[j] w[1 + p] + x[j - 1 + 2p] w[3 - 3p], i.e. offsets (-1, 0, +1) take taps (3, 1, -) for
+    p = 0 and (-, 2, 0) for p = 1 (reference IGEVStereo/igev_stereo.py:44-51 `conv*_up`).  Pure indexing: differentiable."""
+    Ci, Co = w.shape[0], w.shape[1]
+    wz = torch.cat((w, w.new_zeros(Ci, Co, 1, 4, 4)), 2)
+    wz = torch.cat((wz, wz.new_zeros(Ci, Co, 5, 1, 4)), 3)
+    wz = torch.cat((wz, wz.new_zeros(Ci, Co, 5, 5, 1)), 4)
+    parts = []
+    for pd in (0, 1):
+        for ph in (0, 1):
+            for pw in (0, 1):
+                sel = wz[:, :, list(_D4_SEL[pd])][:, :, :, list(_D4_SEL[ph])][:, :, :, :, list(_D4_SEL[pw])]
+                parts.append(sel.transpose(0, 1))
+    return torch.cat(parts, 0).contiguous()
+
+
+class DepthToSpaceFn(torch.autograd.Function):
+    """[B, D, H, W, 8 C] (parity-class-major channels) -> [B, 2D, 2H, 2W, C]; backward = the inverse map."""
+
+    @staticmethod
+    def forward(ctx, y):
+        y = y.contiguous()
+        _chk(y, "y", 5)
+        B, D, H, W, C8 = y.shape
+        C = C8 // 8
+        out = torch.empty(B, 2 * D, 2 * H, 2 * W, C, dtype=torch.float32, device=y.device)
+        _call("stx_depth_to_space", _p(y), _p(out), B, D, H, W, C, 0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, D2, H2, W2, C = g.shape
+        gy = torch.empty(B, D2 // 2, H2 // 2, W2 // 2, 8 * C, dtype=torch.float32, device=g.device)
+        _call("stx_depth_to_space", _p(g), _p(gy), B, D2 // 2, H2 // 2, W2 // 2, C, 1)
+        return gy
+
+
+def _d4_chunks(Co):
+    """Parity classes per launch: the convolution kernels produce at most 128 output channels."""
+    per = max(1, min(8, 128 // Co))
+    return [(c0, min(8, c0 + per)) for c0 in range(0, 8, per)]
+
+
+def deconv4_raw(x, w, want_stats):
+    """Autograd path of ConvTranspose3d(k4, s2, p1): raw output z [B, 2D, 2H, 2W, Cout] (+ BatchNorm partial rows).
+    One (or a few, for 8 Cout > 128) stride-1 3x3x3 MFMA convolutions on the embedded weight + the class interleave;
+    data and weight gradients flow back through the same kernels (ConvRawFn) and the indexing above."""
+    Co = w.shape[1]
+    if Co % 4:
+        raise StxError(f"ConvTranspose3d(k4): {Co} output channels (need a multiple of 4)")
+    w3 = embed_deconv4_weight(w)
+    ys = [ConvRawFn.apply(x, w3[c0 * Co:c1 * Co], 3, 1, False, False)[0] for c0, c1 in _d4_chunks(Co)]
+    z = DepthToSpaceFn.apply(ys[0] if len(ys) == 1 else torch.cat(ys, -1))
+    return z, (bn_stats(z.detach()) if want_stats else z.new_empty(0))
+
+
+def deconv4_forward(x, w, scale=None, bias=None, relu=0, owner=None):
+    """Inference path of ConvTranspose3d(k4, s2, p1) with the folded BatchNorm / activation in the convolution epilogue
+    (scale / bias repeated per parity class), then the class interleave.  Packed weights cached on `owner`."""
+    _chk(x, "x", 5)
+    Co = w.shape[1]
+    if Co % 4:
+        raise StxError(f"ConvTranspose3d(k4): {Co} output channels (need a multiple of 4)")
+    cache = owner.__dict__.setdefault("_stx_packed", {}) if (owner is not None and _CACHE_ENABLED) else None
+    key = (owner._version, owner.data_ptr()) if owner is not None else None
+    hit = cache.get("d4") if cache is not None else None
+    if hit is not None and hit[0] == key:
+        packed = hit[1]
+    else:
+        w3 = embed_deconv4_weight(w)
+        packed = [pack_weight(w3[c0 * Co:c1 * Co].contiguous(), 0) for c0, c1 in _d4_chunks(Co)]
+        if cache is not None:
+            cache["d4"] = (key, packed)
+    ys = []
+    for (c0, c1), wp in zip(_d4_chunks(Co), packed):
+        n = c1 - c0
+        ys.append(conv3d_forward(x, wp, n * Co, 3, 1, None if scale is None else scale.repeat(n),
+                                 None if bias is None else bias.repeat(n), None, relu)[0])
+    B, D, H, W, _ = x.shape
+    y = ys[0] if len(ys) == 1 else torch.cat(ys, -1)
+    out = torch.empty(B, 2 * D, 2 * H, 2 * W, Co, dtype=torch.float32, device=x.device)
+    _call("stx_depth_to_space", _p(y), _p(out), B, D, H, W, Co, 0)
+    return out
+
+
+# --------------------------------------------------------------------------------------- FeatureAtt gate
+class GateFn(torch.autograd.Function):
+    """cv [B, D, H, W, C] * sigmoid(att [B, H, W, C]) (reference IGEVStereo/submodule.py:238-240), one pass; backward one
+    pass over (g, cv) with the gate's gradient summed over D in registers."""
+
+    @staticmethod
+    def forward(ctx, cv, att):
+        out = gate(cv.detach(), att.detach())
+        ctx.save_for_backward(cv, att)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cv, att = ctx.saved_tensors
+        g = g.contiguous()
+        B, D, H, W, C = cv.shape
+        gcv = torch.empty_like(cv) if ctx.needs_input_grad[0] else None
+        gatt = torch.empty_like(att) if ctx.needs_input_grad[1] else None
+        if gcv is not None or gatt is not None:
+            _call("stx_gate_bwd", _p(g), _p(cv), _p(att), _p(gcv), _p(gatt), B, D, H * W, C)
+        return gcv, gatt
+
+
+def gate(cv, att):
+    """cv [B, D, H, W, C] (dense NDHWC) * sigmoid(att [B, H, W, C]) broadcast over D; differentiable."""
+    if torch.is_grad_enabled() and (cv.requires_grad or att.requires_grad):
+        return GateFn.apply(cv.contiguous(), att.contiguous())
+    cv, att = cv.contiguous(), att.contiguous()
+    _chk(cv, "cv", 5)
+    _chk(att, "att", 4)
+    B, D, H, W, C = cv.shape
+    if att.shape != (B, H, W, C) or C % 4:
+        raise StxError(f"gate: volume {tuple(cv.shape)} vs gate {tuple(att.shape)} (need [B,H,W,C], C % 4 == 0)")
+    out = torch.empty_like(cv)
+    _call("stx_gate_fwd", _p(cv), _p(att), _p(out), B, D, H * W, C)
+    return out
 
 
 # --------------------------------------------------------------------------------------- batch norm

@@ -1609,6 +1609,11 @@ static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
     return c;
 }
 
+// march form of the 3x3x3 stride-1 weight gradient (wgrad_march.hip)
+int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, int D, int H, int W, int CF, int CC,
+                           int nchunks, void* stream);
+int stx_wgrad_march_chunks(int B, int D, int H, int W, int npairs);
+
 extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks,
                                                        int stride) {
     const int npairs = (CF / 32) * (CC / 32);
@@ -1617,7 +1622,11 @@ extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, in
     const bool pipe = wgrad_pipe(ks, stride, npairs);
     int TH, TW;
     wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
-    const int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW), npairs, pipe);
+    int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW), npairs, pipe);
+    if (ks == 3 && stride == 1) {                                       // (either kernel may serve the call: STX_WGRAD_MARCH)
+        const int cm = stx_wgrad_march_chunks(B, Dc, Hc, Wc, npairs);
+        if (cm > c) c = cm;
+    }
     return (long long)npairs * c * rows * 1024;
 }
 
@@ -1641,10 +1650,24 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
     a.nHt = stx_cdiv(Hc, TH); a.nWt = stx_cdiv(Wc, TW);
     a.ntiles = B * Dc * a.nHt * a.nWt;
-    const int nchunks = wgrad_chunks(a.ntiles, npairs, pipe);
-    dim3 grid(nchunks, npairs);
+    int nchunks = wgrad_chunks(a.ntiles, npairs, pipe);
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
+    if (ks == 3 && stride == 1 && stx_tune(STX_TUNE_WGRAD_MARCH)) {
+        // march form (wgrad_march.hip): K-contiguous operands, rolling plane windows, runs cut at step granularity
+        int mc = stx_wgrad_march_chunks(B, Dc, Hc, Wc, npairs);
+        const int forced = stx_tune(STX_TUNE_WGRAD_GRID);
+        if (forced > 0 && forced < mc) mc = forced;
+        const int rc = stx_wgrad_march_launch(f, c, workspace, B, Dc, Hc, Wc, CF, CC, mc, stream);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            const int total = npairs * T * 1024;
+            hipLaunchKernelGGL(conv3d_wgrad_reduce4_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st, workspace, dw, CF, CC, T,
+                               mc, 27);
+            return stx_check_launch("conv3d_wgrad_reduce");
+        }
+    }
+    dim3 grid(nchunks, npairs);
     // 3x3x3: eight waves, 3-4 taps (48-64 accumulator registers) each: measured +22 % over four waves with 7
 #define WG_LAUNCH(KS_, S_, TH_, TW_, NW_, PIPE_, LDS_)                                                           \
     {                                                                                                             \

@@ -38,16 +38,7 @@ from IGEVStereo.submodule import disparity_regression as ref_regress  # noqa: E4
 
 from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor  # noqa: E402
 
-MAXDISP, H4, W4, B = 64, 16, 32, 2          # 1/4-resolution volume [B, 8, 16, 16, 32]; levels 1/8, 1/16, 1/32 below it
-FEAT_CH = (96, 64, 192, 160)
-CLASSIFIER_GAIN = 40.0      # the filler's weights give a near-uniform softmax over D' (init_disp ~ 7.5 everywhere, which hides
-                            # errors): the classifier is scaled up so that the regression output is peaky (std ~ 2 px)
-
-
-def fill(sd):
-    fill_state_dict(sd, seed=4321)
-    sd["classifier.weight"].mul_(CLASSIFIER_GAIN)
-    return sd
+from tests.golden.igev_agg_config import B, CLASSIFIER_GAIN, FEAT_CH, H4, MAXDISP, W4, fill  # noqa: E402,F401
 
 
 class RefAggregation(nn.Module):

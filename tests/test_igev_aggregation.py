@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from oracle import torch_oracle as O
 from stereo_toolbox_amd.utils import fill_state_dict, synthetic_tensor
 from tests.backends import be, ndhwc, ptr  # noqa: F401
-from tests.golden.make_golden_igev_agg import B, FEAT_CH, H4, MAXDISP, W4, fill
+from tests.golden.igev_agg_config import B, FEAT_CH, H4, MAXDISP, W4, fill
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -466,9 +466,14 @@ def run_wgrad(be, fine, coarse, ks, stride):
 
 @pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1),
                                   (2, 64, 64, 3, 5, 37, 3, 1), (1, 64, 64, 2, 3, 60, 3, 1),     # four channel-block pairs: un-pipelined staging, 4 x 16 / 2 x 32 tiles
-                                  (1, 64, 128, 3, 7, 21, 3, 2)])
-def test_conv3d_wgrad(be, case):
+                                  (1, 64, 128, 3, 7, 21, 3, 2),
+                                  (2, 32, 32, 5, 9, 37, 3, 1), (1, 32, 64, 4, 4, 16, 3, 1)])      # ragged H / W tiles, batch 2; exact tiles
+@pytest.mark.parametrize("march", [1, 0], ids=["march", "tile_kernel"])
+def test_conv3d_wgrad(be, case, tune, march):
     B, Cin, Cout, D, H, W, ks, s = case
+    if march == 0 and not (ks == 3 and s == 1):
+        pytest.skip("STX_WGRAD_MARCH only selects among the 3x3x3 stride-1 kernels")
+    tune("STX_WGRAD_MARCH", march)
     torch.manual_seed(8)
     x = torch.randn(B, Cin, D, H, W)
     w = (torch.randn(Cout, Cin, ks, ks, ks) * 0.1).requires_grad_()
@@ -478,12 +483,16 @@ def test_conv3d_wgrad(be, case):
     _close(run_wgrad(be, x, gy, ks, s).view_as(w), w.grad)
 
 
-def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune):
+@pytest.mark.parametrize("march", [1, 0], ids=["march", "tile_kernel"])
+def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune, march):
     """The weight-gradient kernels' tile loop with several tiles per workgroup (STX_WGRAD_GRID caps the split-K workgroups; at
-    the small test shapes every workgroup otherwise gets one tile): odd and even tile counts, stride 1 and 2."""
+    the small test shapes every workgroup otherwise gets one tile): odd and even tile counts, stride 1 and 2.  March kernel:
+    runs of several columns per workgroup, cut INSIDE a column (the window is rebuilt there), rolling plane buffers over
+    more than four steps."""
+    tune("STX_WGRAD_MARCH", march)
     torch.manual_seed(8)
     for grid, (B, Cin, Cout, D, H, W, s) in ((1, (1, 32, 32, 3, 5, 37, 1)), (4, (2, 32, 64, 2, 9, 21, 1)), (5, (1, 64, 32, 3, 7, 40, 1)),
-                                             (3, (1, 32, 64, 4, 6, 40, 2))):
+                                             (3, (1, 32, 64, 4, 6, 40, 2)), (3, (1, 32, 32, 7, 8, 20, 1)), (2, (1, 32, 32, 9, 4, 16, 1))):
         tune("STX_WGRAD_GRID", grid)
         x = torch.randn(B, Cin, D, H, W)
         w = (torch.randn(Cout, Cin, 3, 3, 3) * 0.1).requires_grad_()

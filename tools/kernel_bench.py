@@ -92,6 +92,7 @@ AB_SETS = [
     ("march kernel: no plane staging (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 1}),
     ("march kernel: no epilogue stores (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 2}),
     ("stride-2 32->64 with the padded LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": 0}),
+    ("weight gradient 3x3x3 s1: tile kernel of rounds 1-3 instead of the march kernel", "conv_32_32_L0_wgrad,conv_64_32_L0_wgrad,conv_64_64_L1_wgrad,conv_128_128_L2_wgrad", {"STX_WGRAD_MARCH": 0}),
     ("weight gradient: no tile staging (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 1}),
     ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),

@@ -418,7 +418,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     for (int m = m0; m < m1; ++m) macro(m, PF == 2 && m != m0 && (m & 1));
 }
 
-constexpr int CVM_PF_DEFAULT = 2;      // (STX_CV_PF = 1 selects the one-tile-ahead scheme)
+constexpr int CVM_PF_DEFAULT = 1;      // one tile ahead.  STX_CV_PF = 2 selects the line-pair scheme: 11 % fewer bytes fetched (FETCH_SIZE
+                                       // 60.3 vs 67.8 MB x 2) but 5-6 % MORE time, alone and inside the train step (GPU calls B / C of round 4:
+                                       // 0.1071 vs 0.1007 ms) -- the builder is bound by its write stream, not by the feature reads
 
 template <int CPG, int QPW, int NCW, int NSW, int ND, bool SCALE = false, int PF = 1>
 int cvm_launch(const CvmArgs& a, int wgs_per_cu, size_t lds, hipStream_t st) {

@@ -143,7 +143,7 @@ enum StxTune {
     STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)
     STX_TUNE_CV_OLD,         // STX_CV_OLD         0  cost volume forward: first-generation builders (fallback path) for every shape
     STX_TUNE_CV_GRID,        // STX_CV_GRID        0  cost volume forward: workgroups (tests: multi-unit runs)
-    STX_TUNE_CV_PF,          // STX_CV_PF          0  cost volume forward: feature prefetch, 0 = default (2: line pairs), 1 = one tile ahead
+    STX_TUNE_CV_PF,          // STX_CV_PF          0  cost volume forward: feature prefetch, 0 = default (1: one tile ahead), 2 = cache-line pairs through an LDS-DMA slot
     STX_TUNE_CV_UNITS,       // STX_CV_UNITS       1  cost volume forward: workgroup runs cut at units (0: at whole macro-units)
     STX_TUNE_CVB_OLD,        // STX_CVB_OLD        0  cost volume backward: first-generation kernels for every shape
     STX_TUNE_CVB_TEAM,       // STX_CVB_TEAM       0  cost volume backward: row-team schedule (one HBM pass, lock-step)

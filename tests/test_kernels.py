@@ -71,7 +71,7 @@ def test_cost_volume_fwd_launch_variants(be, grid, sched, tune):
     workgroups every multi-unit case has such a cut) or at whole macro-units.
     All cases on the emulator, the GwcNet_GC channel configuration on the GPU."""
     tune("STX_CV_GRID", grid)
-    tune("STX_CV_PF", 1 if sched.startswith("one_ahead") else 2)
+    tune("STX_CV_PF", 1 if sched.startswith("one_ahead") else 2)          # (1 is the default: GPU call C of round 4)
     tune("STX_CV_UNITS", 0 if sched.endswith("macros") else 1)
     for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
         B, Cg, G, Cc, H, W, D, ml = case

@@ -97,9 +97,8 @@ AB_SETS = [
     ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),
     ("cost volume fwd: first-generation fallback kernel", "cost_volume_fwd", {"STX_CV_OLD": 1}),
-    ("cost volume fwd: one tile ahead (half-line requests)", "cost_volume_fwd", {"STX_CV_PF": 1}),
+    ("cost volume fwd: cache-line pairs through the LDS-DMA slot", "cost_volume_fwd", {"STX_CV_PF": 2}),
     ("cost volume fwd: runs cut at whole macro-units", "cost_volume_fwd", {"STX_CV_UNITS": 0}),
-    ("cost volume fwd: one tile ahead + whole macro-units (round 3)", "cost_volume_fwd", {"STX_CV_PF": 1, "STX_CV_UNITS": 0}),
     ("cost volume bwd: first-generation fallback kernel", "cost_volume_bwd", {"STX_CVB_OLD": 1}),
     ("cost volume bwd: team schedule", "cost_volume_bwd", {"STX_CVB_TEAM": 1}),
     ("cost volume bwd: 2 chunk sets in flight", "cost_volume_bwd", {"STX_CVB_NSET": 2}),

@@ -1422,7 +1422,9 @@ static ConvPlan conv_plan(int B, int Di, int Hi, int Wi, int Cin, int Cout, int 
     const int pad = ks / 2;
     const int Do = (Di + 2 * pad - ks) / stride + 1, Ho = (Hi + 2 * pad - ks) / stride + 1, Wo = (Wi + 2 * pad - ks) / stride + 1;
     ConvPlan p{2, 0, 0, 0};
-    if (ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32))) {
+    // (STX_CONV_L1_MARCH: 64 -> 64 as 2 x 2 slices too -- the hourglass's second level, otherwise on the implicit-GEMM kernel)
+    if (ks == 3 && stride == 1 && ((Cin == 32 && Cout <= 64) || (Cin == 64 && Cout <= 32) ||
+                                   (Cin == 64 && Cout <= 64 && stx_tune(STX_TUNE_CONV_L1_MARCH)))) {
         const long long ncols = (long long)B * stx_cdiv(Ho, MW2_TH) * stx_cdiv(Wo, MW2_MW);
         // (planes are addressed through buffer descriptors with 32-bit byte offsets)
         if (ncols * Do < (1ll << 31) && (long long)Hi * Wi * Cin * 4 < (1ll << 31) && (long long)Ho * Wo * Cout * 4 < (1ll << 31)) {

@@ -21,7 +21,7 @@
 //     with x planes o-1, o, o+1 (kd = 0, 1, 2), which stay in LDS for three steps: every x plane is staged ONCE per column
 //     (the old kernel re-staged three planes per output plane), the halo costs 6/4 x 18/16 in H / W only.  Four x buffers
 //     and two gy buffers: the planes of step o+1 are requested before the MFMA loop of step o and written to LDS behind
-//     it -- one barrier per step.
+//     it (in the middle of the MFMA loop of step o, whose planes live in other buffers) -- one barrier per step.
 //   * Work is cut at STEP granularity: the launch's (columns x planes) steps are dealt in equal contiguous runs to the
 //     workgroups; a run that starts inside a column re-builds the window (3 planes) there.
 //
@@ -194,6 +194,12 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
                     for (int kw = 0; kw < 3; ++kw)
                         acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + kw], bv[j], acc[kw], 0, 0, 0);
                 STX_SCHED_BARRIER();
+                if (q == 4) {
+                    // the planes of step o + 1 (requested before the loop, landed long ago) go to LDS here, in the shadow of the
+                    // MFMAs, instead of between the last MFMA and the barrier: their buffers are not read during this step
+                    if (more) { store_x(o + 2); store_g(o + 1); }
+                    STX_SCHED_BARRIER();
+                }
             }
             {
                 const float av[6] = {A0[0].x, A0[0].y, A0[0].z, A0[0].w, A1[0].x, A1[0].y};
@@ -204,7 +210,6 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
                     for (int kw = 0; kw < 3; ++kw)
                         acc8[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j + kw], bv[j], acc8[kw], 0, 0, 0);
             }
-            if (more) { store_x(o + 2); store_g(o + 1); }
             __syncthreads();
         }
         s += oe - ob;

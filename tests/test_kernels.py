@@ -385,6 +385,27 @@ def test_conv3d_fwd(be, case):
     _close(got3, F.mish(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res), rtol=1e-4, atol=1e-5)
 
 
+def test_conv3d_64_64_on_the_march_kernel(be, tune):
+    """STX_CONV_L1_MARCH: the 64 -> 64 3x3x3 stride-1 layers (hourglass conv2 and its data gradient) as 2 x 2 channel slices
+    of the march kernel -- K slices accumulate through the output tensor, the epilogue (BN statistics, affine, residual,
+    activation) runs in the last one."""
+    tune("STX_CONV_L1_MARCH", 1)
+    torch.manual_seed(5)
+    for B, D, H, W in ((1, 3, 5, 37), (2, 5, 8, 16)):
+        x = torch.randn(B, 64, D, H, W)
+        w = torch.randn(64, 64, 3, 3, 3) * 0.1
+        ref = F.conv3d(x, w, None, 1, 1)
+        got, st = run_conv(be, x, w, 3, 1, stats=True)
+        _close(got, ref)
+        _close(st[:, 0].sum(0), ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        _close(st[:, 1].sum(0), (ref ** 2).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        sc, bs, res = torch.rand(64) + 0.5, torch.randn(64), torch.randn_like(ref)
+        got2, _ = run_conv(be, x, w, 3, 1, sc, bs, res, 1)
+        _close(got2, F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res))
+        got3, _ = run_conv(be, x, w, 3, 1, sc, bs, None, 1)
+        _close(got3, F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1)))
+
+
 @pytest.mark.parametrize("dense", [1, 0])
 def test_conv3d_stride2_lds_tile_layouts(be, dense, tune):
     """Stride-2 32 -> 64 convolution (the first convolution of every hourglass) with the un-padded LDS tile (default,

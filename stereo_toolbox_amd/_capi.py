@@ -145,7 +145,9 @@ class StxLib:
 
 _LIB = None
 _LOCK = threading.Lock()
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstx_hip.so")
+# STX_HIP_LIB: another build of the SAME sources (e.g. tools/build_variant.sh -DSTX_PRECISE_MATH) for A/B measurements; it
+# must exist -- a missing file raises, nothing falls back.
+LIB_PATH = os.environ.get("STX_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libstx_hip.so")
 
 
 def get_lib():

@@ -11,6 +11,7 @@
 #include "hipemu.h"
 #define STX_DYN_SMEM(name) char* name = hipemu::dyn_smem()
 #define stx_exp(x) expf(x)
+#define stx_fdiv(a, b) ((a) / (b))
 #define STX_SCHED_BARRIER() ((void)0)
 #define STX_SCHED_GROUP(mask, n) ((void)0)
 #define STX_OPAQUE_VGPR(x) ((void)0)
@@ -21,7 +22,16 @@
 #else
 #include <hip/hip_runtime.h>
 #define STX_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// exp / division of the streaming kernels (softmax of the regression head, Mish, the FeatureAtt gate): the hardware
+// approximations (v_exp_f32 behind one multiply, v_rcp_f32) unless the library is built with -DSTX_PRECISE_MATH (correctly
+// rounded-to-1-ulp libm forms; an A/B build for error attribution, see tests/test_models.py "hand_written_path_isolated")
+#ifdef STX_PRECISE_MATH
+#define stx_exp(x) expf(x)
+#define stx_fdiv(a, b) ((a) / (b))
+#else
 #define stx_exp(x) __expf(x)
+#define stx_fdiv(a, b) __fdividef((a), (b))
+#endif
 // Instruction-scheduling fence (guide 5.4 rule 18 / T19): nothing moves across it.
 #define STX_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // Instruction interleave inside one scheduling region (guide T19): the next `n` instructions of class `mask` (0x008 MFMA,
@@ -163,7 +173,7 @@ int stx_tune(StxTune id);
 __device__ __forceinline__ float stx_mish_tanh_sp(float x, float& w) {
     w = stx_exp(x < 20.f ? x : 20.f);
     const float n = w * (w + 2.f);
-    return x > 20.f ? 1.f : __fdividef(n, n + 2.f);
+    return x > 20.f ? 1.f : stx_fdiv(n, n + 2.f);
 }
 __device__ __forceinline__ float stx_mish(float x) {
     float w;
@@ -173,7 +183,7 @@ __device__ __forceinline__ float stx_mish(float x) {
 __device__ __forceinline__ float stx_mish_grad(float x) {
     float w;
     const float t = stx_mish_tanh_sp(x, w);
-    const float ds = x > 20.f ? 1.f : __fdividef(w, 1.f + w);
+    const float ds = x > 20.f ? 1.f : stx_fdiv(w, 1.f + w);
     return t + x * (1.f - t * t) * ds;
 }
 #define STX_LEAKY_SLOPE 0.01f

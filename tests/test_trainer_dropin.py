@@ -196,37 +196,55 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-def _same_grads(named_params, want, what, parity_log=None):
-    """Gradients of two runs of the same step.  The hand-written kernels are deterministic: given identical features every
-    parameter behind the 2-D feature CNN agrees bit for bit.  The 2-D CNN itself runs MIOpen kernels whose backward-weights
-    pass accumulates with atomics and whose algorithm choice may differ between two module instances (the same effect the
-    64x128 train-parity tests of test_models.py document): its parameters get the GPU floor of those tests (1 % of the
-    tensor's max), and whatever its forward leaves different in the features is allowed to move the 3-D path's gradients
-    by 1e-4 of their max.  The achieved numbers go to the parity report."""
-    worst2d, worst3d, n_exact, n = 0.0, 0.0, 0, 0
-    bad = []
+def _grad_distance(named_params, want):
+    """Worst relative distance (to the tensor's max) between the gradients of a module and a reference list, separately for
+    the 2-D feature CNN and for everything behind it; parameters without a gradient on either side must agree on that."""
+    worst = {"2d": 0.0, "3d": 0.0}
+    n_exact, n = 0, 0
     for (name, p), g in zip(named_params, want):
         if g is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, (what, name)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
             continue
-        assert p.grad is not None, (what, name)
+        assert p.grad is not None, name
         n += 1
         if torch.equal(p.grad, g):
             n_exact += 1
             continue
         rel = (p.grad - g).abs().max().item() / (g.abs().max().item() + 1e-30)
-        if name.startswith("feature_extraction."):
-            worst2d = max(worst2d, rel)
-            if rel > 1e-2:
-                bad.append((name, rel))
-        else:
-            worst3d = max(worst3d, rel)
-            if rel > 1e-4:
-                bad.append((name, rel))
+        k = "2d" if name.startswith("feature_extraction.") else "3d"
+        worst[k] = max(worst[k], rel)
+    return worst, n_exact, n
+
+
+def _same_grads(named_params, want, noise, what, parity_log=None):
+    """Gradients of a wrapped / synchronised module against the plain module's.  Two runs of the SAME plain step on this box
+    are not bit-identical: the stock 2-D CNN's MIOpen kernels differ from run to run (atomics in backward-weights, algorithm
+    choice per module instance), and at these tiny shapes (a few hundred voxels per channel at the 1/16 level) train-mode
+    BatchNorm amplifies one-ulp feature differences to 1e-3 .. 1e-2 of a gradient's max (GPU call D of round 4: 0 of 269
+    tensors bitwise equal between two plain runs, worst 0.6 % / 4 %).  `noise` is that run-to-run distance measured in the
+    same test (plain vs a second plain instance); the wrapped module may be at most 5 x as far from plain as plain is from
+    itself (floor 2 % -- one pair of runs is a noisy estimate of that distance).  A wrapper that dropped, doubled or
+    mis-scaled a gradient would be off by O(1); the exact-equality form of this check runs on the deterministic CPU /
+    gloo / emulator path (test_reference_trainer_prepare_model_two_ranks: 1e-6)."""
+    worst, n_exact, n = _grad_distance(named_params, want)
     if parity_log is not None:
-        parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst2d, worst_rel_3d_path=worst3d)
-    assert not bad, (what, bad[:5])
+        parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst["2d"], worst_rel_3d_path=worst["3d"],
+                   plain_run_to_run_2d=noise["2d"], plain_run_to_run_3d=noise["3d"])
+    for k in ("2d", "3d"):
+        assert worst[k] <= max(5.0 * noise[k], 2e-2), (what, k, worst[k], noise[k])
     return n_exact, n
+
+
+def _plain_reference(ctor, *a, **k):
+    """The un-wrapped module's gradients / BatchNorm statistics for one step, and the run-to-run noise of that step."""
+    plain = _filled_model(ctor, *a, **k).cuda().train()
+    _gpu_step(plain)
+    want = [p.grad.clone() if p.grad is not None else None for p in plain.parameters()]
+    stats = {kk: v.clone() for kk, v in plain.state_dict().items() if "running" in kk or "num_batches" in kk}
+    again = _filled_model(ctor, *a, **k).cuda().train()
+    _gpu_step(again)
+    noise, _, _ = _grad_distance(again.named_parameters(), want)
+    return want, stats, noise
 
 
 def _gpu_step(model, Hh=64, Ww=128, Dd=64, B=1):
@@ -248,11 +266,8 @@ def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1, parity_lo
     identity), the wrapped module must keep working for a second step, and SyncBatchNorm conversion must not change a
     1-rank result."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    torch.backends.cudnn.benchmark = False             # same MIOpen algorithm in the three runs below
-    plain = _filled_model("GwcNet_GC", 64).cuda().train()
-    _gpu_step(plain)
-    want = [p.grad.clone() for p in plain.parameters()]
-    want_stats = {k: v.clone() for k, v in plain.state_dict().items() if "running" in k or "num_batches" in k}
+    torch.backends.cudnn.benchmark = False
+    want, want_stats, noise = _plain_reference("GwcNet_GC", 64)
 
     for convert in (False, True):
         m = _filled_model("GwcNet_GC", 64).cuda()
@@ -261,10 +276,10 @@ def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1, parity_lo
         ddp = DDP(m.train(), device_ids=[0], output_device=0, find_unused_parameters=False)
         _gpu_step(ddp)
         torch.cuda.synchronize()
-        _same_grads(ddp.module.named_parameters(), want, f"ddp_world1[sync_bn_converted={convert}]", parity_log)
+        _same_grads(ddp.module.named_parameters(), want, noise, f"ddp_world1[sync_bn_converted={convert}]", parity_log)
         sd = ddp.module.state_dict()
         for k, v in want_stats.items():
-            assert torch.equal(sd[k], v) or (sd[k] - v).abs().max().item() <= 1e-6 * (1 + v.abs().max().item()), (convert, k)
+            assert torch.equal(sd[k], v) or (sd[k] - v).abs().max().item() <= 1e-4 * (1 + v.abs().max().item()), (convert, k)
         ddp.zero_grad(set_to_none=True)
         _gpu_step(ddp)                                 # the reducer re-arms: a second iteration works
         assert all(p.grad is not None for p in ddp.module.parameters())
@@ -277,15 +292,13 @@ def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1, parity_lo
     starts at the outputs of the custom Functions."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     torch.backends.cudnn.benchmark = False
-    plain = _filled_model("ACVNet", 64, attn_weights_only=True).cuda().train()
-    _gpu_step(plain)
+    want, _, noise = _plain_reference("ACVNet", 64, attn_weights_only=True)
     m = _filled_model("ACVNet", 64, attn_weights_only=True).cuda().train()
     ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True)
     _gpu_step(ddp)
     torch.cuda.synchronize()
-    _, used = _same_grads(ddp.module.named_parameters(), [q.grad for q in plain.parameters()], "ddp_world1_acv_attention_only",
-                          parity_log)
-    assert 0 < used < sum(1 for _ in plain.parameters())
+    _, used = _same_grads(ddp.module.named_parameters(), want, noise, "ddp_world1_acv_attention_only", parity_log)
+    assert 0 < used < len(want)
 
 
 @pytest.mark.gpu
@@ -296,8 +309,7 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
     through RCCL."""
     from stereo_toolbox_amd.distributed import FlatGradSync
     torch.backends.cudnn.benchmark = False
-    plain = _filled_model("GwcNet_GC", 64).cuda().train()
-    _gpu_step(plain)
+    want, _, noise = _plain_reference("GwcNet_GC", 64)
     m = _filled_model("GwcNet_GC", 64).cuda().train()
     gs = FlatGradSync(m, buckets=2, overlap=True, collective_at_world_1=True)
     assert gs.overlap and gs.exchange and gs.nb == 2
@@ -316,8 +328,7 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
             gs.finish()
             torch.cuda.synchronize()
             assert gs.views_intact() and all(gs._launched)
-            _same_grads(m.named_parameters(), [q.grad for q in plain.parameters()], f"flat_grad_sync_overlap_world1[step{it}]",
-                        parity_log)
+            _same_grads(m.named_parameters(), want, noise, f"flat_grad_sync_overlap_world1[step{it}]", parity_log)
     finally:
         dist.all_reduce = orig
     assert len(calls) == 4 and all(c[1] for c in calls) and all(c[2] == dist.ReduceOp.AVG for c in calls)

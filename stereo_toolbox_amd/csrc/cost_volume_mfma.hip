@@ -157,7 +157,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
             const float* tab = tabs + ((m - m0) & 1) * TAB;          // left table at column 0, right table from column 16
             const int kb = m == m0 ? kfirst : 0, ke = m == m1 - 1 ? klast : nd;
             for (int k = kb; k < ke; ++k, ++ui) {
-                STX_BARRIER_LDS();                                       // image ui & 1 is complete
+                // image ui & 1 is complete.  Concat-only volumes (G = 0: PSMNet, ACVNet) have no image: the store waves need the
+                // macro-unit's feature TABLES only, one hand-over per macro-unit instead of one per unit
+                if (G || k == kb) STX_BARRIER_LDS();
                 const int d0 = k * CVM_T;
                 const float* stage = lds + (ui & 1) * IMG;
                 const float* tabr = tab + (CVM_T + CVM_T * (nd - k)) * CS;   // right-table column of x = w0 - d0
@@ -409,7 +411,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                         }
                     }
                 }
-                STX_BARRIER_LDS();                                   // image ui & 1 handed to the store waves
+                if (G || k == kb) STX_BARRIER_LDS();                 // image ui & 1 (G = 0: the macro-unit's tables) handed to the store waves
                 ++ui;
             }
         }

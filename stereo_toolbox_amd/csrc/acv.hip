@@ -45,22 +45,31 @@ __global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_kernel(DwArgs a) {
         const long long r = v / a.W;
         const int h = (int)(r % a.H);
         const float* xrow = a.x + (r - h) * a.W * a.C + 4 * cq;      // plane (b, d) of this voxel
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // all nine taps are requested before the first is used: out-of-image taps read a clamped address and are zeroed by a
+        // select (round 4; the loads used to sit inside the bounds tests -- nine dependent branch / load / wait rounds per
+        // output: 0.385 ms per 265 MB volume = 0.17 of the HBM rate, latency-bound)
+        float4 xv[9];
+        bool ok[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int hh = h + dl * (i - 1);
+            const int hc = hh < 0 ? 0 : (hh >= a.H ? a.H - 1 : hh);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int ww = w + dl * (j - 1);
-                const int k = 3 * i + j;
-                if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
-                    const float4 xv = stx_ld4(xrow + ((size_t)hh * a.W + ww) * a.C);
-                    acc.x = fmaf(xv.x, wc[k], acc.x);
-                    acc.y = fmaf(xv.y, wc[9 + k], acc.y);
-                    acc.z = fmaf(xv.z, wc[18 + k], acc.z);
-                    acc.w = fmaf(xv.w, wc[27 + k], acc.w);
-                }
+                const int wc2 = ww < 0 ? 0 : (ww >= a.W ? a.W - 1 : ww);
+                ok[3 * i + j] = hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+                xv[3 * i + j] = stx_ld4(xrow + ((size_t)hc * a.W + wc2) * a.C);
             }
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 t = ok[k] ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            acc.x = fmaf(t.x, wc[k], acc.x);
+            acc.y = fmaf(t.y, wc[9 + k], acc.y);
+            acc.z = fmaf(t.z, wc[18 + k], acc.z);
+            acc.w = fmaf(t.w, wc[27 + k], acc.w);
         }
         stx_st4(a.out + (size_t)v * a.C + 4 * cq, acc);
     }
@@ -85,21 +94,27 @@ __global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_wgrad_kernel(const floa
         const int w = (int)(v % W), h = (int)((v / W) % H);
         const size_t bd = v / ((size_t)W * H);
         const float4 g = stx_ld4(gy + v * C + 4 * cq);
+        float4 xv[9];                                  // (branch-free loads: see dwconv_hw_kernel)
+        bool ok[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int hh = h + dl * (i - 1);
+            const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int ww = w + dl * (j - 1);
-                if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                    const float4 xv = stx_ld4(x + ((bd * H + hh) * W + ww) * C + 4 * cq);
-                    const int k = 3 * i + j;
-                    s[k] = fmaf(g.x, xv.x, s[k]);
-                    s[9 + k] = fmaf(g.y, xv.y, s[9 + k]);
-                    s[18 + k] = fmaf(g.z, xv.z, s[18 + k]);
-                    s[27 + k] = fmaf(g.w, xv.w, s[27 + k]);
-                }
+                const int wc2 = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+                ok[3 * i + j] = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                xv[3 * i + j] = stx_ld4(x + ((bd * H + hc) * W + wc2) * C + 4 * cq);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 t = ok[k] ? xv[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s[k] = fmaf(g.x, t.x, s[k]);
+            s[9 + k] = fmaf(g.y, t.y, s[9 + k]);
+            s[18 + k] = fmaf(g.z, t.z, s[18 + k]);
+            s[27 + k] = fmaf(g.w, t.w, s[27 + k]);
         }
     }
 #pragma unroll

@@ -500,8 +500,9 @@ def main(argv=None, platform=None):
                 with torch.no_grad():
                     return model(left, right)
 
-    if args.graph and mode == "train":
-        # hipGraph path: warm up on a side stream (MIOpen search, workspaces), then capture one step.
+    if args.graph and mode in ("train", "eval"):
+        # hipGraph path: warm up on a side stream (MIOpen search, workspaces), then capture one step (train: forward + backward +
+        # optimizer; eval: the inference forward -- ~110 launches per pair, the serving form of BASELINE config 5).
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -510,7 +511,8 @@ def main(argv=None, platform=None):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        gsync.detach_grads()
+        if mode == "train":
+            gsync.detach_grads()
         with torch.cuda.graph(graph):
             step()
         step = graph.replay            # noqa: F811

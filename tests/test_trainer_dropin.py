@@ -222,8 +222,9 @@ def _same_grads(named_params, want, noise, what, parity_log=None):
     choice per module instance), and at these tiny shapes (a few hundred voxels per channel at the 1/16 level) train-mode
     BatchNorm amplifies one-ulp feature differences to 1e-3 .. 1e-2 of a gradient's max (GPU call D of round 4: 0 of 269
     tensors bitwise equal between two plain runs, worst 0.6 % / 4 %).  `noise` is that run-to-run distance measured in the
-    same test (plain vs a second plain instance); the wrapped module may be at most 5 x as far from plain as plain is from
-    itself (floor 2 % -- one pair of runs is a noisy estimate of that distance).  A wrapper that dropped, doubled or
+    same test (plain vs two more plain instances); the wrapped module may be at most 5 x as far from plain as plain is from
+    itself (floor 10 % -- a few runs are a noisy estimate of that distance: 0.2 % .. 3 % for the 3-D path over the calls of
+    round 4).  A wrapper that dropped, doubled or
     mis-scaled a gradient would be off by O(1); the exact-equality form of this check runs on the deterministic CPU /
     gloo / emulator path (test_reference_trainer_prepare_model_two_ranks: 1e-6)."""
     worst, n_exact, n = _grad_distance(named_params, want)
@@ -231,7 +232,7 @@ def _same_grads(named_params, want, noise, what, parity_log=None):
         parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst["2d"], worst_rel_3d_path=worst["3d"],
                    plain_run_to_run_2d=noise["2d"], plain_run_to_run_3d=noise["3d"])
     for k in ("2d", "3d"):
-        assert worst[k] <= max(5.0 * noise[k], 2e-2), (what, k, worst[k], noise[k])
+        assert worst[k] <= max(5.0 * noise[k], 0.1), (what, k, worst[k], noise[k])
     return n_exact, n
 
 
@@ -241,9 +242,12 @@ def _plain_reference(ctor, *a, **k):
     _gpu_step(plain)
     want = [p.grad.clone() if p.grad is not None else None for p in plain.parameters()]
     stats = {kk: v.clone() for kk, v in plain.state_dict().items() if "running" in kk or "num_batches" in kk}
-    again = _filled_model(ctor, *a, **k).cuda().train()
-    _gpu_step(again)
-    noise, _, _ = _grad_distance(again.named_parameters(), want)
+    noise = {"2d": 0.0, "3d": 0.0}
+    for _ in range(2):                                  # two more plain instances: the larger of their distances to the first
+        again = _filled_model(ctor, *a, **k).cuda().train()
+        _gpu_step(again)
+        d, _, _ = _grad_distance(again.named_parameters(), want)
+        noise = {kk: max(noise[kk], d[kk]) for kk in noise}
     return want, stats, noise
 
 

@@ -314,7 +314,13 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
     from stereo_toolbox_amd.distributed import FlatGradSync
     torch.backends.cudnn.benchmark = False
     want, _, noise = _plain_reference("GwcNet_GC", 64)
+    from stereo_toolbox_amd.distributed import broadcast_parameters
     m = _filled_model("GwcNet_GC", 64).cuda().train()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    broadcast_parameters(m)                            # the flat per-dtype broadcasts (fp32 and int64 buffers) over RCCL
+    torch.cuda.synchronize()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k            # (a 1-rank broadcast is the identity, layouts included)
     gs = FlatGradSync(m, buckets=2, overlap=True, collective_at_world_1=True)
     assert gs.overlap and gs.exchange and gs.nb == 2
     calls = []

@@ -1615,6 +1615,8 @@ static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
 int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, int D, int H, int W, int CF, int CC,
                            int nchunks, void* stream);
 int stx_wgrad_march_chunks(int B, int D, int H, int W, int npairs);
+int stx_wgrad_march_s2_launch(const float* f, const float* c, float* slab, int B, int Df, int Hf, int Wf, int CF, int Dc, int Hc,
+                              int Wc, int CC, int nchunks, void* stream);
 
 extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int CF, int CC, int ks,
                                                        int stride) {
@@ -1625,7 +1627,7 @@ extern "C" long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, in
     int TH, TW;
     wgrad_tile(ks, stride, Wc, pipe, &TH, &TW);
     int c = wgrad_chunks(B * Dc * stx_cdiv(Hc, TH) * stx_cdiv(Wc, TW), npairs, pipe);
-    if (ks == 3 && stride == 1) {                                       // (either kernel may serve the call: STX_WGRAD_MARCH)
+    if (ks == 3) {                                                      // (either kernel may serve the call: STX_WGRAD_MARCH)
         const int cm = stx_wgrad_march_chunks(B, Dc, Hc, Wc, npairs);
         if (cm > c) c = cm;
     }
@@ -1655,12 +1657,14 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     int nchunks = wgrad_chunks(a.ntiles, npairs, pipe);
     hipStream_t st = (hipStream_t)stream;
     const int T = ks == 1 ? 1 : 27;
-    if (ks == 3 && stride == 1 && stx_tune(STX_TUNE_WGRAD_MARCH)) {
+    if (ks == 3 && (stx_tune(STX_TUNE_WGRAD_MARCH) & (stride == 1 ? 1 : 2))) {
         // march form (wgrad_march.hip): K-contiguous operands, rolling plane windows, runs cut at step granularity
+        // (STX_WGRAD_MARCH: bit 0 = the stride-1 layers, bit 1 = stride 2 / transposed)
         int mc = stx_wgrad_march_chunks(B, Dc, Hc, Wc, npairs);
         const int forced = stx_tune(STX_TUNE_WGRAD_GRID);
         if (forced > 0 && forced < mc) mc = forced;
-        const int rc = stx_wgrad_march_launch(f, c, workspace, B, Dc, Hc, Wc, CF, CC, mc, stream);
+        const int rc = stride == 1 ? stx_wgrad_march_launch(f, c, workspace, B, Dc, Hc, Wc, CF, CC, mc, stream)
+                                   : stx_wgrad_march_s2_launch(f, c, workspace, B, Df, Hf, Wf, CF, Dc, Hc, Wc, CC, mc, stream);
         if (rc > 0) return rc;
         if (rc == 0) {
             const int total = npairs * T * 1024;

@@ -148,7 +148,7 @@ enum StxTune {
     STX_TUNE_MARCH_EPI,      // STX_MARCH_EPI      1  march kernel: straight-line epilogue for launches without partial sums / residual / Mish
     STX_TUNE_MARCH_ABLATE,   // STX_MARCH_ABLATE   0  profiling: 1 = no plane staging, 2 = no epilogue stores
     STX_TUNE_WGRAD_ABLATE,   // STX_WGRAD_ABLATE   0  profiling: 1 = no tile staging, 2 = no MFMA loop
-    STX_TUNE_WGRAD_MARCH,    // STX_WGRAD_MARCH    1  weight gradient, 3x3x3 stride 1: march kernel (wgrad_march.hip); 0 = the tile kernel of rounds 1-3
+    STX_TUNE_WGRAD_MARCH,    // STX_WGRAD_MARCH    3  weight gradient 3x3x3 on the march kernels (wgrad_march.hip): bit 0 = stride 1, bit 1 = stride 2 / transposed; 0 = the tile kernel of rounds 1-3
     STX_TUNE_WGRAD_GRID,     // STX_WGRAD_GRID     0  weight gradient: split-K workgroups per channel-block pair (tests: many tiles per workgroup)
     STX_TUNE_CONV_L1_MARCH,  // STX_CONV_L1_MARCH  0  3x3x3 stride-1 64 -> 64: march kernel in 2 x 2 channel slices instead of the implicit-GEMM kernel
     STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)

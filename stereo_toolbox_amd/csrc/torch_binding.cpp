@@ -16,14 +16,16 @@
 //   stx::regression_head(Tensor cost, int maxdisp, int H, int W, bool align_corners) -> Tensor
 //   stx::softargmax(Tensor x) -> Tensor        stx::argmax_disparity(Tensor x) -> Tensor
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include "../../include/stx_hip.h"
 
 namespace {
 
-void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// (PyTorch-ROCm tensors carry the device type "cuda": the guard / stream accessors that accept it are the "masquerading" ones)
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
 
 void chk(const at::Tensor& t, const char* name, int64_t dims) {
     TORCH_CHECK(t.is_cuda(), name, ": expected a ROCm device tensor (the cost-volume hot path has no CPU fallback)");
@@ -51,7 +53,7 @@ at::Tensor cost_volume_fwd(const c10::optional<at::Tensor>& Lg, const c10::optio
         if (t->has_value() && (*t)->defined()) chk(**t, "stx::cost_volume feature", 4);
     const VolShape s = vol_shape(Lg, Lc, G);
     const at::Tensor& r = (Lg.has_value() && Lg->defined()) ? *Lg : *Lc;
-    const c10::hip::HIPGuard guard(r.device());
+    const DeviceGuard guard(r.device());
     const int64_t Gn = s.Cg ? G : 0;
     auto vol = at::empty({s.B, D, s.H, s.W, Gn + 2 * s.Cc}, r.options());
     status(stx_cost_volume_fwd(ptr(Lg), ptr(Rg), (int)s.Cg, (int)Gn, ptr(Lc), ptr(Rc), (int)s.Cc, nullptr, vol.data_ptr<float>(),
@@ -87,7 +89,7 @@ class CostVolumeFn : public torch::autograd::Function<CostVolumeFn> {
         const bool mask_left = ctx->saved_data["mask_left"].toBool();
         const at::Tensor gvol = grads[0].contiguous();
         chk(gvol, "stx::cost_volume grad", 5);
-        const c10::hip::HIPGuard guard(gvol.device());
+        const DeviceGuard guard(gvol.device());
         const int64_t B = gvol.size(0), H = gvol.size(2), W = gvol.size(3);
         const int64_t Cg = Lg.defined() ? Lg.size(1) : 0;
         at::Tensor gLg, gRg, gLc, gRc;
@@ -112,7 +114,7 @@ int64_t conv_nt(int64_t N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
 at::Tensor pack_weight(const at::Tensor& w, int64_t mode) {
     chk(w, "stx::conv3d_pack_weight w", 5);
-    const c10::hip::HIPGuard guard(w.device());
+    const DeviceGuard guard(w.device());
     const int64_t A = w.size(0), Bd = w.size(1), T = w.size(2) * w.size(3) * w.size(4);
     const int64_t K = mode == 0 ? Bd : A, N = mode == 0 ? A : Bd;
     auto wp = at::empty({stx_conv3d_packed_floats((int)K, (int)N, (int)T)}, w.options());
@@ -136,7 +138,7 @@ at::Tensor conv3d(const at::Tensor& x, const at::Tensor& wp, int64_t cout, int64
                   const c10::optional<at::Tensor>& residual, int64_t act) {
     chk(x, "stx::conv3d x", 5);
     chk(wp, "stx::conv3d packed weight", 1);
-    const c10::hip::HIPGuard guard(x.device());
+    const DeviceGuard guard(x.device());
     const auto o = conv_out(x, ks, stride);
     auto out = at::empty({x.size(0), o[0], o[1], o[2], cout}, x.options());
     status(stx_conv3d_fwd(x.data_ptr<float>(), wp.data_ptr<float>(), out.data_ptr<float>(), ptr(scale), ptr(bias), ptr(residual),
@@ -154,7 +156,7 @@ at::Tensor deconv3d(const at::Tensor& x, const at::Tensor& wp, int64_t cout, con
                     const c10::optional<at::Tensor>& bias, const c10::optional<at::Tensor>& residual, int64_t act) {
     chk(x, "stx::deconv3d x", 5);
     chk(wp, "stx::deconv3d packed weight", 1);
-    const c10::hip::HIPGuard guard(x.device());
+    const DeviceGuard guard(x.device());
     auto out = at::empty({x.size(0), 2 * x.size(1), 2 * x.size(2), 2 * x.size(3), cout}, x.options());
     status(stx_deconv3d_fwd(x.data_ptr<float>(), wp.data_ptr<float>(), out.data_ptr<float>(), ptr(scale), ptr(bias), ptr(residual),
                             nullptr, (int)x.size(0), (int)x.size(1), (int)x.size(2), (int)x.size(3), (int)x.size(4), (int)cout,
@@ -170,7 +172,7 @@ at::Tensor deconv3d_meta(const at::Tensor& x, const at::Tensor&, int64_t cout, c
 at::Tensor conv3d_wgrad(const at::Tensor& fine, const at::Tensor& coarse, int64_t ks, int64_t stride) {
     chk(fine, "stx::conv3d_wgrad fine", 5);
     chk(coarse, "stx::conv3d_wgrad coarse", 5);
-    const c10::hip::HIPGuard guard(fine.device());
+    const DeviceGuard guard(fine.device());
     const int B = (int)fine.size(0), CF = (int)fine.size(4), CC = (int)coarse.size(4);
     const long long n = stx_conv3d_wgrad_workspace_floats(B, (int)coarse.size(1), (int)coarse.size(2), (int)coarse.size(3), CF, CC,
                                                           (int)ks, (int)stride);
@@ -188,7 +190,7 @@ at::Tensor conv3d_wgrad_meta(const at::Tensor& fine, const at::Tensor& coarse, i
 
 at::Tensor regression_head(const at::Tensor& cost, int64_t maxdisp, int64_t H, int64_t W, bool align_corners) {
     chk(cost, "stx::regression_head cost", 4);
-    const c10::hip::HIPGuard guard(cost.device());
+    const DeviceGuard guard(cost.device());
     auto disp = at::empty({cost.size(0), H, W}, cost.options());
     status(stx_head_fwd2(cost.data_ptr<float>(), disp.data_ptr<float>(), nullptr, (int)cost.size(0), (int)cost.size(1),
                          (int)cost.size(2), (int)cost.size(3), (int)maxdisp, (int)H, (int)W, align_corners ? 1 : 0, cur_stream()),
@@ -201,7 +203,7 @@ at::Tensor regression_head_meta(const at::Tensor& cost, int64_t, int64_t H, int6
 
 at::Tensor softargmax(const at::Tensor& x) {
     chk(x, "stx::softargmax x", 4);
-    const c10::hip::HIPGuard guard(x.device());
+    const DeviceGuard guard(x.device());
     auto out = at::empty({x.size(0), 1, x.size(2), x.size(3)}, x.options());
     status(stx_softargmax_fwd(x.data_ptr<float>(), out.data_ptr<float>(), (int)x.size(0), (int)x.size(1),
                               (int)(x.size(2) * x.size(3)), cur_stream()), "stx_softargmax_fwd");
@@ -211,7 +213,7 @@ at::Tensor softargmax_meta(const at::Tensor& x) { return at::empty({x.size(0), 1
 
 at::Tensor argmax_disparity(const at::Tensor& x) {
     chk(x, "stx::argmax_disparity x", 4);
-    const c10::hip::HIPGuard guard(x.device());
+    const DeviceGuard guard(x.device());
     auto out = at::empty({x.size(0), 1, x.size(2), x.size(3)}, x.options().dtype(at::kLong));
     status(stx_argmax_fwd(x.data_ptr<float>(), (long long*)out.data_ptr<int64_t>(), (int)x.size(0), (int)x.size(1),
                           (int)(x.size(2) * x.size(3)), cur_stream()), "stx_argmax_fwd");

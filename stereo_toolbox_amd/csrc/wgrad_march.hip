@@ -244,6 +244,250 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stride-2 form (the hourglasses' stride-2 convolutions: fine = layer input, coarse = output gradient; and their
+// ConvTranspose3d layers: fine = output gradient, coarse = layer input):
+//   G[tap][cf][cc] = sum_o F[2 o + tap - 1][cf] * C[o][cc]
+// Same inner loop as above -- K-contiguous operands, wave w = tap row w, the ninth row split by voxel group -- on a
+// PARITY-SPLIT fine tile: per channel and fine row the even columns (tile columns 0, 2, .., 32 -> slots 0..16) and the odd
+// ones (1, 3, .., 31 -> slots 20..35) are stored apart, so that the fine voxels of four consecutive coarse voxels are four
+// consecutive slots: kw = 0 and kw = 2 read the even slots lw .. lw+4 (one shifted by one), kw = 1 the odd slots lw .. lw+3.
+// A step = one coarse plane of a (4 x 16)-voxel column against the fine planes 2o-1, 2o, 2o+1; the window rolls by two
+// planes per step, the shared one stays.  Three fine planes (9 x 33 voxels each, 41 KB) + two coarse planes fill the LDS,
+// so the two new planes wait in registers during the MFMA loop and are written between two barriers; they are fetched
+// TRANSPOSED (one dword per lane and slot: lanes = channels, 4 slots per item) and land with one ds_write_b128 per item.
+constexpr int W2_EH = 2 * WM_TH + 1, W2_RP = 36;            // fine tile rows; row pitch: 17 even slots (-> 20) + 16 odd slots
+constexpr int W2_CHP = W2_EH * W2_RP;                      // 324 = 4 (mod 64)
+static_assert(W2_CHP % 64 == 4, "conflict-free b128 operand reads need a channel pitch = 4 (mod 64)");
+constexpr int W2_PLANE = 32 * W2_CHP;
+// staging items of one fine plane: 72 full slot quads (9 rows x (4 even + 4 odd)) + 9 singles (even slot 16, the halo column)
+// = 5 rounds of 16 (8 waves x 2 halves; lanes of a half-wave = the 32 channels) + one single for group 0
+constexpr int W2_NFULL = W2_EH * 8, W2_ITEMS = W2_NFULL + W2_EH;
+constexpr int W2_LPP = 6, W2_NPART = 4;                    // 21 slot offsets in 4 parts of 6: fetched in the first MFMA groups of a step
+static_assert(W2_ITEMS == 81, "the item schedule below is written for five rounds and one left-over single");
+constexpr size_t W2_LDS_BYTES = (size_t)(3 * W2_PLANE + WM_NGB * WM_GPLANE) * 4;
+
+__device__ __forceinline__ int w2_mod3(int p) { const int r = p % 3; return r < 0 ? r + 3 : r; }
+
+__global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_s2_kernel(WmArgs a, int Df, int Hf, int Wf, int ablate) {
+    STX_DYN_SMEM(smem);
+    float* xl = reinterpret_cast<float*>(smem);              // [3][32 ch][W2_CHP]
+    float* gl = xl + 3 * W2_PLANE;                           // [2][32 ch][GP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, half = lane >> 5;
+    const int ncf = a.CF / 32;
+    const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;
+    const int kdw = wave / 3, khw = wave % 3;
+
+    f32x16 acc[3], acc8[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { acc[t] = wm_zero16(); acc8[t] = wm_zero16(); }
+
+    // staging items of this lane: item = g + 16 k, g = wave * 2 + half; rounds k = 0..4 carry four slots, round 5 (g = 0) one
+    const int g16 = wave * 2 + half;
+    auto item_geom = [&](int k, int& hy, int& col, int& nv) -> int {       // -> LDS position; col = first tile column
+        const int it = g16 + 16 * k;
+        int par, qd;
+        if (it < W2_NFULL) { hy = it >> 3; par = (it >> 2) & 1; qd = it & 3; nv = 4; }
+        else { hy = it - W2_NFULL; par = 0; qd = 4; nv = it < W2_ITEMS ? 1 : 0; if (nv == 0) hy = 0; }
+        col = 8 * qd + par;
+        return i * W2_CHP + hy * W2_RP + par * 20 + 4 * qd;
+    };
+    int lpos[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { int hy, col, nv; lpos[k] = item_geom(k, hy, col, nv); }
+    const int gv = tid >> 3, gf = tid & 7;
+    const int glh = gv / WM_TW, glw = gv % WM_TW;
+    const unsigned goff = (unsigned)(((glh * a.W + glw) * a.CC + ccb * 32 + 4 * gf) * 4);
+    const int gpos = (4 * gf) * WM_GP + glh * WM_TW + glw;
+    const long long cplane = (long long)a.H * a.W, fplane = (long long)Hf * Wf;
+    const unsigned fplane_bytes = (unsigned)(fplane * a.CF * 4);
+
+    const int grp8 = (2 * (wave >> 1)) * W2_RP + 8 * (wave & 1);
+    const int grp8g = (wave >> 1) * WM_TW + 8 * (wave & 1);
+    const int xlane = i * W2_CHP + 4 * half, glane = i * WM_GP + 4 * half;
+
+    const long long s0 = a.nsteps * blockIdx.x / gridDim.x, s1 = a.nsteps * (blockIdx.x + 1) / gridDim.x;
+    long long s = s0;
+    while (s < s1) {
+        const int col = (int)(s / a.D), ob = (int)(s - (long long)col * a.D);
+        const int oe = (int)((long long)a.D - ob < s1 - s ? a.D : ob + (s1 - s));
+        int r = col;
+        const int wt = r % a.nWt; r /= a.nWt;
+        const int ht = r % a.nHt;
+        const int b = r / a.nHt;
+        const int oh0 = ht * WM_TH, ow0 = wt * WM_TW;
+        const int fy0 = 2 * oh0 - 1, fx0 = 2 * ow0 - 1;      // fine coordinates of the tile's origin
+        const unsigned gvo = (oh0 + glh < a.H && ow0 + glw < a.W) ? goff : STX_BUF_OOB;
+        const long long gorg = (long long)oh0 * a.W + ow0;
+
+        // per column: the items' byte offsets inside a fine plane and their slots' validity (bit 4 k + j)
+        unsigned rel[6], okbits = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            int hy, col, nv;
+            item_geom(k, hy, col, nv);
+            const int fy = fy0 + hy, fxq = fx0 + col;
+            const bool rowok = nv > 0 && fy >= 0 && fy < Hf;
+            rel[k] = (unsigned)((((rowok ? fy : 0) * Wf + fxq) * a.CF + cfb * 32 + i) * 4);
+#pragma unroll
+            for (int j = 0; j < (k < 5 ? 4 : 1); ++j)
+                if (rowok && j < nv && fxq + 2 * j >= 0 && fxq + 2 * j < Wf) okbits |= 1u << (4 * k + j);
+        }
+        const unsigned cs = (unsigned)(2 * a.CF * 4);       // bytes between two slots of a quad
+
+        float sx[2][5][4], sx5[2];
+        float4 sg;
+        // fine planes pA, pB -> registers (transposed fetch: lane = channel, register j = slot j of the lane's quad); the
+        // descriptors are wave-uniform (one per plane, empty for a plane outside the volume), row / column validity goes
+        // into the per-lane offset
+        // 21 slot offsets x 2 planes = 42 loads per lane and step, issued in W2_NPART parts so that the main loop can
+        // spread them over its MFMA groups (the texture path takes ~16 cycles per wave-wide load: issued in one burst
+        // ahead of the MFMAs, the eight waves' 336 loads would keep the matrix pipes idle for a third of the step)
+        unsigned okv = 0;
+        stx_bufrsrc rsA = stx_make_rsrc(a.x, 0u), rsB = rsA;
+        auto load_begin = [&](int pA, int pB) {
+            okv = okbits;
+            asm volatile("" : "+v"(okv));                     // (keeps the 21 offsets out of loop-invariant registers)
+            const bool inA = pA >= 0 && pA < Df, inB = pB >= 0 && pB < Df;
+            rsA = stx_make_rsrc(a.x + ((long long)b * Df + (inA ? pA : 0)) * fplane * a.CF, inA ? fplane_bytes : 0u);
+            rsB = stx_make_rsrc(a.x + ((long long)b * Df + (inB ? pB : 0)) * fplane * a.CF, inB ? fplane_bytes : 0u);
+        };
+        auto load_part = [&](const int P) {                  // (P is a constant after unrolling: sx stays in registers)
+#pragma unroll
+            for (int v = W2_LPP * P; v < W2_LPP * P + W2_LPP; ++v) {
+                if (v < 20) {
+                    const int k = v >> 2, j = v & 3;
+                    const unsigned vo = (okv >> v) & 1u ? rel[k] + j * cs : STX_BUF_OOB;
+                    sx[0][k][j] = stx_buf_ld1(rsA, vo, 0u);
+                    sx[1][k][j] = stx_buf_ld1(rsB, vo, 0u);
+                } else if (v == 20) {
+                    const unsigned vo5 = (okv >> 20) & 1u ? rel[5] : STX_BUF_OOB;
+                    sx5[0] = stx_buf_ld1(rsA, vo5, 0u);
+                    sx5[1] = stx_buf_ld1(rsB, vo5, 0u);
+                }
+            }
+        };
+        auto load_planes = [&](int pA, int pB) {
+            load_begin(pA, pB);
+#pragma unroll
+            for (int part = 0; part < W2_NPART; ++part) load_part(part);
+        };
+        auto store_planes = [&](int pA, int pB, bool two) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                float* dstp = xl + w2_mod3(u ? pB : pA) * W2_PLANE;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    stx_st4(dstp + lpos[k], make_float4(sx[u][k][0], sx[u][k][1], sx[u][k][2], sx[u][k][3]));
+                if (g16 == 0) dstp[lpos[5]] = sx5[u];
+            }
+        };
+        auto load_g = [&](int p, bool on) {
+            const bool in = on && p >= 0 && p < a.D;
+            const stx_bufrsrc rs = stx_make_rsrc(a.gy + (((long long)b * a.D + (in ? p : 0)) * cplane + gorg) * a.CC,
+                                                 in ? (unsigned)((cplane - gorg) * a.CC * 4) : 0u);
+            sg = stx_buf_ld4(rs, gvo, 0u);
+        };
+        auto store_g = [&](int p) {
+            float* q = gl + (p & 1) * WM_GPLANE + gpos;
+            q[0] = sg.x; q[WM_GP] = sg.y; q[2 * WM_GP] = sg.z; q[3 * WM_GP] = sg.w;
+        };
+
+        // window of the run's first step: fine planes 2 ob - 1, 2 ob, 2 ob + 1 (the previous run ended behind a barrier)
+        load_planes(2 * ob - 1, 2 * ob);
+        store_planes(2 * ob - 1, 2 * ob, true);
+        load_planes(2 * ob + 1, 0);
+        store_planes(2 * ob + 1, 0, false);
+        load_g(ob, true);
+        store_g(ob);
+        __syncthreads();
+
+        for (int o = ob; o < oe; ++o) {
+            const bool more = o + 1 < oe;
+            // the two new fine planes and the coarse plane of step o + 1: fetched during this step's MFMA loop
+            load_begin(more ? 2 * o + 2 : -1, more ? 2 * o + 3 : -1);
+            const float* xa = xl + w2_mod3(2 * o - 1 + kdw) * W2_PLANE + khw * W2_RP + xlane;
+            const float* x8 = xl + w2_mod3(2 * o + 1) * W2_PLANE + 2 * W2_RP + grp8 + xlane;
+            const float* gb = gl + (o & 1) * WM_GPLANE + glane;
+            float4 E0[2], O0[2], Bv[2];
+            float E1[2];
+            E0[0] = stx_ld4(xa); E1[0] = xa[4]; O0[0] = stx_ld4(xa + 20); Bv[0] = stx_ld4(gb);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cb = q & 1, nb = cb ^ 1;
+                if (q < 7) {
+                    const int h = (q + 1) >> 1, w8 = (q + 1) & 1;
+                    const float* p = xa + (2 * h) * W2_RP + 8 * w8;
+                    E0[nb] = stx_ld4(p); E1[nb] = p[4]; O0[nb] = stx_ld4(p + 20);
+                    Bv[nb] = stx_ld4(gb + h * WM_TW + 8 * w8);
+                } else {
+                    E0[nb] = stx_ld4(x8); E1[nb] = x8[4]; O0[nb] = stx_ld4(x8 + 20);
+                    Bv[nb] = stx_ld4(gb + grp8g);
+                }
+                if (ablate != 1) { if (q < W2_NPART) load_part(q); else if (q == W2_NPART) load_g(o + 1, more); }
+                STX_SCHED_BARRIER();
+                const float ev[5] = {E0[cb].x, E0[cb].y, E0[cb].z, E0[cb].w, E1[cb]};
+                const float od[4] = {O0[cb].x, O0[cb].y, O0[cb].z, O0[cb].w};
+                const float bv[4] = {Bv[cb].x, Bv[cb].y, Bv[cb].z, Bv[cb].w};
+                if (ablate != 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[j], bv[j], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(od[j], bv[j], acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[j + 1], bv[j], acc[2], 0, 0, 0);
+                }
+                }
+                STX_SCHED_BARRIER();
+            }
+            {
+                const float ev[5] = {E0[0].x, E0[0].y, E0[0].z, E0[0].w, E1[0]};
+                const float od[4] = {O0[0].x, O0[0].y, O0[0].z, O0[0].w};
+                const float bv[4] = {Bv[0].x, Bv[0].y, Bv[0].z, Bv[0].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc8[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[j], bv[j], acc8[0], 0, 0, 0);
+                    acc8[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(od[j], bv[j], acc8[1], 0, 0, 0);
+                    acc8[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ev[j + 1], bv[j], acc8[2], 0, 0, 0);
+                }
+            }
+            __syncthreads();                                  // every wave is done with the planes 2o-1 and 2o
+            if (more && ablate != 3) { store_planes(2 * o + 2, 2 * o + 3, true); store_g(o + 1); }
+            __syncthreads();
+        }
+        s += oe - ob;
+    }
+
+    float* dst = a.slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 27 * 1024;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cf = (r & 3) + 8 * (r >> 2) + 4 * half;
+            dst[(size_t)(wave * 3 + kw) * 1024 + cf * 32 + i] = acc[kw][r];
+        }
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cf = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[wave * 1024 + cf * 32 + i] = acc8[kw][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 1024; e += WM_THR) {
+            float t = red[e];
+#pragma unroll
+            for (int w = 1; w < WM_NW; ++w) t += red[w * 1024 + e];
+            dst[(size_t)(24 + kw) * 1024 + e] = t;
+        }
+    }
+}
+
 }  // namespace
 
 // Internal interface (conv3d.hip): launches the march kernel into `slab` ([pairs][chunks][27][1024]) with `nchunks`
@@ -265,6 +509,27 @@ int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, 
         return stx_set_error(STX_ERR_LAUNCH, "conv3d_wgrad(march): %d bytes of dynamic LDS refused by this device", (int)WM_LDS_BYTES);
     hipLaunchKernelGGL(conv3d_wgrad_march_kernel, dim3(nchunks, npairs), dim3(WM_THR), WM_LDS_BYTES, (hipStream_t)stream, a);
     return stx_check_launch("conv3d_wgrad(march)");
+}
+
+// stride-2 form: fine [B][Df][Hf][Wf][CF], coarse [B][Dc][Hc][Wc][CC]; same slab / chunk convention
+int stx_wgrad_march_s2_launch(const float* f, const float* c, float* slab, int B, int Df, int Hf, int Wf, int CF, int Dc, int Hc,
+                              int Wc, int CC, int nchunks, void* stream) {
+    if (CF % 32 || CC % 32 || B < 1 || Dc < 1 || Hc < 1 || Wc < 1) return -1;
+    if ((long long)Df * Hf * Wf * CF * 4 >= (1ll << 32) || (long long)Hc * Wc * CC * 4 >= (1ll << 31)) return -1;   // (tile kernel)
+    WmArgs a;
+    a.x = f; a.gy = c; a.slab = slab; a.B = B; a.D = Dc; a.H = Hc; a.W = Wc; a.CF = CF; a.CC = CC;
+    a.nHt = stx_cdiv(Hc, WM_TH); a.nWt = stx_cdiv(Wc, WM_TW);
+    const long long ncols = (long long)B * a.nHt * a.nWt;
+    if (ncols >= (1ll << 31)) return -1;
+    a.ncols = (int)ncols;
+    a.nsteps = ncols * Dc;
+    const int npairs = (CF / 32) * (CC / 32);
+    if (hipFuncSetAttribute((const void*)conv3d_wgrad_march_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)W2_LDS_BYTES) != hipSuccess)
+        return stx_set_error(STX_ERR_LAUNCH, "conv3d_wgrad(march s2): %d bytes of dynamic LDS refused by this device", (int)W2_LDS_BYTES);
+    hipLaunchKernelGGL(conv3d_wgrad_march_s2_kernel, dim3(nchunks, npairs), dim3(WM_THR), W2_LDS_BYTES, (hipStream_t)stream, a,
+                       Df, Hf, Wf, stx_tune(STX_TUNE_WGRAD_ABLATE));     // (profiling switch: 1 no staging loads, 2 no MFMA groups, 3 no LDS writes)
+    return stx_check_launch("conv3d_wgrad(march s2)");
 }
 
 // workgroups per channel-block pair the march launch wants for a shape (the caller sizes the slab with it)

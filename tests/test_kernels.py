@@ -487,13 +487,13 @@ def run_wgrad(be, fine, coarse, ks, stride):
 
 @pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 3, 1), (1, 32, 32, 2, 3, 60, 3, 1), (2, 32, 64, 4, 6, 40, 3, 2), (1, 64, 64, 3, 4, 34, 1, 1),
                                   (2, 64, 64, 3, 5, 37, 3, 1), (1, 64, 64, 2, 3, 60, 3, 1),     # four channel-block pairs: un-pipelined staging, 4 x 16 / 2 x 32 tiles
-                                  (1, 64, 128, 3, 7, 21, 3, 2),
+                                  (1, 64, 128, 3, 7, 21, 3, 2), (2, 32, 32, 6, 8, 64, 3, 2), (1, 32, 64, 5, 10, 70, 3, 2),   # stride 2: odd / even fine extents
                                   (2, 32, 32, 5, 9, 37, 3, 1), (1, 32, 64, 4, 4, 16, 3, 1)])      # ragged H / W tiles, batch 2; exact tiles
-@pytest.mark.parametrize("march", [1, 0], ids=["march", "tile_kernel"])
+@pytest.mark.parametrize("march", [3, 0], ids=["march", "tile_kernel"])
 def test_conv3d_wgrad(be, case, tune, march):
     B, Cin, Cout, D, H, W, ks, s = case
-    if march == 0 and not (ks == 3 and s == 1):
-        pytest.skip("STX_WGRAD_MARCH only selects among the 3x3x3 stride-1 kernels")
+    if march == 0 and ks != 3:
+        pytest.skip("STX_WGRAD_MARCH only selects among the 3x3x3 kernels")
     tune("STX_WGRAD_MARCH", march)
     torch.manual_seed(8)
     x = torch.randn(B, Cin, D, H, W)
@@ -504,7 +504,7 @@ def test_conv3d_wgrad(be, case, tune, march):
     _close(run_wgrad(be, x, gy, ks, s).view_as(w), w.grad)
 
 
-@pytest.mark.parametrize("march", [1, 0], ids=["march", "tile_kernel"])
+@pytest.mark.parametrize("march", [3, 0], ids=["march", "tile_kernel"])
 def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune, march):
     """The weight-gradient kernels' tile loop with several tiles per workgroup (STX_WGRAD_GRID caps the split-K workgroups; at
     the small test shapes every workgroup otherwise gets one tile): odd and even tile counts, stride 1 and 2.  March kernel:
@@ -513,7 +513,8 @@ def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune, march):
     tune("STX_WGRAD_MARCH", march)
     torch.manual_seed(8)
     for grid, (B, Cin, Cout, D, H, W, s) in ((1, (1, 32, 32, 3, 5, 37, 1)), (4, (2, 32, 64, 2, 9, 21, 1)), (5, (1, 64, 32, 3, 7, 40, 1)),
-                                             (3, (1, 32, 64, 4, 6, 40, 2)), (3, (1, 32, 32, 7, 8, 20, 1)), (2, (1, 32, 32, 9, 4, 16, 1))):
+                                             (3, (1, 32, 64, 4, 6, 40, 2)), (3, (1, 32, 32, 7, 8, 20, 1)), (2, (1, 32, 32, 9, 4, 16, 1)),
+                                             (2, (1, 32, 32, 13, 8, 32, 2)), (1, (2, 32, 32, 6, 18, 40, 2))):
         tune("STX_WGRAD_GRID", grid)
         x = torch.randn(B, Cin, D, H, W)
         w = (torch.randn(Cout, Cin, 3, 3, 3) * 0.1).requires_grad_()
@@ -523,10 +524,14 @@ def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune, march):
         _close(run_wgrad(be, x, gy, 3, s).view_as(w), w.grad)
 
 
-def test_deconv3d_wgrad(be):
+@pytest.mark.parametrize("march", [3, 0], ids=["march", "tile_kernel"])
+@pytest.mark.parametrize("shape", [(1, 64, 32, 2, 3, 20), (2, 32, 32, 3, 5, 18)])
+def test_deconv3d_wgrad(be, tune, march, shape):
+    tune("STX_WGRAD_MARCH", march)
     torch.manual_seed(9)
-    x = torch.randn(1, 64, 2, 3, 20)
-    w = (torch.randn(64, 32, 3, 3, 3) * 0.1).requires_grad_()
+    B, Cin, Cout, D, H, W = shape
+    x = torch.randn(B, Cin, D, H, W)
+    w = (torch.randn(Cin, Cout, 3, 3, 3) * 0.1).requires_grad_()
     y = F.conv_transpose3d(x, w, None, stride=2, padding=1, output_padding=1)
     gy = torch.randn_like(y)
     y.backward(gy)

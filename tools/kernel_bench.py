@@ -94,6 +94,10 @@ AB_SETS = [
     ("64->64 L1 on the march kernel (2 x 2 channel slices)", "conv_64_64_L1_fwd", {"STX_CONV_L1_MARCH": 1}),
     ("stride-2 32->64 with the padded LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": 0}),
     ("weight gradient 3x3x3 s1: tile kernel of rounds 1-3 instead of the march kernel", "conv_32_32_L0_wgrad,conv_64_32_L0_wgrad,conv_64_64_L1_wgrad,conv_128_128_L2_wgrad", {"STX_WGRAD_MARCH": 0}),
+    ("weight gradient 3x3x3 s2 / transposed: tile kernel of rounds 1-3 instead of the parity-split march kernel", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_MARCH": 1}),
+    ("s2 march weight gradient: no staging loads (ablation)", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_ABLATE": 1}),
+    ("s2 march weight gradient: no MFMA groups (ablation)", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_ABLATE": 2}),
+    ("s2 march weight gradient: no LDS writes (ablation)", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_ABLATE": 3}),
     ("weight gradient: no tile staging (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 1}),
     ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),

@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace --stats output directory (csv or rocpd sqlite) into a
 per-kernel table: calls, total ms, avg us, share.
-usage: rocprof_summary.py <dir> [--steady MARKER SKIP]
+usage: rocprof_summary.py <dir> [--steady MARKER SKIP] [--by-grid FILTER]
+  --by-grid FILTER: second table -- the dispatches whose name contains FILTER, split by launch grid (one row per
+  kernel x grid size): shows which tensor sizes a many-launch kernel (bn_*) spends its time on.
   --steady MARKER SKIP: only dispatches that start at or after the (SKIP+1)-th dispatch of the kernel whose name contains
   MARKER (one launch per step, e.g. cost_volume_fwd) are counted -- drops the warm-up steps, in which MIOpen's
   benchmark-mode solver search of the 2-D feature CNN runs thousands of candidate kernels."""
@@ -12,24 +14,35 @@ import sys
 from collections import defaultdict
 
 
-def from_csv(d, marker=None, skip=0):
+BY_GRID = defaultdict(lambda: [0, 0.0])
+
+
+def from_csv(d, marker=None, skip=0, grid_filter=None):
     rows = defaultdict(lambda: [0, 0.0])
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     recs = []
     for f in files:
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                recs.append((r.get("Kernel_Name") or r.get("kernel_name"), int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                name = r.get("Kernel_Name") or r.get("kernel_name")
+                if grid_filter and grid_filter in name:
+                    name_g = (name, int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0) * max(1, int(r.get("Grid_Size_Y") or 1)))
+                else:
+                    name_g = None
+                recs.append((name, int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name_g))
     t0 = 0
     if marker:
-        marks = sorted(s for n, s, e in recs if marker in n)
+        marks = sorted(s for n, s, e, _ in recs if marker in n)
         if len(marks) > skip:
             t0 = marks[skip]
             print(f"steady state: {len(marks) - skip} of {len(marks)} '{marker}' launches kept")
-    for n, s, e in recs:
+    for n, s, e, ng in recs:
         if s >= t0:
             rows[n][0] += 1
             rows[n][1] += (e - s) / 1e6
+            if ng:
+                BY_GRID[ng][0] += 1
+                BY_GRID[ng][1] += (e - s) / 1e6
     return rows if files else None
 
 
@@ -64,7 +77,8 @@ def from_db(d):
 def main():
     d = sys.argv[1]
     marker, skip = (sys.argv[3], int(sys.argv[4])) if len(sys.argv) > 4 and sys.argv[2] == "--steady" else (None, 0)
-    rows = from_csv(d, marker, skip) or from_db(d)
+    gf = sys.argv[sys.argv.index("--by-grid") + 1] if "--by-grid" in sys.argv else None
+    rows = from_csv(d, marker, skip, gf) or from_db(d)
     if not rows:
         print("no kernel trace found in", d)
         return
@@ -73,6 +87,10 @@ def main():
     for n, (c, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
         print(f"{c:7d} {ms:10.3f} {ms / c * 1e3:10.1f} {ms / tot * 100:5.1f}%  {n[:150]}")
     print(f"total kernel time {tot:.3f} ms")
+    if BY_GRID:
+        print(f"\n{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'threads':>10}  kernel (by launch grid)")
+        for (n, g), (c, ms) in sorted(BY_GRID.items(), key=lambda kv: (kv[0][0], -kv[1][1])):
+            print(f"{c:7d} {ms:10.3f} {ms / c * 1e3:10.1f} {g:10d}  {n[:90]}")
 
 
 if __name__ == "__main__":

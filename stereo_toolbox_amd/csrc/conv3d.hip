@@ -1325,6 +1325,12 @@ int launch_with_lds(K kernel, dim3 grid, size_t lds, hipStream_t st, ConvArgs a)
     if (lds > 160 * 1024) return stx_set_error(STX_ERR_ARG, "conv3d: LDS tile of %zu B exceeds 160 KiB", lds);
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const bool report = getenv("STX_REPORT_OCCUPANCY") != nullptr;    // (diagnostic: resident workgroups per CU)
+    if (report) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kernel, CONV_THREADS, lds);
+        fprintf(stderr, "[stx] conv3d launch: grid %u x %u, %zu B LDS, %d workgroups per CU\n", grid.x, grid.y, lds, nb);
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(CONV_THREADS), lds, st, a);
     return 0;
 }

@@ -93,13 +93,100 @@ void run(int per_cu, const float* w, const float* x, float* out) {
            mfmas * 4096 / ms / 1e9, mfmas * 4096 / ms / 1e9 / 157.3, ms);
 }
 
+// The proposed replacement: one 8-wave workgroup per CU, (2 x 4 x 32)-voxel tile (dense stride-2 halo tile: 23 760 floats), the
+// chunk's weights (27 taps x 8 input x 64 output channels: 13 824 floats) in LDS; per chunk 12 + 7 float4 per thread are fetched
+// into registers during the taps (halo tile from a 64 MB region: HBM; weights from the 221 KB packed array: L2) and written to
+// LDS between two barriers.  PF = 1: the LDS operands one tap ahead (as in conv_chunk_taps27).
+template <int STG>
+__global__ __launch_bounds__(512) void k8(float* out, const float* __restrict__ w, const float* __restrict__ x, int tiles) {
+    extern __shared__ float lds[];
+    float* tile = lds;
+    float* wl = lds + 23760;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 23760; i += 512) tile[i] = x[i];
+    for (int i = tid; i < 13824; i += 512) wl[i] = w[i];
+    __syncthreads();
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const float* abase = tile + ((wave >> 2) * 2 * 594 + (wave & 3) * 2 * 66 + (lane & 31)) * 8 + 4 * (lane >> 5);
+    const float* wq = wl + lane * 4;
+    float sink = 0.f;
+    const size_t xbase = (size_t)blockIdx.x * 65536;
+    for (int t = 0; t < tiles; ++t) {
+        for (int c = 0; c < CHUNKS; ++c) {
+            float4 sa[12], sb[7];
+            if (STG) {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) sa[s] = *(const float4*)(x + (xbase + (size_t)((t * CHUNKS + c) * 12 + s) * 2048 + tid * 4) % (1 << 24));
+#pragma unroll
+                for (int s = 0; s < 7; ++s) sb[s] = *(const float4*)(w + ((size_t)c * 13824 + (s * 512 + tid) * 4) % (1 << 16));
+            }
+            float4 b[2][2], a[2];
+            b[0][0] = *(const float4*)(wq); b[0][1] = *(const float4*)(wq + 256);
+            a[0] = *(const float4*)abase;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) {
+                    b[(tap + 1) & 1][0] = *(const float4*)(wq + (tap + 1) * 512);
+                    b[(tap + 1) & 1][1] = *(const float4*)(wq + (tap + 1) * 512 + 256);
+                    a[(tap + 1) & 1] = *(const float4*)(abase + ((tap + 1) % 3) * 264 + (((tap + 1) / 3) % 3) * 528 + ((tap + 1) / 9) * 4752);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 av = a[tap & 1], b0 = b[tap & 1][0], b1 = b[tap & 1][1];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            if (STG) {
+#pragma unroll
+                for (int s = 0; s < 12; ++s) { const int e = s * 512 + tid; if (e < 5940) *(float4*)(tile + e * 4) = sa[s]; }
+#pragma unroll
+                for (int s = 0; s < 7; ++s) { const int e = s * 512 + tid; if (e < 3456) *(float4*)(wl + e * 4) = sb[s]; }
+            }
+            __syncthreads();
+        }
+        sink += acc0[0] + acc1[0];
+    }
+    float s = sink;
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+}
+
+template <int STG>
+void run8(const float* w, const float* x, float* out) {
+    const int tiles = 12;
+    const size_t lds = (23760 + 13824) * 4;
+    hipFuncSetAttribute((const void*)k8<STG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(256), blk(512);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k8<STG>), grid, blk, lds, 0, out, w, x, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k8<STG>), grid, blk, lds, 0, out, w, x, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double mfmas = (double)grid.x * 8 * tiles * CHUNKS * TAPS * 8;
+    printf("8 waves, weights + tile in LDS, stg=%d : %6.1f TFLOP/s  %.3f of 157.3 (%.3f ms)\n", STG, mfmas * 4096 / ms / 1e9,
+           mfmas * 4096 / ms / 1e9 / 157.3, ms);
+}
+
 int main() {
-    const size_t nw = 1 << 18, nx = 1 << 22;
+    const size_t nw = 1 << 18, nx = 1 << 24;
     float* h = (float*)malloc(nx * 4);
     srand(1);
     for (size_t i = 0; i < nx; ++i) h[i] = (float)rand() / RAND_MAX * 2.f - 1.f;
     float *w, *x, *out;
-    hipMalloc(&w, nw * 4); hipMalloc(&x, nx * 4); hipMalloc(&out, 256 * 4 * 256 * 4);
+    hipMalloc(&w, nw * 4); hipMalloc(&x, nx * 4); hipMalloc(&out, 256 * 4 * 512 * 4);
     hipMemcpy(w, h, nw * 4, hipMemcpyHostToDevice);
     hipMemcpy(x, h, nx * 4, hipMemcpyHostToDevice);
     for (int pc = 1; pc <= 4; ++pc) run<0, 0, 0>(pc, w, x, out);
@@ -107,5 +194,6 @@ int main() {
     for (int pc = 1; pc <= 3; ++pc) run<1, 1, 0>(pc, w, x, out);
     for (int pc = 1; pc <= 2; ++pc) run<0, 0, 1>(pc, w, x, out);
     for (int pc = 1; pc <= 2; ++pc) run<1, 1, 1>(pc, w, x, out);
+    run8<0>(w, x, out); run8<1>(w, x, out);
     return 0;
 }

@@ -54,6 +54,7 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 
 namespace hipemu {

@@ -147,6 +147,20 @@ int stx_gate_fwd(const float* cv, const float* att, float* out, int B, int D, lo
 int stx_gate_bwd(const float* g, const float* cv, const float* att, float* gcv, float* gatt, int B, int D, long long HW,
                  int C, void* stream);
 
+/* ---- channel concatenation of channels-last activations --------------------------------------------------
+ * Replaces `torch.cat((l2, l3, l4), dim=1)` of the feature extractors (reference models/GwcNet/gwcnet.py:59,
+ * models/ACVNet/acv.py:48) for dense [nvox][C_k] (NHWC / NDHWC) tensors: out[v] = in0[v] | in1[v] | in2[v] | in3[v]; unused
+ * parts: NULL with C = 0; every C_k a multiple of 4.  stx_split_channels is the inverse (the concatenation's backward); a
+ * part with C_k > 0 must have a destination. */
+int stx_concat_channels(const float* in0, const float* in1, const float* in2, const float* in3, int C0, int C1, int C2, int C3,
+                        float* out, long long nvox, void* stream);
+int stx_split_channels(const float* in, float* out0, float* out1, float* out2, float* out3, int C0, int C1, int C2, int C3,
+                       long long nvox, void* stream);
+/* Batched 2-D transpose out[n][c][r] = in[n][r][c]: the channels-last <-> channel-major re-layout of the feature maps in front
+ * of the cost-volume builders (their kernels take NCHW rows, the 2-D CNN produces NHWC; `Tensor.contiguous()` in the reference's
+ * terms).  rows and cols multiples of 4. */
+int stx_transpose(const float* in, float* out, int N, int rows, int cols, void* stream);
+
 /* ---- ACVNet extras (models/ACVNet/acv.py) --------------------------------------------------------------
  * Depth-wise nn.Conv3d(C, C, (1,3,3), groups=C, dilation=d, padding=(0,d,d)) (acv.py:109-112,183-187) on a channels-last
  * volume; `dil` = int[C/4] dilation per channel quad (device pointer); w = [C][9]; flip=1 mirrors the taps (input gradient). */

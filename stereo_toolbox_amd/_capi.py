@@ -62,6 +62,9 @@ SIGNATURES = {
     "stx_depth_to_space": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_gate_fwd": [_P, _P, _P, _I, _I, _L, _I, _P],
     "stx_gate_bwd": [_P, _P, _P, _P, _P, _I, _I, _L, _I, _P],
+    "stx_concat_channels": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _L, _P],
+    "stx_split_channels": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _P],
+    "stx_transpose": [_P, _P, _I, _I, _I, _P],
     # acv.hip
     "stx_dwconv_hw_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "stx_dwconv_hw_wgrad_workspace_floats": [_I],

@@ -112,6 +112,64 @@ int act_grid(size_t nquads) {
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 
+// Channel concatenation of up to four channels-last activations [nvox][C_k] -> [nvox][sum C_k] (the `torch.cat((l2, l3, l4),
+// dim=1)` of the feature extractors, gwcnet.py:59 / acv.py:48, on channels_last tensors: torch's cat takes its generic strided
+// copy there, 0.23 ms for the 2 x 320 x 144 x 240 map; this is one coalesced pass) and its inverse (the backward: three dense
+// gradients out of the 320-channel one instead of three strided `contiguous()` copies).  One thread per float4 of the wide side.
+struct CatArgs {
+    const float* in[4];
+    float* out[4];
+    int cq[4];           // channels / 4 per part
+};
+template <bool SPLIT>
+__global__ __launch_bounds__(ACT_THREADS) void cat_channels_kernel(CatArgs a, const float* __restrict__ wide_in,
+                                                                   float* __restrict__ wide_out, int CQ, size_t nquads) {
+    for (size_t i = (size_t)blockIdx.x * ACT_THREADS + threadIdx.x; i < nquads; i += (size_t)gridDim.x * ACT_THREADS) {
+        const size_t v = i / CQ;
+        int q = (int)(i - v * CQ), k = 0;
+        while (k < 3 && q >= a.cq[k]) { q -= a.cq[k]; ++k; }
+        const size_t part = (v * a.cq[k] + q) * 4;
+        if (SPLIT) stx_st4(a.out[k] + part, stx_ld4(wide_in + i * 4));
+        else stx_st4(wide_out + i * 4, stx_ld4(a.in[k] + part));
+    }
+}
+
+// Batched 2-D transpose out[n][c][r] = in[n][r][c] (rows x cols -> cols x rows), 64 x 64 tiles through LDS: the channels-last
+// <-> channel-major re-layout of the 320-channel feature maps in front of (and, in backward, behind) the cost-volume builders,
+// whose kernels take NCHW rows.  torch's `contiguous()` does this with its generic strided copy (0.10 ms per 320 x 144 x 240
+// map, 0.78 TB/s); both sides of this kernel are 256-byte runs.  rows % 4 == 0 and cols % 4 == 0.
+constexpr int TR_T = 64;
+__global__ __launch_bounds__(ACT_THREADS) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                                int cols, int ntr, int ntc, long long tiles) {
+    __shared__ float tile[TR_T][TR_T + 1];
+    const int tid = threadIdx.x, q = tid & 15, l = tid >> 4;
+    const size_t per = (size_t)rows * cols;
+    for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int n = (int)(t / ((long long)ntr * ntc));
+        const int rem = (int)(t - (long long)n * ntr * ntc);
+        const int r0 = (rem / ntc) * TR_T, c0 = (rem % ntc) * TR_T;
+        const float* src = in + (size_t)n * per;
+        float* dst = out + (size_t)n * per;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + l + 16 * k, c = c0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c < cols) v = stx_ld4(src + (size_t)r * cols + c);
+            tile[l + 16 * k][4 * q + 0] = v.x; tile[l + 16 * k][4 * q + 1] = v.y;
+            tile[l + 16 * k][4 * q + 2] = v.z; tile[l + 16 * k][4 * q + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + l + 16 * k, r = r0 + 4 * q;
+            if (c < cols && r < rows)
+                stx_st4(dst + (size_t)c * rows + r, make_float4(tile[4 * q + 0][l + 16 * k], tile[4 * q + 1][l + 16 * k],
+                                                               tile[4 * q + 2][l + 16 * k], tile[4 * q + 3][l + 16 * k]));
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // x, y: n floats, n a multiple of 4 (dense channels-last activations always are); in place (y == x) allowed
@@ -141,6 +199,54 @@ extern "C" int stx_depth_to_space(const float* y, float* out, int B, int D, int 
     hipLaunchKernelGGL(depth_to_space_kernel, dim3(act_grid(nquads)), dim3(ACT_THREADS), 0, (hipStream_t)stream, y, out, D, H,
                        W, C / 4, nquads, inverse);
     return stx_check_launch("depth_to_space");
+}
+
+// out[n][c][r] = in[n][r][c] for n < N: [N][rows][cols] -> [N][cols][rows]; rows % 4 == 0, cols % 4 == 0
+extern "C" int stx_transpose(const float* in, float* out, int N, int rows, int cols, void* stream) {
+    stx_begin();
+    STX_REQUIRE(in && out && N > 0 && rows > 0 && cols > 0 && rows % 4 == 0 && cols % 4 == 0,
+                "transpose: bad arguments (%d x %d x %d; rows and cols multiples of 4)", N, rows, cols);
+    const int ntr = (rows + TR_T - 1) / TR_T, ntc = (cols + TR_T - 1) / TR_T;
+    const long long tiles = (long long)N * ntr * ntc;
+    const int grid = (int)(tiles > 8192 ? 8192 : tiles);
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid), dim3(ACT_THREADS), 0, (hipStream_t)stream, in, out, rows, cols, ntr, ntc, tiles);
+    return stx_check_launch("transpose");
+}
+
+// out[v][0 .. C0 + C1 + C2 + C3) = in0[v][..] | in1[v][..] | in2[v][..] | in3[v][..] (unused parts: NULL with C = 0); every C_k % 4 == 0
+extern "C" int stx_concat_channels(const float* in0, const float* in1, const float* in2, const float* in3, int C0, int C1, int C2,
+                                   int C3, float* out, long long nvox, void* stream) {
+    stx_begin();
+    const int C = C0 + C1 + C2 + C3;
+    STX_REQUIRE(out && nvox > 0 && C > 0 && C0 >= 0 && C1 >= 0 && C2 >= 0 && C3 >= 0 && !((C0 | C1 | C2 | C3) & 3),
+                "concat_channels: bad arguments (C = %d + %d + %d + %d)", C0, C1, C2, C3);
+    STX_REQUIRE((in0 || !C0) && (in1 || !C1) && (in2 || !C2) && (in3 || !C3), "concat_channels: null part");
+    CatArgs a;
+    a.in[0] = in0; a.in[1] = in1; a.in[2] = in2; a.in[3] = in3;
+    a.out[0] = a.out[1] = a.out[2] = a.out[3] = nullptr;
+    a.cq[0] = C0 / 4; a.cq[1] = C1 / 4; a.cq[2] = C2 / 4; a.cq[3] = C3 / 4;
+    const size_t nquads = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(cat_channels_kernel<false>, dim3(act_grid(nquads)), dim3(ACT_THREADS), 0, (hipStream_t)stream, a,
+                       (const float*)nullptr, out, C / 4, nquads);
+    return stx_check_launch("concat_channels");
+}
+
+// the inverse: out_k[v][..] = in[v][its channel range]; a NULL out_k skips that part
+extern "C" int stx_split_channels(const float* in, float* out0, float* out1, float* out2, float* out3, int C0, int C1, int C2,
+                                  int C3, long long nvox, void* stream) {
+    stx_begin();
+    const int C = C0 + C1 + C2 + C3;
+    STX_REQUIRE(in && nvox > 0 && C > 0 && C0 >= 0 && C1 >= 0 && C2 >= 0 && C3 >= 0 && !((C0 | C1 | C2 | C3) & 3),
+                "split_channels: bad arguments (C = %d + %d + %d + %d)", C0, C1, C2, C3);
+    STX_REQUIRE((out0 || !C0) && (out1 || !C1) && (out2 || !C2) && (out3 || !C3), "split_channels: null part");
+    CatArgs a;
+    a.in[0] = a.in[1] = a.in[2] = a.in[3] = nullptr;
+    a.out[0] = out0; a.out[1] = out1; a.out[2] = out2; a.out[3] = out3;
+    a.cq[0] = C0 / 4; a.cq[1] = C1 / 4; a.cq[2] = C2 / 4; a.cq[3] = C3 / 4;
+    const size_t nquads = (size_t)nvox * (C / 4);
+    hipLaunchKernelGGL(cat_channels_kernel<true>, dim3(act_grid(nquads)), dim3(ACT_THREADS), 0, (hipStream_t)stream, a, in,
+                       (float*)nullptr, C / 4, nquads);
+    return stx_check_launch("split_channels");
 }
 
 // FeatureAtt gate (IGEVStereo/submodule.py:228-241): out = cv * sigmoid(att), cv / out [B][D][HW][C], att [B][HW][C]

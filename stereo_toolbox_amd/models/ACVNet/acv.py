@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...aggregation import convbn_block, deferred_bn_counters
-from ..features2d import ResTrunk, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
+from ..features2d import ResTrunk, cat_features, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from ..GwcNet.gwcnet import classifier, run_classifier
 from .submodule import attention_block, convbn_3d
 
@@ -21,7 +21,7 @@ class feature_extraction(ResTrunk):
     fused_everywhere = True       # every BatchNorm2d of this extractor runs through features2d.conv_bn_act in train mode
 
     def forward(self, x):
-        return {"gwc_feature": torch.cat(self.trunk(x), dim=1)}
+        return {"gwc_feature": cat_features(self.trunk(x))}
 
 
 class hourglass(nn.Module):

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...aggregation import conv_block, convbn_block, deferred_bn_counters
-from ..features2d import ResTrunk, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
+from ..features2d import ResTrunk, cat_features, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from .submodule import convbn_3d
 
 
@@ -26,7 +26,7 @@ class feature_extraction(ResTrunk):
                                           nn.Conv2d(128, concat_feature_channel, 1, bias=False))
 
     def forward(self, x):
-        gwc = torch.cat(self.trunk(x), dim=1)
+        gwc = cat_features(self.trunk(x))
         if not self.concat_feature:
             return {"gwc_feature": gwc}
         return {"gwc_feature": gwc, "concat_feature": run_head2d(self.lastconv, gwc)}

@@ -499,6 +499,83 @@ def gate(cv, att):
     return out
 
 
+# --------------------------------------------------------------------------------------- channels-last <-> channel-major
+class ChannelMajorFn(torch.autograd.Function):
+    """NCHW-logical tensor stored channels-last (dense [B, H, W, C]) -> the same values stored NCHW-contiguous, through the
+    tiled transpose kernel (stx_transpose); backward: the inverse transpose, so the gradient goes back dense in the
+    producer's layout (torch's `contiguous()` takes its generic strided copy both ways: 0.10 ms per 320 x 144 x 240 map, and
+    its backward hands the producer an NCHW gradient that every channels-last consumer re-lays again)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device)
+        _call("stx_transpose", _p(x.permute(0, 2, 3, 1)), _p(out), B, H * W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        gx = torch.empty((B, H, W, C), dtype=g.dtype, device=g.device)
+        _call("stx_transpose", _p(g), _p(gx), B, C, H * W)
+        return gx.permute(0, 3, 1, 2)
+
+
+def channel_major(x):
+    """`x.contiguous()` for a 4-D NCHW-logical tensor: a no-op for NCHW-contiguous input, the transpose kernel for dense
+    channels-last fp32 input whose H*W and C are multiples of 4, torch's copy otherwise."""
+    if x.is_contiguous():
+        return x
+    if (x.dim() == 4 and x.dtype == torch.float32 and on_device(x) and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[1] % 4 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0):
+        return ChannelMajorFn.apply(x)
+    return x.contiguous()
+
+
+# --------------------------------------------------------------------------------------- channel concatenation
+class CatChannelsFn(torch.autograd.Function):
+    """Dense channels-last tensors [..., C_k] -> [..., sum C_k] in one coalesced pass (stx_concat_channels); backward: one
+    pass that writes the dense per-part gradients (stx_split_channels).  Reference: `torch.cat(..., dim=1)` of the feature
+    extractors (gwcnet.py:59, acv.py:48)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        ctx.cs = [int(p.shape[-1]) for p in parts]
+        nvox = parts[0].numel() // ctx.cs[0]
+        out = parts[0].new_empty(*parts[0].shape[:-1], sum(ctx.cs))
+        ptrs = [_p(p) for p in parts] + [None] * (4 - len(parts))
+        cs = ctx.cs + [0] * (4 - len(parts))
+        _call("stx_concat_channels", *ptrs, *cs, _p(out), nvox)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        nvox = g.numel() // g.shape[-1]
+        outs = [g.new_empty(*g.shape[:-1], c) if need else None for c, need in zip(ctx.cs, ctx.needs_input_grad)]
+        if any(o is not None for o in outs):
+            # (a part that needs no gradient still gets a destination: the kernel writes every part)
+            dst = [o if o is not None else g.new_empty(*g.shape[:-1], c) for o, c in zip(outs, ctx.cs)]
+            ptrs = [_p(o) for o in dst] + [None] * (4 - len(dst))
+            cs = ctx.cs + [0] * (4 - len(dst))
+            _call("stx_split_channels", _p(g), *ptrs, *cs, nvox)
+        return tuple(outs)
+
+
+def cat_channels(parts):
+    """Concatenate 2-4 dense channels-last tensors of equal leading shape along their LAST (channel) axis; every width a
+    multiple of 4.  Differentiable."""
+    parts = [p.contiguous() for p in parts]
+    if not 2 <= len(parts) <= 4:
+        raise StxError(f"cat_channels: {len(parts)} parts (2 to 4)")
+    lead = parts[0].shape[:-1]
+    for p in parts:
+        if p.shape[:-1] != lead or p.shape[-1] % 4 or p.dtype != torch.float32 or p.device != parts[0].device:
+            raise StxError(f"cat_channels: parts {[tuple(q.shape) for q in parts]} (equal leading shape, fp32, widths % 4 == 0)")
+    return CatChannelsFn.apply(*parts)
+
+
 # --------------------------------------------------------------------------------------- batch norm
 def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, groups=1):
     """partials [rows, 2, C] ([groups, rows, 2, C] for groups > 1) -> scale, shift, mean, invstd ([C] each, [groups, C] for
@@ -724,7 +801,7 @@ class CostVolumeFn(torch.autograd.Function):
 
 
 def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
-    ts = [t.contiguous() if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    ts = [channel_major(t) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         return CostVolumeFn.apply(*ts, maxdisp, num_groups, mask_left)
     return cost_volume_forward(*ts, maxdisp, num_groups, mask_left)
@@ -764,7 +841,7 @@ def sampled_volume(Lg, Rg, Lc, Rc, samples, num_groups):
     """Cascade-stage cost volume from per-pixel disparity hypotheses `samples` [B, S, H, W] (integer-valued floats, no
     gradient): see include/stx_hip.h.  The channel axis is padded with zeros to a multiple of 8; `conv_block` accepts
     such a volume for a convolution whose weight has the un-padded input width."""
-    ts = [t.contiguous() if t is not None else None for t in (Lg, Rg, Lc, Rc)]
+    ts = [channel_major(t) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
     for n, t in (("ref gwc", ts[0]), ("tgt gwc", ts[1]), ("ref concat", ts[2]), ("tgt concat", ts[3])):
         _chk(t, n, 4)
     samples = samples.detach().contiguous()

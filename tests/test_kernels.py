@@ -275,6 +275,38 @@ def test_modal_estimators(be, case):
         assert bad <= (0 if entry == "stx_unimodal_fwd" else B * H * W // 100), f"{entry}: {bad} pixels differ"
 
 
+@pytest.mark.parametrize("case", [(2, 128, 64), (1, 136, 12), (3, 68, 320), (1, 4, 4), (2, 320, 200)])
+def test_transpose(be, case):
+    """stx_transpose vs Tensor.transpose: exact (a permutation); tile edges in both directions."""
+    N, rows, cols = case
+    torch.manual_seed(4)
+    x = torch.randn(N, rows, cols)
+    out = be.empty(N, cols, rows)
+    out.fill_(-3.0)
+    be.call("stx_transpose", ptr(be.dev(x)), ptr(out), N, rows, cols)
+    assert torch.equal(out.cpu(), x.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("case", [(37, (64, 128, 128)), (5, (8, 4)), (130, (12, 64, 4, 16)), (1, (32, 32))])
+def test_concat_split_channels(be, case):
+    """stx_concat_channels / stx_split_channels vs torch.cat / torch.split on dense channels-last tensors: exact (copies).
+    Replaces the feature extractors' `torch.cat((l2, l3, l4), dim=1)` (reference gwcnet.py:59, acv.py:48) and its backward."""
+    nvox, cs = case
+    torch.manual_seed(3)
+    parts = [torch.randn(nvox, c) for c in cs]
+    want = torch.cat(parts, -1)
+    dp = [be.dev(t) for t in parts]
+    pad = [None] * (4 - len(cs))
+    out = be.empty(nvox, sum(cs))
+    out.fill_(-7.0)
+    be.call("stx_concat_channels", *[ptr(t) for t in dp], *pad, *cs, *([0] * len(pad)), ptr(out), nvox)
+    assert torch.equal(out.cpu(), want)
+    back = [be.empty(nvox, c) for c in cs]
+    be.call("stx_split_channels", ptr(out), *[ptr(t) for t in back], *pad, *cs, *([0] * len(pad)), nvox)
+    for got, t in zip(back, parts):
+        assert torch.equal(got.cpu(), t)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 5, 9, 21), (1, 48, 4, 7, 22), (1, 192, 6, 40, 31), (2, 16, 6, 10, 0),
                                   (1, 608, 2, 5, 3)])
 def test_split_mode(be, case):

@@ -335,6 +335,44 @@ def test_psmnet_config1_eval():
     assert (got - ref).abs().max().item() < 1e-3
 
 
+def test_cat_features_matches_torch_cat(env):
+    """features2d.cat_features (the extractors' channel concatenation on ops.cat_channels) vs torch.cat on channels_last
+    maps: values and the three branch gradients exact (copies both ways)."""
+    from stereo_toolbox_amd.models.features2d import cat_features
+    torch.manual_seed(5)
+    parts = [torch.randn(2, c, 6, 10).contiguous(memory_format=torch.channels_last) for c in (64, 128, 128)]
+    g = torch.randn(2, 320, 6, 10).contiguous(memory_format=torch.channels_last)
+    ref_in = [p.clone().requires_grad_() for p in parts]
+    torch.cat(ref_in, 1).backward(g)
+    with env.ctx():
+        dev_in = [p.to(env.device).contiguous(memory_format=torch.channels_last).requires_grad_() for p in parts]
+        out = cat_features(dev_in)
+        assert out.shape == (2, 320, 6, 10) and out.is_contiguous(memory_format=torch.channels_last)
+        out.backward(g.to(env.device))
+    assert torch.equal(out.detach().cpu(), torch.cat(parts, 1))
+    for a, b in zip(dev_in, ref_in):
+        assert torch.equal(a.grad.cpu(), b.grad)
+
+
+def test_channel_major_is_contiguous_with_a_dense_gradient(env):
+    """ops.channel_major (the re-layout in front of the cost-volume builders) vs Tensor.contiguous(): same values in NCHW
+    memory; the gradient comes back dense channels-last and equal."""
+    from stereo_toolbox_amd import ops
+    torch.manual_seed(6)
+    x = torch.randn(3, 24, 6, 10).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(3, 24, 6, 10)
+    with env.ctx():
+        dx = x.to(env.device).contiguous(memory_format=torch.channels_last).requires_grad_()
+        half = dx[1:]                                           # a batch slice of the stacked two-view map, as run_pair hands out
+        y = ops.channel_major(half)
+        assert y.is_contiguous() and torch.equal(y.detach().cpu(), x[1:].contiguous())
+        y.backward(g[1:].to(env.device))
+        assert ops.channel_major(y) is y
+    want = torch.zeros_like(x)
+    want[1:] = g[1:]
+    assert torch.equal(dx.grad.cpu(), want) and dx.grad.is_contiguous(memory_format=torch.channels_last)
+
+
 def test_functional_api(env):
     """Drop-in functions of models/GwcNet/submodule.py and disparity_estimators."""
     from stereo_toolbox_amd.disparity_estimators import (argmax_disparity_estimator, dominant_modal_disparity_estimator,

@@ -224,7 +224,9 @@ int stx_bn_bwd_apply(const float* gy, const float* y, const float* z1, const flo
                      int relu, void* stream);
 /* The same two passes taking the ReLU mask from the forward pass's per-channel scale / shift instead of the activated
  * output (y may be NULL): sign(y) = sign(fmaf(z1, scale1, shift1) [+ fmaf(z2, scale2, shift2)]) is recomputed from
- * operands these passes read anyway -- one volume-sized read less per pass.  (A block with a plain residual still passes y.) */
+ * operands these passes read anyway -- one volume-sized read less per pass.  (A block with a plain residual still passes y.)
+ * With groups > 1 `sums` holds groups + 1 slabs of [3][C]: the per-group sums, then their total over the groups (the gradients
+ * of the gamma / beta the groups share); stx_bn_bwd_apply2 reads the first `groups` slabs. */
 int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* z1, const float* mean1, const float* invstd1,
                        const float* z2, const float* mean2, const float* invstd2, const float* scale1,
                        const float* shift1, const float* scale2, const float* shift2, float* partials, float* sums,

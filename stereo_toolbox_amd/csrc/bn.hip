@@ -288,17 +288,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const float* __res
     }
 }
 
-// sums[m] = sum over rows of partials[r][m], fp64 accumulate; one workgroup per column.
+// sums[g][m] = sum over rows of partials[g][r][m], fp64 accumulate; one workgroup per column, the groups one after the other;
+// with more than one group a further slab sums[groups][m] = sums[0][m] + sums[1][m] + .. (fp32, group order): the parameter
+// gradients of a BatchNorm shared by the groups (the two views of the 2-D CNN) without a reduction launch of their own.
 __global__ __launch_bounds__(BN_THREADS) void bn_colsum_kernel(const float* __restrict__ partials, int nrows, int M,
-                                                               float* __restrict__ sums) {
+                                                               float* __restrict__ sums, int groups) {
     __shared__ double red[BN_THREADS];
     const int m = blockIdx.x, tid = threadIdx.x;
-    partials += (size_t)blockIdx.y * nrows * M;                      // group blockIdx.y
-    sums += (size_t)blockIdx.y * M;
-    double s = 0.0;
-    for (int r = tid; r < nrows; r += BN_THREADS) s += (double)partials[(size_t)r * M + m];
-    s = bn_block_sum(s, red, tid);
-    if (tid == 0) sums[m] = (float)s;
+    float tot = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const float* p = partials + (size_t)g * nrows * M;
+        double s = 0.0;
+        for (int r = tid; r < nrows; r += BN_THREADS) s += (double)p[(size_t)r * M + m];
+        s = bn_block_sum(s, red, tid);
+        if (tid == 0) {
+            sums[(size_t)g * M + m] = (float)s;
+            tot += (float)s;
+        }
+    }
+    if (groups > 1 && tid == 0) sums[(size_t)groups * M + m] = tot;
 }
 
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
@@ -464,7 +472,7 @@ extern "C" int stx_bn_bwd_reduce2(const float* gy, const float* y, const float* 
                        z2, mean2, invstd2, scale1, shift1, scale2, shift2, partials, (size_t)nvox, C, relu);
     int rc = stx_check_launch("bn_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C, groups), dim3(BN_THREADS), 0, st, partials, nblk, 3 * C, sums);
+    hipLaunchKernelGGL(bn_colsum_kernel, dim3(3 * C), dim3(BN_THREADS), 0, st, partials, nblk, 3 * C, sums, groups);
     return stx_check_launch("bn_colsum");
 }
 

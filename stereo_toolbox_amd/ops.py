@@ -690,10 +690,12 @@ class BnActFn(torch.autograd.Function):
         lib = get_lib()
         NB = lib.raw("stx_bn_reduce_blocks")()
         part = _WS.get("bnred", G * NB * 3 * C, z1.device)
-        sums = torch.empty(G, 3, C, dtype=torch.float32, device=z1.device)
+        # (groups > 1: one more slab = the total over the groups, written by the same launch)
+        sums_all = torch.empty(G + (1 if G > 1 else 0), 3, C, dtype=torch.float32, device=z1.device)
+        sums = sums_all[:G]
         _call("stx_bn_bwd_reduce2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
               _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(sc1), _p(sh1), _p(sc2), _p(sh2), _p(part),
-              _p(sums), nvox, C, int(ctx.relu), G)
+              _p(sums_all), nvox, C, int(ctx.relu), G)
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
@@ -713,7 +715,7 @@ class BnActFn(torch.autograd.Function):
               _p(sc2), _p(sh2), _p(use), _p(dz1), _p(dz2), _p(gres), nvox, C, int(ctx.relu), G)
         if ctx.has_res and not ctx.relu:
             gres = gy
-        tot = sums[0] if G == 1 else sums.sum(0)          # gamma / beta are shared between the groups
+        tot = sums_all[G] if G > 1 else sums_all[0]       # gamma / beta are shared between the groups
         return (dz1, tot[1], tot[0], dz2, tot[2] if ctx.two else None, tot[0] if ctx.two else None, gres,
                 None, None, None, None)
 

@@ -165,19 +165,43 @@ def _raw_conv(x, conv, want):
     return ops.ConvRawFn.apply(x, conv.weight, ks, stride, _is_transposed(conv), want)
 
 
-def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False, leaky=False):
+def shared_input_convs(x, blocks):
+    """Train-mode raw outputs of several `convbn_3d` blocks (nn.Sequential(Conv3d, BatchNorm3d)) reading the SAME activation
+    `x`, through one autograd node whose backward accumulates the input gradients inside the producing kernels instead of
+    in volume-sized `add` launches (ops.SharedInputConvsFn).  Returns one `raw` triple per block for conv_block's `raw=` /
+    `second_raw=` arguments, or None when the combination is not served (transposed / odd widths / inference): the caller then
+    takes the block-by-block path."""
+    cfgs, ws = [], []
+    for seq in blocks:
+        conv, bn = seq[0], seq[1]
+        if _is_transposed(conv) or not bn.training or conv.weight.shape[1] != x.shape[-1] or conv.weight.shape[1] % 8 \
+                or conv.weight.shape[0] % 8:
+            return None
+        ks, stride = _conv_cfg(conv)
+        cfgs.append((ks, stride, True))
+        ws.append(conv.weight)
+    if not _needs_grad(x, *[m for seq in blocks for m in (seq[0], seq[1])]):
+        return None
+    outs = ops.SharedInputConvsFn.apply(x, tuple(cfgs), *ws)
+    return [(outs[2 * k], outs[2 * k + 1]) for k in range(len(blocks))]
+
+
+def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False, leaky=False, raw=None, second_raw=None):
     """One fused block on NDHWC tensors.
     leaky: LeakyReLU(0.01) instead of ReLU (IGEV family, activation code 3 of the kernels).
     second = (x2, conv2, bn2): adds BN2(conv2(x2)) before the activation (hourglass redir path).
     residual: NDHWC tensor added before the activation.
     mish: Mish instead of ReLU (PCWNet / CFNet family): fused into the conv epilogue in inference and into the BatchNorm
-    apply / backward passes in training (differentiated at the recomputed pre-activation value)."""
+    apply / backward passes in training (differentiated at the recomputed pre-activation value).
+    raw / second_raw = (z, partial rows) from shared_input_convs: the (train-mode) raw output of `conv` / of second's conv
+    computed earlier; `x` / second[0] are then not read."""
     if (mish and relu) or (leaky and (relu or mish)):
         raise ops.StxError("conv_block: relu, mish and leaky are mutually exclusive")
     if second is not None and residual is not None:
         raise ops.StxError("conv_block: `second` and `residual` are mutually exclusive")
     mods = [conv, bn] + ([second[1], second[2]] if second is not None else [])
-    grad = _needs_grad(x, residual, *(m for m in mods if m is not None), *([second[0]] if second else []))
+    grad = (raw is not None or second_raw is not None
+            or _needs_grad(x, residual, *(m for m in mods if m is not None), *([second[0]] if second else [])))
     train_bn = (bn is not None and bn.training) or (second is not None and second[2].training)
     if mish and (grad or train_bn) and (bn is None or residual is not None):
         # autograd path without a BatchNorm to fuse into: Mish as its own streaming pass (forward + backward kernels)
@@ -200,7 +224,7 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
 
     # ---- autograd path
     want = bn is not None and bn.training
-    z1, part1 = _raw_conv(x, conv, want)
+    z1, part1 = raw if raw is not None else _raw_conv(x, conv, want)
     if bn is None:
         y = z1
         if residual is not None:
@@ -213,15 +237,15 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     if second is not None:
         x2, conv2, bn2 = second
         want2 = bn2.training
-        z2, part2 = _raw_conv(x2, conv2, want2)
+        z2, part2 = second_raw if second_raw is not None else _raw_conv(x2, conv2, want2)
         st2 = _bn_state(bn2, part2 if want2 else None, z2.numel() // z2.shape[-1])
         return ops.BnActFn.apply(z1, bn.weight, bn.bias, z2, bn2.weight, bn2.bias, None, relu, st1, st2)
     return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None)
 
 
-def convbn_block(x, seq, relu=False, second=None, residual=None, mish=False):
+def convbn_block(x, seq, relu=False, second=None, residual=None, mish=False, raw=None, second_raw=None):
     """`seq` = nn.Sequential(conv, bn) as built by convbn_3d (or (ConvTranspose3d, BatchNorm3d))."""
     sec = None
     if second is not None:
         sec = (second[0], second[1][0], second[1][1])
-    return conv_block(x, seq[0], seq[1], relu=relu, second=sec, residual=residual, mish=mish)
+    return conv_block(x, seq[0], seq[1], relu=relu, second=sec, residual=residual, mish=mish, raw=raw, second_raw=second_raw)

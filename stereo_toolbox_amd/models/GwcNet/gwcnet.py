@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...aggregation import conv_block, convbn_block, deferred_bn_counters
+from ...aggregation import conv_block, convbn_block, deferred_bn_counters, shared_input_convs
 from ..features2d import ResTrunk, cat_features, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from .submodule import convbn_3d
 
@@ -48,15 +48,22 @@ class hourglass(nn.Module):
         self.redir1 = convbn_3d(c, c, kernel_size=1, stride=1, pad=0)
         self.redir2 = convbn_3d(c * 2, c * 2, kernel_size=1, stride=1, pad=0)
 
-    def forward(self, x, mid=None):
-        c1 = convbn_block(x, self.conv1[0], relu=True)
+    def forward(self, x, mid=None, also=None):
+        """also: a further convbn_3d block that reads `x` (the classifier head of the hourglass's INPUT volume, gwcnet.py:192):
+        in training its raw output comes out of the same autograd node as conv1 / redir1 (see shared_input_convs) and the
+        call returns (out, raw) with `raw` for convbn_block's `raw=` argument (None when the shared path does not apply)."""
+        rx = shared_input_convs(x, [self.conv1[0], self.redir1] + ([also] if also is not None else []))
+        rx = rx or [None, None, None]
+        c1 = convbn_block(x, self.conv1[0], relu=True, raw=rx[0])
         c2 = convbn_block(c1, self.conv2[0], relu=True)
-        c3 = convbn_block(c2, self.conv3[0], relu=True)
+        r2 = shared_input_convs(c2, [self.conv3[0], self.redir2]) or [None, None]
+        c3 = convbn_block(c2, self.conv3[0], relu=True, raw=r2[0])
         c4 = convbn_block(c3, self.conv4[0], relu=True)
         if mid is not None:          # ACVNet inserts its windowed attention here
             c4 = mid(c4)
-        c5 = convbn_block(c4, self.conv5, relu=True, second=(c2, self.redir2))
-        return convbn_block(c5, self.conv6, relu=True, second=(x, self.redir1))
+        c5 = convbn_block(c4, self.conv5, relu=True, second=(c2, self.redir2), second_raw=r2[1])
+        out = convbn_block(c5, self.conv6, relu=True, second=(x, self.redir1), second_raw=rx[1])
+        return (out, rx[2]) if also is not None else out
 
 
 def classifier(c):
@@ -64,9 +71,10 @@ def classifier(c):
                          nn.Conv3d(c, 1, kernel_size=3, padding=1, stride=1, bias=False))
 
 
-def run_classifier(seq, x, add=None):
-    """convbn_3d + ReLU + Conv3d(32->1) -> dense cost [B, D', H', W'] (optionally + `add`)."""
-    h = convbn_block(x, seq[0], relu=True)
+def run_classifier(seq, x, add=None, raw=None):
+    """convbn_3d + ReLU + Conv3d(32->1) -> dense cost [B, D', H', W'] (optionally + `add`).  raw: the first convolution's
+    raw output when an hourglass call computed it together with its own readers of `x` (hourglass.forward `also`)."""
+    h = convbn_block(x, seq[0], relu=True, raw=raw)
     cost = conv_block(h, seq[2], residual=None if add is None else add.unsqueeze(-1))
     return cost.squeeze(-1)
 
@@ -110,13 +118,18 @@ class GwcNet(nn.Module):
         cost0 = convbn_block(cost0, self.dres0[2], relu=True)
         t = convbn_block(cost0, self.dres1[0], relu=True)
         cost0 = convbn_block(t, self.dres1[2], relu=False, residual=cost0)
+        if self.training:
+            # the heads of cost0 / out1 / out2 read the volume the next hourglass reads: their first convolution shares that
+            # hourglass's autograd node, so the volume's gradient is accumulated in kernel epilogues (no `add` launches)
+            out1, r0 = self.dres2(cost0, also=self.classif0[0])
+            out2, r1 = self.dres3(out1, also=self.classif1[0])
+            out3, r2 = self.dres4(out2, also=self.classif2[0])
+            return [ops.regression_head(run_classifier(c, o, raw=r), self.maxdisp, H, W)
+                    for c, o, r in ((self.classif0, cost0, r0), (self.classif1, out1, r1), (self.classif2, out2, r2),
+                                    (self.classif3, out3, None))]
         out1 = self.dres2(cost0)
         out2 = self.dres3(out1)
         out3 = self.dres4(out2)
-        if self.training:
-            return [ops.regression_head(run_classifier(c, o), self.maxdisp, H, W)
-                    for c, o in ((self.classif0, cost0), (self.classif1, out1), (self.classif2, out2),
-                                 (self.classif3, out3))]
         return ops.regression_head(run_classifier(self.classif3, out3), self.maxdisp, H, W)
 
 

@@ -369,6 +369,65 @@ class ConvRawFn(torch.autograd.Function):
         return gx, gw, None, None, None, None
 
 
+class SharedInputConvsFn(torch.autograd.Function):
+    """Raw outputs (+ BN partial sums) of SEVERAL plain convolutions of ONE activation -- the tensors with more than one
+    convolution consumer in the reference graphs: the hourglass input (conv1 stride 2 + redir1 1x1x1, gwcnet.py:85,103) together
+    with the classifier head that reads the same volume (gwcnet.py:192-195), conv2's output (conv3 + redir2).  Forward = the
+    same launches ConvRawFn makes.  Backward: autograd would sum the consumers' input gradients with one volume-sized `add`
+    per extra consumer (three passes over a 212 MB volume each: 0.65 ms per GwcNet_GC train step); here every gradient after
+    the first is accumulated in the epilogue of the kernel that produces it (`residual` operand: one extra read).  Order: the
+    3x3x3 stride-1 layer first (its march kernel keeps its straight-line epilogue), then stride 2, then 1x1x1.
+    cfgs: one (ks, stride, want_stats) per convolution; weights [Cout, Cin, k, k, k], Cin % 8 == 0, Cout % 8 == 0."""
+
+    @staticmethod
+    def forward(ctx, x, cfgs, *ws):
+        _chk(x, "x", 5)
+        outs = []
+        for (ks, stride, want), w in zip(cfgs, ws):
+            if x.shape[-1] != w.shape[1] or w.shape[1] % 8 or w.shape[0] % 8 or _is_c1(w, ks, stride, False):
+                raise StxError(f"SharedInputConvsFn: weight {tuple(w.shape)} on an input of {x.shape[-1]} channels")
+            z, stats = conv3d_forward(x, pack_weight(w, 0), w.shape[0], ks, stride, want_stats=want)
+            if stats is None:
+                stats = x.new_empty(0)
+            ctx.mark_non_differentiable(stats)
+            outs += [z, stats]
+        ctx.save_for_backward(x, *ws)
+        ctx.cfgs = cfgs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        B, D, H, W, Ci = x.shape
+        gzs = [None if g is None else g.contiguous() for g in grads[0::2]]
+        gws = [None] * len(ws)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            rank = lambda k: (0 if ctx.cfgs[k][0] == 3 and ctx.cfgs[k][1] == 1 else (1 if ctx.cfgs[k][1] == 2 else 2))
+            for k in sorted((k for k in range(len(ws)) if gzs[k] is not None), key=rank):
+                (ks, stride, _), w, gz = ctx.cfgs[k], ws[k], gzs[k]
+                if stride == 1:
+                    gx, _ = conv3d_forward(gz, pack_weight(w, 1), Ci, ks, 1, residual=gx)
+                else:                     # stride-2 dgrad = transposed conv of gz (its kernel takes GEMM-K in steps of 32)
+                    Co = w.shape[0]
+                    gz_k, w_k = gz, w
+                    if Co % 32:
+                        Cp = (Co + 31) // 32 * 32
+                        gz_k = _pad_channels(gz, Cp)
+                        w_k = w.new_zeros(Cp, *w.shape[1:])
+                        w_k[:Co] = w
+                    gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W), residual=gx)
+        for k, (w, gz) in enumerate(zip(ws, gzs)):
+            if gz is None or not ctx.needs_input_grad[2 + k]:
+                continue
+            ks, stride, _ = ctx.cfgs[k]
+            Co = w.shape[0]
+            gz_w = gz if Co % 32 == 0 else _pad_channels(gz, (Co + 31) // 32 * 32)
+            x_w = x if Ci % 32 == 0 else _pad_channels(x, (Ci + 31) // 32 * 32)
+            gws[k] = conv3d_wgrad(x_w, gz_w, ks, stride)[:Co, :Ci].reshape(w.shape)
+        return (gx, None, *gws)
+
+
 # --------------------------------------------------------------------------------------- ConvTranspose3d(k4, s2, p1)
 _D4_SEL = ((3, 1, 4), (4, 2, 0))       # per axis and output parity p: the k4 tap at offsets -1, 0, +1 (4 = the zero slice)
 

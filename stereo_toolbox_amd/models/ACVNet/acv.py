@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...aggregation import convbn_block, deferred_bn_counters
+from ...aggregation import convbn_block, deferred_bn_counters, shared_input_convs
 from ..features2d import ResTrunk, cat_features, channels_last_weights_, convbn, init_reference_style, run_head2d, run_pair
 from ..GwcNet.gwcnet import classifier, run_classifier
 from .submodule import attention_block, convbn_3d
@@ -42,13 +42,16 @@ class hourglass(nn.Module):
         self.redir2 = convbn_3d(c * 2, c * 2, kernel_size=1, stride=1, pad=0)
 
     def forward(self, x):
-        c1 = convbn_block(x, self.conv1[0], relu=True)
+        # (training: the two readers of `x` and of `c2` share an autograd node each -- aggregation.shared_input_convs)
+        rx = shared_input_convs(x, [self.conv1[0], self.redir1]) or [None, None]
+        c1 = convbn_block(x, self.conv1[0], relu=True, raw=rx[0])
         c2 = convbn_block(c1, self.conv2[0], relu=True)
-        c3 = convbn_block(c2, self.conv3[0], relu=True)
+        r2 = shared_input_convs(c2, [self.conv3[0], self.redir2]) or [None, None]
+        c3 = convbn_block(c2, self.conv3[0], relu=True, raw=r2[0])
         c4 = convbn_block(c3, self.conv4[0], relu=True)
         c4 = self.attention_block(c4)
-        c5 = convbn_block(c4, self.conv5, relu=True, second=(c2, self.redir2))
-        return convbn_block(c5, self.conv6, relu=True, second=(x, self.redir1))
+        c5 = convbn_block(c4, self.conv5, relu=True, second=(c2, self.redir2), second_raw=r2[1])
+        return convbn_block(c5, self.conv6, relu=True, second=(x, self.redir1), second_raw=rx[1])
 
 
 class ACVNet(nn.Module):

@@ -373,6 +373,42 @@ def test_channel_major_is_contiguous_with_a_dense_gradient(env):
     assert torch.equal(dx.grad.cpu(), want) and dx.grad.is_contiguous(memory_format=torch.channels_last)
 
 
+def test_shared_input_convs_match_separate_nodes(env):
+    """aggregation.shared_input_convs (one autograd node for the convolutions that read one volume: stride-2 3x3x3, 1x1x1 and
+    the classifier's 3x3x3, input gradient accumulated in kernel epilogues) vs the same three blocks as separate ConvRawFn
+    nodes whose input gradients autograd adds: same raw outputs and BN rows bit for bit (same launches), same weight
+    gradients bit for bit, input gradient equal up to the order of two fp32 additions."""
+    import torch.nn as nn
+    from stereo_toolbox_amd import ops
+    from stereo_toolbox_amd.aggregation import _raw_conv, shared_input_convs
+    from stereo_toolbox_amd.models.GwcNet.submodule import convbn_3d
+    torch.manual_seed(7)
+    blocks = [convbn_3d(32, 64, 3, 2, 1), convbn_3d(32, 32, 1, 1, 0), convbn_3d(32, 32, 3, 1, 1)]
+    x0 = torch.randn(1, 4, 6, 20, 32)
+    gs = [torch.randn(1, 2, 3, 10, 64), torch.randn(1, 4, 6, 20, 32), torch.randn(1, 4, 6, 20, 32)]
+    with env.ctx():
+        mods = nn.ModuleList(blocks).to(env.device).train()
+        dg = [g.to(env.device) for g in gs]
+        xa = x0.to(env.device).requires_grad_()
+        raws = shared_input_convs(xa, list(mods))
+        assert raws is not None and len(raws) == 3
+        sum((z * g).sum() for (z, _), g in zip(raws, dg)).backward()
+        ga = [m[0].weight.grad.clone() for m in mods]
+        for m in mods:
+            m[0].weight.grad = None
+        xb = x0.to(env.device).requires_grad_()
+        sep = [_raw_conv(xb, m[0], True) for m in mods]
+        sum((z * g).sum() for (z, _), g in zip(sep, dg)).backward()
+        for (za, pa), (zb, pb) in zip(raws, sep):
+            assert torch.equal(za, zb) and torch.equal(pa, pb)
+        for a, m in zip(ga, mods):
+            assert torch.equal(a, m[0].weight.grad)
+        scale = xb.grad.abs().max().item()
+        assert (xa.grad - xb.grad).abs().max().item() <= 4e-6 * scale
+        mods[1][1].eval()                                       # a frozen BatchNorm among the readers: block-by-block path
+        assert shared_input_convs(xa.detach().requires_grad_(), list(mods)) is None
+
+
 def test_functional_api(env):
     """Drop-in functions of models/GwcNet/submodule.py and disparity_estimators."""
     from stereo_toolbox_amd.disparity_estimators import (argmax_disparity_estimator, dominant_modal_disparity_estimator,

@@ -119,6 +119,18 @@ long long stx_conv3d_wgrad_workspace_floats(int B, int Dc, int Hc, int Wc, int C
 int stx_conv3d_wgrad(const float* fine, const float* coarse, float* dw, float* workspace, int B, int Df, int Hf, int Wf,
                      int CF, int Dc, int Hc, int Wc, int CC, int ks, int stride, void* stream);
 
+/* The same weight gradient for a 3x3x3 stride-1 `convbn_3d` (+ ReLU) block in training (reference models/GwcNet/submodule.py:17-20
+ * under autograd), taking the gradient gy BEHIND the BatchNorm / activation: the gradient of the raw convolution output
+ *   dz = gamma invstd (gy' - sum_g / n - xhat sum_gx / n),  gy' = gy masked by the activation (sign of fmaf(z, scale, shift)),
+ *   xhat = (z - mean) invstd,  sums = [2][CC] = rows 0 and 1 of stx_bn_bwd_reduce2's sums,  inv_n = 1 / (B D H W),
+ * is formed inside the kernel and also written to `dz` (for the data-gradient launch): the stx_bn_bwd_apply2 pass of the block is
+ * not needed.  act: 0 none, 1 ReLU.  gamma may be NULL (ones).  Only shapes stx_conv3d_wgrad_bn_supported accepts; workspace as
+ * stx_conv3d_wgrad_workspace_floats(B, D, H, W, CF, CC, 3, 1). */
+int stx_conv3d_wgrad_bn_supported(int B, int D, int H, int W, int CF, int CC);
+int stx_conv3d_wgrad_bn(const float* x, const float* gy, const float* z, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, const float* gamma, const float* sums, float inv_n, int act, float* dz, float* dw,
+                        float* workspace, int B, int D, int H, int W, int CF, int CC, void* stream);
+
 /* Classifier tail Conv3d(Cin, 1, k=3, p=1, bias=False) (GwcNet/gwcnet.py:139-153, PSMNet/stackhourglass.py:74-84):
  * N = 1 is not GEMM-shaped, so it gets VALU kernels. w: torch layout [1][Cin][27]; out/residual/gy: [B][D][H][W].
  * Cin % 16 == 0 (wgrad: Cin <= 64). dgrad: gx [B][D][H][W][Cin] = autograd input gradient of the same layer

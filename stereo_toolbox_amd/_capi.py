@@ -51,6 +51,8 @@ SIGNATURES = {
     "stx_deconv3d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_wgrad_workspace_floats": [_I, _I, _I, _I, _I, _I, _I, _I],
     "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "stx_conv3d_wgrad_bn_supported": [_I, _I, _I, _I, _I, _I],
+    "stx_conv3d_wgrad_bn": [_P] * 9 + [_F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     # conv_c1.hip
     "stx_conv3d_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_c1_wgrad_workspace_floats": [_I],

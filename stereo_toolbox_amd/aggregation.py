@@ -11,6 +11,7 @@ Three execution modes of one block  y = act(BN(conv(x)) [+ BN2(conv2(x2))] [+ re
   * training  (train BN): conv emits raw z + batch-stat partials -> bn_finalize -> bn_apply;
   * eval BN with autograd: as training but with the running statistics.
 """
+import os
 import threading
 
 import torch
@@ -240,7 +241,12 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
         z2, part2 = second_raw if second_raw is not None else _raw_conv(x2, conv2, want2)
         st2 = _bn_state(bn2, part2 if want2 else None, z2.numel() // z2.shape[-1])
         return ops.BnActFn.apply(z1, bn.weight, bn.bias, z2, bn2.weight, bn2.bias, None, relu, st1, st2)
-    return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None)
+    # a 3x3x3 stride-1 block without residual: its BatchNorm's backward-apply pass rides inside the convolution's march
+    # weight-gradient kernel (ops._PendingBn; the convolution's backward node falls back to the stand-alone pass otherwise)
+    defer = (residual is None and want and relu in (0, 1, False, True) and not _is_transposed(conv) and _conv_cfg(conv) == (3, 1)
+             and conv.weight.shape[0] % 32 == 0 and conv.weight.shape[1] % 32 == 0 and not st1.get("sync")
+             and os.environ.get("STX_BN_BWD_IN_WGRAD", "1") != "0")
+    return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None, 1, defer)
 
 
 def convbn_block(x, seq, relu=False, second=None, residual=None, mish=False, raw=None, second_raw=None):

@@ -1618,8 +1618,13 @@ static int wgrad_chunks(int ntiles, int npairs, bool pipe) {
 }
 
 // march form of the 3x3x3 stride-1 weight gradient (wgrad_march.hip)
-int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, int D, int H, int W, int CF, int CC,
-                           int nchunks, void* stream);
+struct StxWgradBn {        // (wgrad_march.hip)
+    const float* z; float* dz;
+    const float *scale, *shift, *mean, *invstd, *gamma, *sum_g, *sum_gx;
+    float inv_n; int act;
+};
+int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, int D, int H, int W, int CF, int CC, int nchunks,
+                           void* stream, const StxWgradBn* bn);
 int stx_wgrad_march_chunks(int B, int D, int H, int W, int npairs);
 int stx_wgrad_march_s2_launch(const float* f, const float* c, float* slab, int B, int Df, int Hf, int Wf, int CF, int Dc, int Hc,
                               int Wc, int CC, int nchunks, void* stream);
@@ -1669,7 +1674,7 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
         int mc = stx_wgrad_march_chunks(B, Dc, Hc, Wc, npairs);
         const int forced = stx_tune(STX_TUNE_WGRAD_GRID);
         if (forced > 0 && forced < mc) mc = forced;
-        const int rc = stride == 1 ? stx_wgrad_march_launch(f, c, workspace, B, Dc, Hc, Wc, CF, CC, mc, stream)
+        const int rc = stride == 1 ? stx_wgrad_march_launch(f, c, workspace, B, Dc, Hc, Wc, CF, CC, mc, stream, nullptr)
                                    : stx_wgrad_march_s2_launch(f, c, workspace, B, Df, Hf, Wf, CF, Dc, Hc, Wc, CC, mc, stream);
         if (rc > 0) return rc;
         if (rc == 0) {
@@ -1704,5 +1709,44 @@ extern "C" int stx_conv3d_wgrad(const float* f, const float* c, float* dw, float
     const int total = npairs * T * 1024;
     hipLaunchKernelGGL(conv3d_wgrad_reduce4_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, st, workspace, dw, CF, CC, T,
                        nchunks, ks == 1 ? 4 : 27);                   // (KS = 1: one slab row per wave of the 4-wave producer)
+    return stx_check_launch("conv3d_wgrad_reduce");
+}
+
+// Whether stx_conv3d_wgrad_bn serves a 3x3x3 stride-1 layer of this shape (the march kernel's conditions + its tuning switch).
+extern "C" int stx_conv3d_wgrad_bn_supported(int B, int D, int H, int W, int CF, int CC) {
+    stx_begin();
+    return (stx_tune(STX_TUNE_WGRAD_MARCH) & 1) && B > 0 && D > 0 && H > 0 && W > 0 && CF >= 32 && CC >= 32 && CF % 32 == 0 &&
+           CC % 32 == 0 && (long long)H * W * CF * 4 < (1ll << 31) && (long long)H * W * CC * 4 < (1ll << 31) &&
+           (long long)B * stx_cdiv(H, 4) * stx_cdiv(W, 16) < (1ll << 31);
+}
+
+// Weight gradient of a 3x3x3 stride-1 convolution whose raw output z went through train-mode BatchNorm (+ ReLU when act = 1)
+// -- reference `convbn_3d` + `nn.ReLU` (models/GwcNet/submodule.py:17-20) under autograd -- taking the gradient gy BEHIND that
+// BatchNorm / activation: the kernel forms  dz = gamma invstd (gy' - sum_g / n - xhat sum_gx / n)  on the way to the matrix cores
+// (gy' = gy masked by the activation, recomputed from fmaf(z, scale, shift); xhat = (z - mean) invstd; sums = the [2][CC]
+// rows "sum gy'" and "sum gy' xhat" of stx_bn_bwd_reduce2) and writes it to `dz` for the data-gradient launch: the
+// stx_bn_bwd_apply2 pass of such a block is not needed.  dw / workspace as in stx_conv3d_wgrad (ks = 3, stride = 1).
+extern "C" int stx_conv3d_wgrad_bn(const float* x, const float* gy, const float* z, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, const float* gamma, const float* sums, float inv_n,
+                                   int act, float* dz, float* dw, float* workspace, int B, int D, int H, int W, int CF, int CC,
+                                   void* stream) {
+    stx_begin();
+    STX_REQUIRE(x && gy && z && scale && shift && mean && invstd && sums && dz && dw && workspace, "conv3d_wgrad_bn: null operand");
+    STX_REQUIRE(act == 0 || act == 1, "conv3d_wgrad_bn: activation code %d (0 or 1)", act);
+    STX_REQUIRE(stx_conv3d_wgrad_bn_supported(B, D, H, W, CF, CC), "conv3d_wgrad_bn: shape (%d x %d x %d x %d, %d -> %d channels) is "
+                "not served by the march kernel (ask stx_conv3d_wgrad_bn_supported)", B, D, H, W, CF, CC);
+    const int npairs = (CF / 32) * (CC / 32);
+    int mc = stx_wgrad_march_chunks(B, D, H, W, npairs);
+    const int forced = stx_tune(STX_TUNE_WGRAD_GRID);
+    if (forced > 0 && forced < mc) mc = forced;
+    StxWgradBn bn;
+    bn.z = z; bn.dz = dz; bn.scale = scale; bn.shift = shift; bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma;
+    bn.sum_g = sums; bn.sum_gx = sums + CC; bn.inv_n = inv_n; bn.act = act;
+    const int rc = stx_wgrad_march_launch(x, gy, workspace, B, D, H, W, CF, CC, mc, stream, &bn);
+    if (rc > 0) return rc;
+    STX_REQUIRE(rc == 0, "conv3d_wgrad_bn: the march kernel refused the shape");
+    const int total = npairs * 27 * 1024;
+    hipLaunchKernelGGL(conv3d_wgrad_reduce4_kernel, dim3(total / 64), dim3(CONV_THREADS), 0, (hipStream_t)stream, workspace, dw, CF,
+                       CC, 27, mc, 27);
     return stx_check_launch("conv3d_wgrad_reduce");
 }

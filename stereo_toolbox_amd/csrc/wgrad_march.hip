@@ -51,6 +51,13 @@ struct WmArgs {
     int B, D, H, W, CF, CC;
     int nHt, nWt, ncols;
     long long nsteps;   // ncols * D
+    // BatchNorm-backward form (conv3d_wgrad_march_kernel<true>): `gy` is the gradient BEHIND the BatchNorm + activation, the
+    // gradient of the convolution's raw output is formed on the way into LDS and written to `dz` for the data-gradient launch
+    const float* z;     // the convolution's raw output [B][D][H][W][CC]
+    float* dz;          // [B][D][H][W][CC]
+    const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_gamma, *bn_sum_g, *bn_sum_gx;   // [CC] each (gamma may be NULL)
+    float bn_inv_n;
+    int bn_act;         // activation code of the block: 0 or 1 (ReLU)
 };
 
 __device__ __forceinline__ f32x16 wm_zero16() {
@@ -60,6 +67,12 @@ __device__ __forceinline__ f32x16 wm_zero16() {
     return z;
 }
 
+// BN = true: the coarse operand is  dz = gamma invstd (g' - sum_g / n - xhat sum_gx / n),  g' = gy masked by the activation
+// (sign of fmaf(z, scale, shift)), xhat = (z - mean) invstd -- exactly what bn_bwd_apply_kernel (bn.hip) writes -- computed per
+// element between the global load of (gy, z) and the LDS write; the workgroups of the first input-channel block also store it
+// (every coarse voxel passes through exactly one step of every channel-block pair).  A train-mode conv + BN block then needs
+// no bn_bwd_apply launch: its three volume passes (two reads, one write) ride inside this MFMA-bound kernel.
+template <bool BN>
 __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
     STX_DYN_SMEM(smem);
     float* xl = reinterpret_cast<float*>(smem);              // [4][32 ch][CHP]
@@ -92,6 +105,14 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
     const unsigned goff = (unsigned)(((glh * a.W + glw) * a.CC + ccb * 32 + 4 * gf) * 4);
     const int gpos = (4 * gf) * WM_GP + glh * WM_TW + glw;
     const long long plane = (long long)a.H * a.W;
+    // BN form: the per-channel vectors of this lane's four coarse channels
+    float4 bsc, bsh, bmu, bis, bgm, bsg, bsx;
+    if constexpr (BN) {
+        const int c4 = ccb * 32 + 4 * gf;
+        bsc = stx_ld4(a.bn_scale + c4); bsh = stx_ld4(a.bn_shift + c4); bmu = stx_ld4(a.bn_mean + c4);
+        bis = stx_ld4(a.bn_invstd + c4); bsg = stx_ld4(a.bn_sum_g + c4); bsx = stx_ld4(a.bn_sum_gx + c4);
+        bgm = a.bn_gamma ? stx_ld4(a.bn_gamma + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
 
     // operand addresses: lane (channel i, K half) reads voxels [8 q + 4 half, + 8) of its channel's tile row
     const int grp8 = (wave >> 1) * WM_EWP + 8 * (wave & 1);  // the wave's voxel group of the ninth tap row
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
         const unsigned gvo = (oh0 + glh < a.H && ow0 + glw < a.W) ? goff : STX_BUF_OOB;
         const long long xorg = (long long)(oh0 - 1) * a.W + (ow0 - 1), gorg = (long long)oh0 * a.W + ow0;
 
-        float4 sx[WM_NPX], sg;
+        float4 sx[WM_NPX], sg, sz;
         auto load_x = [&](int p) {
             const bool in = p >= 0 && p < a.D;
             const stx_bufrsrc rs = stx_make_rsrc(a.x + (((long long)b * a.D + (in ? p : 0)) * plane + xorg) * a.CF,
@@ -131,6 +152,29 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
             const stx_bufrsrc rs = stx_make_rsrc(a.gy + (((long long)b * a.D + (in ? p : 0)) * plane + gorg) * a.CC,
                                                  in ? (unsigned)((plane - gorg) * a.CC * 4) : 0u);
             sg = stx_buf_ld4(rs, gvo, 0u);
+            if constexpr (BN) {
+                const stx_bufrsrc rz = stx_make_rsrc(a.z + (((long long)b * a.D + (in ? p : 0)) * plane + gorg) * a.CC,
+                                                     in ? (unsigned)((plane - gorg) * a.CC * 4) : 0u);
+                sz = stx_buf_ld4(rz, gvo, 0u);
+            }
+        };
+        // (gy, z) -> dz for the plane in the staging registers (same expression, operand order and activation rule as
+        // bn_bwd_apply_kernel); plane p's slice goes to global memory from the first input-channel block
+        auto bn_apply_staged = [&](int p) {
+            float4 g = sg;
+            if (a.bn_act) {
+                g.x = stx_act_bwd(g.x, fmaf(sz.x, bsc.x, bsh.x), a.bn_act); g.y = stx_act_bwd(g.y, fmaf(sz.y, bsc.y, bsh.y), a.bn_act);
+                g.z = stx_act_bwd(g.z, fmaf(sz.z, bsc.z, bsh.z), a.bn_act); g.w = stx_act_bwd(g.w, fmaf(sz.w, bsc.w, bsh.w), a.bn_act);
+            }
+            const float n1 = a.bn_inv_n;
+            float4 d;
+            d.x = bgm.x * bis.x * (g.x - bsg.x * n1 - (sz.x - bmu.x) * bis.x * bsx.x * n1);
+            d.y = bgm.y * bis.y * (g.y - bsg.y * n1 - (sz.y - bmu.y) * bis.y * bsx.y * n1);
+            d.z = bgm.z * bis.z * (g.z - bsg.z * n1 - (sz.z - bmu.z) * bis.z * bsx.z * n1);
+            d.w = bgm.w * bis.w * (g.w - bsg.w * n1 - (sz.w - bmu.w) * bis.w * bsx.w * n1);
+            if (gvo == STX_BUF_OOB) d = make_float4(0.f, 0.f, 0.f, 0.f);      // (voxels outside the volume: zero operands)
+            else if (cfb == 0) stx_st4(a.dz + (((long long)b * a.D + p) * plane + gorg) * a.CC + (goff >> 2), d);
+            sg = d;
         };
         auto store_x = [&](int p) {
             float* dst = xl + (p & 3) * WM_XPLANE;
@@ -142,6 +186,7 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
                 }
         };
         auto store_g = [&](int p) {
+            if constexpr (BN) bn_apply_staged(p);
             float* q = gl + (p & 1) * WM_GPLANE + gpos;
             q[0] = sg.x; q[WM_GP] = sg.y; q[2 * WM_GP] = sg.z; q[3 * WM_GP] = sg.w;
         };
@@ -165,6 +210,11 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_kernel(WmArgs a) {
                 const stx_bufrsrc rg = stx_make_rsrc(a.gy + (((long long)b * a.D + (more ? o + 1 : 0)) * plane + gorg) * a.CC,
                                                      more ? (unsigned)((plane - gorg) * a.CC * 4) : 0u);
                 sg = stx_buf_ld4(rg, gvo, 0u);
+                if constexpr (BN) {
+                    const stx_bufrsrc rz = stx_make_rsrc(a.z + (((long long)b * a.D + (more ? o + 1 : 0)) * plane + gorg) * a.CC,
+                                                         more ? (unsigned)((plane - gorg) * a.CC * 4) : 0u);
+                    sz = stx_buf_ld4(rz, gvo, 0u);
+                }
             }
             const float* xa = xl + ((o + kdw - 1) & 3) * WM_XPLANE + khw * WM_EWP + xlane;
             const float* x8 = xl + ((o + 1) & 3) * WM_XPLANE + 2 * WM_EWP + grp8 + xlane;
@@ -492,22 +542,35 @@ __global__ __launch_bounds__(WM_THR) void conv3d_wgrad_march_s2_kernel(WmArgs a,
 
 // Internal interface (conv3d.hip): launches the march kernel into `slab` ([pairs][chunks][27][1024]) with `nchunks`
 // workgroups per channel-block pair; the caller runs the common reduction.  Returns -1 when the shape is not served.
+struct StxWgradBn {        // the BatchNorm-backward operands of stx_conv3d_wgrad_bn (conv3d.hip fills it)
+    const float* z; float* dz;
+    const float *scale, *shift, *mean, *invstd, *gamma, *sum_g, *sum_gx;
+    float inv_n; int act;
+};
+
 int stx_wgrad_march_launch(const float* x, const float* gy, float* slab, int B, int D, int H, int W, int CF, int CC,
-                           int nchunks, void* stream) {
+                           int nchunks, void* stream, const StxWgradBn* bn) {
     if (CF % 32 || CC % 32 || B < 1 || D < 1 || H < 1 || W < 1) return -1;
     if ((long long)H * W * CF * 4 >= (1ll << 31) || (long long)H * W * CC * 4 >= (1ll << 31)) return -1;   // descriptor range of a plane
     WmArgs a;
     a.x = x; a.gy = gy; a.slab = slab; a.B = B; a.D = D; a.H = H; a.W = W; a.CF = CF; a.CC = CC;
+    a.z = nullptr; a.dz = nullptr;
+    a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_sum_g = a.bn_sum_gx = nullptr;
+    a.bn_inv_n = 0.f; a.bn_act = 0;
+    if (bn) {
+        a.z = bn->z; a.dz = bn->dz; a.bn_scale = bn->scale; a.bn_shift = bn->shift; a.bn_mean = bn->mean; a.bn_invstd = bn->invstd;
+        a.bn_gamma = bn->gamma; a.bn_sum_g = bn->sum_g; a.bn_sum_gx = bn->sum_gx; a.bn_inv_n = bn->inv_n; a.bn_act = bn->act;
+    }
     a.nHt = stx_cdiv(H, WM_TH); a.nWt = stx_cdiv(W, WM_TW);
     const long long ncols = (long long)B * a.nHt * a.nWt;
     if (ncols >= (1ll << 31)) return -1;
     a.ncols = (int)ncols;
     a.nsteps = ncols * D;
     const int npairs = (CF / 32) * (CC / 32);
-    if (hipFuncSetAttribute((const void*)conv3d_wgrad_march_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)WM_LDS_BYTES) != hipSuccess)
+    void (*kern)(WmArgs) = bn ? conv3d_wgrad_march_kernel<true> : conv3d_wgrad_march_kernel<false>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WM_LDS_BYTES) != hipSuccess)
         return stx_set_error(STX_ERR_LAUNCH, "conv3d_wgrad(march): %d bytes of dynamic LDS refused by this device", (int)WM_LDS_BYTES);
-    hipLaunchKernelGGL(conv3d_wgrad_march_kernel, dim3(nchunks, npairs), dim3(WM_THR), WM_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(nchunks, npairs), dim3(WM_THR), WM_LDS_BYTES, (hipStream_t)stream, a);
     return stx_check_launch("conv3d_wgrad(march)");
 }
 
@@ -516,7 +579,7 @@ int stx_wgrad_march_s2_launch(const float* f, const float* c, float* slab, int B
                               int Wc, int CC, int nchunks, void* stream) {
     if (CF % 32 || CC % 32 || B < 1 || Dc < 1 || Hc < 1 || Wc < 1) return -1;
     if ((long long)Df * Hf * Wf * CF * 4 >= (1ll << 32) || (long long)Hc * Wc * CC * 4 >= (1ll << 31)) return -1;   // (tile kernel)
-    WmArgs a;
+    WmArgs a = {};
     a.x = f; a.gy = c; a.slab = slab; a.B = B; a.D = Dc; a.H = Hc; a.W = Wc; a.CF = CF; a.CC = CC;
     a.nHt = stx_cdiv(Hc, WM_TH); a.nWt = stx_cdiv(Wc, WM_TW);
     const long long ncols = (long long)B * a.nHt * a.nWt;

@@ -243,6 +243,45 @@ def conv3d_wgrad(fine, coarse, ks, stride):
     return dw
 
 
+def conv3d_wgrad_bn(x, gy, pend):
+    """Weight gradient of a 3x3x3 stride-1 convolution from the gradient BEHIND its train-mode BatchNorm (+ ReLU): returns
+    (dw [CC, CF, 27], dz) -- see stx_conv3d_wgrad_bn.  `pend` = the record BnActFn.backward left (_PendingBn)."""
+    B, D, H, W, CF = x.shape
+    CC = gy.shape[-1]
+    n = get_lib().raw("stx_conv3d_wgrad_workspace_floats")(B, D, H, W, CF, CC, 3, 1)
+    ws = _WS.get("wgrad", n, x.device)
+    dw = torch.empty(CC, CF, 27, dtype=torch.float32, device=x.device)
+    dz = torch.empty_like(gy)
+    _call("stx_conv3d_wgrad_bn", _p(x), _p(gy), _p(pend.z), _p(pend.scale), _p(pend.shift), _p(pend.mean), _p(pend.invstd),
+          _p(pend.gamma), _p(pend.sums), float(pend.inv_n), int(pend.act), _p(dz), _p(dw), _p(ws), B, D, H, W, CF, CC)
+    return dw, dz
+
+
+class _PendingBn:
+    """What BnActFn.backward hands to the backward of the convolution that produced its input when the BatchNorm's
+    `bn_bwd_apply` pass is folded into that convolution's weight-gradient kernel (conv_block decides: `defer`): the
+    operands of dz = gamma invstd (gy' - sum_g / n - xhat sum_gx / n).  Keyed by the identity of the gradient tensor."""
+    __slots__ = ("g", "z", "scale", "shift", "mean", "invstd", "gamma", "sums", "inv_n", "act")
+
+    def materialize(self):
+        """The BatchNorm-backward apply pass on its own (a consumer that cannot fold it: frozen weights, other kernels)."""
+        C = self.z.shape[-1]
+        nvox = self.z.numel() // C
+        dz = torch.empty_like(self.z)
+        _call("stx_bn_bwd_apply2", _p(self.g), None, _p(self.z), _p(self.mean), _p(self.invstd), _p(self.gamma), None, None,
+              None, None, _p(self.scale), _p(self.shift), None, None, _p(self.sums), _p(dz), None, None, nvox, C, int(self.act), 1)
+        return dz
+
+
+_PENDING_BN = {}
+
+
+def _take_pending_bn(g):
+    """The deferred-BatchNorm record for gradient tensor `g`, if BnActFn.backward left one (and `g` is that very tensor)."""
+    pend = _PENDING_BN.pop(id(g), None) if g is not None else None
+    return pend if pend is not None and pend.g is g else None
+
+
 def _is_c1(w, ks, stride, transposed):
     """Classifier tail Conv3d(Cin, 1, 3, padding=1): served by the VALU kernels of conv_c1.hip."""
     return (not transposed) and ks == 3 and stride == 1 and w.shape[0] == 1 and w.shape[1] % 16 == 0 and w.shape[1] <= 64
@@ -313,9 +352,21 @@ class ConvRawFn(torch.autograd.Function):
     def backward(ctx, gz, _gstats):
         x, w = ctx.saved_tensors
         ks, stride, transposed = ctx.cfg
-        gz = gz.contiguous()
+        pend = _take_pending_bn(gz)
         gx = gw = None
         B, D, H, W, Cin = x.shape
+        if pend is not None:
+            # gz is the gradient BEHIND this convolution's BatchNorm (BnActFn deferred its apply pass): the march weight
+            # gradient forms dz itself and writes it for the data gradient below
+            if (ctx.needs_input_grad[1] and not transposed and ks == 3 and stride == 1 and ctx.cin_true is None
+                    and get_lib().raw("stx_conv3d_wgrad_bn_supported")(B, D, H, W, Cin, w.shape[0])):
+                gw_pre, gz = conv3d_wgrad_bn(x, gz, pend)
+                gw_pre = gw_pre.reshape(w.shape)
+            else:
+                gw_pre, gz = None, pend.materialize()
+        else:
+            gw_pre = None
+        gz = gz.contiguous()
         if transposed:
             Ci, Co = w.shape[0], w.shape[1]
             if ctx.needs_input_grad[0]:   # stride-2 conv of gz with the deconv weight read as [Cout'][Cin']
@@ -354,7 +405,9 @@ class ConvRawFn(torch.autograd.Function):
                         w_k = w.new_zeros(Cp, *w.shape[1:])
                         w_k[:Co] = w
                     gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W))
-            if ctx.needs_input_grad[1]:
+            if gw_pre is not None:
+                gw = gw_pre
+            elif ctx.needs_input_grad[1]:
                 if c1:
                     gw = conv3d_c1_wgrad(x, gz)
                 else:
@@ -399,8 +452,19 @@ class SharedInputConvsFn(torch.autograd.Function):
     def backward(ctx, *grads):
         x, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         B, D, H, W, Ci = x.shape
-        gzs = [None if g is None else g.contiguous() for g in grads[0::2]]
         gws = [None] * len(ws)
+        gzs = []
+        for k, g in enumerate(grads[0::2]):
+            pend = _take_pending_bn(g)
+            if pend is not None:                       # (see ConvRawFn.backward)
+                ks, stride, _ = ctx.cfgs[k]
+                if (ctx.needs_input_grad[2 + k] and ks == 3 and stride == 1
+                        and get_lib().raw("stx_conv3d_wgrad_bn_supported")(B, D, H, W, Ci, ws[k].shape[0])):
+                    gw, g = conv3d_wgrad_bn(x, g, pend)
+                    gws[k] = gw.reshape(ws[k].shape)
+                else:
+                    g = pend.materialize()
+            gzs.append(None if g is None else g.contiguous())
         gx = None
         if ctx.needs_input_grad[0]:
             rank = lambda k: (0 if ctx.cfgs[k][0] == 3 and ctx.cfgs[k][1] == 1 else (1 if ctx.cfgs[k][1] == 2 else 2))
@@ -418,7 +482,7 @@ class SharedInputConvsFn(torch.autograd.Function):
                         w_k[:Co] = w
                     gx, _ = deconv3d_forward(gz_k, pack_weight(w_k, 2), Ci, out_dims=(D, H, W), residual=gx)
         for k, (w, gz) in enumerate(zip(ws, gzs)):
-            if gz is None or not ctx.needs_input_grad[2 + k]:
+            if gz is None or not ctx.needs_input_grad[2 + k] or gws[k] is not None:
                 continue
             ks, stride, _ = ctx.cfgs[k]
             Co = w.shape[0]
@@ -695,8 +759,11 @@ class BnActFn(torch.autograd.Function):
     separate forward calls would (the two views of the 2-D feature CNN, reference gwcnet.py:172-173)."""
 
     @staticmethod
-    def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2, groups=1):
+    def forward(ctx, z1, gamma1, beta1, z2, gamma2, beta2, residual, relu, bn1, bn2, groups=1, defer=False):
         G = int(groups)
+        # defer: z1 is the raw output of a 3x3x3 stride-1 convolution whose backward node folds this BatchNorm's
+        # backward-apply pass into its weight-gradient kernel (conv_block sets it; see _PendingBn)
+        ctx.defer = bool(defer)
 
         def affine(gamma, beta, bn):
             if bn["training"]:
@@ -755,6 +822,16 @@ class BnActFn(torch.autograd.Function):
         _call("stx_bn_bwd_reduce2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
               _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(sc1), _p(sh1), _p(sc2), _p(sh2), _p(part),
               _p(sums_all), nvox, C, int(ctx.relu), G)
+        if (ctx.defer and not ctx.two and not ctx.has_res and ctx.relu in (0, 1) and ctx.train1 and not ctx.sync and G == 1
+                and (not ctx.relu or ctx.remask)):
+            pend = _PendingBn()
+            pend.g, pend.z, pend.scale, pend.shift, pend.mean, pend.invstd = gy, z1, sc1, sh1, m1, i1
+            pend.gamma, pend.sums, pend.inv_n, pend.act = gamma1, sums, 1.0 / nvox, int(ctx.relu)
+            if pend.scale is None:                     # (no activation: the mask operands were not saved; any finite pair does)
+                pend.scale = pend.shift = m1
+            _PENDING_BN[id(gy)] = pend
+            tot = sums_all[0]
+            return (gy, tot[1], tot[0], None, None, None, None, None, None, None, None, None)
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None
@@ -776,7 +853,7 @@ class BnActFn(torch.autograd.Function):
             gres = gy
         tot = sums_all[G] if G > 1 else sums_all[0]       # gamma / beta are shared between the groups
         return (dz1, tot[1], tot[0], dz2, tot[2] if ctx.two else None, tot[0] if ctx.two else None, gres,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------- activations

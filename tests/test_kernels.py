@@ -536,6 +536,47 @@ def test_conv3d_wgrad(be, case, tune, march):
     _close(run_wgrad(be, x, gy, ks, s).view_as(w), w.grad)
 
 
+@pytest.mark.parametrize("case", [(1, 32, 32, 3, 5, 37, 1), (2, 64, 32, 2, 9, 21, 1), (1, 32, 64, 3, 4, 16, 0), (1, 64, 64, 5, 6, 40, 1)])
+def test_conv3d_wgrad_bn(be, tune, case):
+    """stx_conv3d_wgrad_bn (weight gradient of a 3x3x3 stride-1 conv taking the gradient BEHIND its train-mode BatchNorm + ReLU,
+    dz formed inside the march kernel) vs the two-launch pipeline it replaces: stx_bn_bwd_apply2 -> stx_conv3d_wgrad.  dz to a
+    few ulp (the same expression, contracted by two compilers' schedules), dw like any weight gradient.  Ragged tiles, two
+    input-channel blocks (dz written once), several steps per workgroup, no activation."""
+    B, Cin, Cout, D, H, W, act = case
+    tune("STX_WGRAD_GRID", 3)
+    torch.manual_seed(12)
+    nvox = B * D * H * W
+    x = torch.randn(B, D, H, W, Cin)
+    z = torch.randn(B, D, H, W, Cout)
+    gy = torch.randn(B, D, H, W, Cout)
+    scale, shift = torch.randn(Cout), torch.randn(Cout) * 0.3
+    mean, invstd, gamma = torch.randn(Cout) * 0.2, torch.rand(Cout) + 0.5, torch.rand(Cout) + 0.5
+    dx, dz_in, dgy = be.dev(x), be.dev(z), be.dev(gy)
+    dsc, dsh, dm, di, dgm = (be.dev(t) for t in (scale, shift, mean, invstd, gamma))
+    NB = be.raw("stx_bn_reduce_blocks")()
+    part, sums = be.empty(NB, 3, Cout), be.empty(3, Cout)
+    be.call("stx_bn_bwd_reduce2", ptr(dgy), None, ptr(dz_in), ptr(dm), ptr(di), None, None, None, ptr(dsc), ptr(dsh), None, None,
+            ptr(part), ptr(sums), nvox, Cout, act, 1)
+    dz_ref = be.empty(B, D, H, W, Cout)
+    be.call("stx_bn_bwd_apply2", ptr(dgy), None, ptr(dz_in), ptr(dm), ptr(di), ptr(dgm), None, None, None, None, ptr(dsc),
+            ptr(dsh), None, None, ptr(sums), ptr(dz_ref), None, None, nvox, Cout, act, 1)
+    n = be.raw("stx_conv3d_wgrad_workspace_floats")(B, D, H, W, Cin, Cout, 3, 1)
+    ws = be.empty(n)
+    dw_ref = be.empty(Cout, Cin, 27)
+    be.call("stx_conv3d_wgrad", ptr(dx), ptr(dz_ref), ptr(dw_ref), ptr(ws), B, D, H, W, Cin, D, H, W, Cout, 3, 1)
+    assert be.raw("stx_conv3d_wgrad_bn_supported")(B, D, H, W, Cin, Cout) == 1
+    dz, dw = be.empty(B, D, H, W, Cout), be.empty(Cout, Cin, 27)
+    dz.fill_(float("nan"))
+    be.call("stx_conv3d_wgrad_bn", ptr(dx), ptr(dgy), ptr(dz_in), ptr(dsc), ptr(dsh), ptr(dm), ptr(di), ptr(dgm), ptr(sums),
+            1.0 / nvox, act, ptr(dz), ptr(dw), ptr(ws), B, D, H, W, Cin, Cout)
+    _close(dz, dz_ref.cpu(), rtol=1e-5, atol=1e-6)
+    _close(dw, dw_ref.cpu(), rtol=2e-4, atol=2e-4)
+    # and against autograd through conv3d on the CPU (the gradient the pair of launches stands for)
+    w0 = torch.zeros(Cout, Cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x.permute(0, 4, 1, 2, 3), w0, None, 1, 1).backward(dz_ref.cpu().permute(0, 4, 1, 2, 3))
+    _close(dw.view_as(w0), w0.grad, rtol=2e-3, atol=2e-3)
+
+
 @pytest.mark.parametrize("march", [3, 0], ids=["march", "tile_kernel"])
 def test_conv3d_wgrad_many_tiles_per_workgroup(be, tune, march):
     """The weight-gradient kernels' tile loop with several tiles per workgroup (STX_WGRAD_GRID caps the split-K workgroups; at

@@ -260,7 +260,7 @@ def conv3d_wgrad_bn(x, gy, pend):
 class _PendingBn:
     """What BnActFn.backward hands to the backward of the convolution that produced its input when the BatchNorm's
     `bn_bwd_apply` pass is folded into that convolution's weight-gradient kernel (conv_block decides: `defer`): the
-    operands of dz = gamma invstd (gy' - sum_g / n - xhat sum_gx / n).  Keyed by the identity of the gradient tensor."""
+    operands of dz = gamma invstd (gy' - sum_g / n - xhat sum_gx / n).  Attached to the gradient tensor it describes."""
     __slots__ = ("g", "z", "scale", "shift", "mean", "invstd", "gamma", "sums", "inv_n", "act")
 
     def materialize(self):
@@ -273,13 +273,36 @@ class _PendingBn:
         return dz
 
 
-_PENDING_BN = {}
+# Safety net of the deferral: a record that no convolution backward consumed means that convolution differentiated the
+# UN-normalised gradient.  Every backward pass that defers queues one end-of-pass callback that raises in that case.
+_BN_DEFER = {"outstanding": 0, "armed": False}
+
+
+def _bn_defer_check():
+    n, _BN_DEFER["outstanding"], _BN_DEFER["armed"] = _BN_DEFER["outstanding"], 0, False
+    if n:
+        raise StxError(f"{n} deferred BatchNorm-backward record(s) were not consumed by their convolution's backward node: "
+                       "the gradients of this backward pass are wrong (set STX_BN_BWD_IN_WGRAD=0 and report)")
+
+
+def _defer_pending_bn(g, pend):
+    g._stx_pending_bn = pend
+    _BN_DEFER["outstanding"] += 1
+    if not _BN_DEFER["armed"]:
+        _BN_DEFER["armed"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_bn_defer_check)
 
 
 def _take_pending_bn(g):
-    """The deferred-BatchNorm record for gradient tensor `g`, if BnActFn.backward left one (and `g` is that very tensor)."""
-    pend = _PENDING_BN.pop(id(g), None) if g is not None else None
-    return pend if pend is not None and pend.g is g else None
+    """The deferred-BatchNorm record BnActFn.backward attached to gradient tensor `g`, if any (it travels ON the tensor object:
+    no global table to leak when a backward pass is interrupted, nothing shared between threads)."""
+    pend = getattr(g, "_stx_pending_bn", None) if g is not None else None
+    if pend is not None:
+        del g._stx_pending_bn
+        _BN_DEFER["outstanding"] -= 1
+        if pend.g is not g:                        # (cannot happen; a stale record must never be applied to another tensor)
+            raise StxError("deferred BatchNorm backward: record attached to a different gradient tensor")
+    return pend
 
 
 def _is_c1(w, ks, stride, transposed):
@@ -829,7 +852,7 @@ class BnActFn(torch.autograd.Function):
             pend.gamma, pend.sums, pend.inv_n, pend.act = gamma1, sums, 1.0 / nvox, int(ctx.relu)
             if pend.scale is None:                     # (no activation: the mask operands were not saved; any finite pair does)
                 pend.scale = pend.shift = m1
-            _PENDING_BN[id(gy)] = pend
+            _defer_pending_bn(gy, pend)
             tot = sums_all[0]
             return (gy, tot[1], tot[0], None, None, None, None, None, None, None, None, None)
         dz1 = torch.empty_like(z1)

@@ -409,6 +409,46 @@ def test_shared_input_convs_match_separate_nodes(env):
         assert shared_input_convs(xa.detach().requires_grad_(), list(mods)) is None
 
 
+def test_bn_backward_in_weight_gradient_matches_separate_pass(env, monkeypatch):
+    """A 3x3x3 stride-1 convbn_3d + ReLU block through aggregation.convbn_block: with the BatchNorm's backward-apply pass folded
+    into the march weight gradient (default) vs as its own launch (STX_BN_BWD_IN_WGRAD=0): same gradients (dz differs by the
+    contraction of one expression: a few ulp); frozen convolution weights take the stand-alone pass; a record that no convolution
+    backward consumes makes the backward pass fail loudly."""
+    from stereo_toolbox_amd import ops
+    from stereo_toolbox_amd.aggregation import convbn_block
+    from stereo_toolbox_amd.models.GwcNet.submodule import convbn_3d
+    torch.manual_seed(9)
+    x0 = torch.randn(1, 3, 6, 20, 32)
+    g0 = torch.randn(1, 3, 6, 20, 32)
+
+    def run(flag, freeze=False):
+        monkeypatch.setenv("STX_BN_BWD_IN_WGRAD", flag)
+        torch.manual_seed(10)
+        blk = convbn_3d(32, 32, 3, 1, 1)
+        with env.ctx():
+            blk = blk.to(env.device).train()
+            blk[0].weight.requires_grad_(not freeze)
+            x = x0.to(env.device).requires_grad_()
+            convbn_block(x, blk, relu=True).backward(g0.to(env.device))
+            return [t.cpu() for t in (x.grad, blk[1].weight.grad, blk[1].bias.grad)] + ([] if freeze else [blk[0].weight.grad.cpu()])
+
+    calls = {"n": 0}
+    orig = ops.conv3d_wgrad_bn
+    monkeypatch.setattr(ops, "conv3d_wgrad_bn", lambda *a: (calls.__setitem__("n", calls["n"] + 1), orig(*a))[1])
+    fused, plain = run("1"), run("0")
+    assert calls["n"] == 1
+    for a, b in zip(fused, plain):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-7
+    frozen_fused, frozen_plain = run("1", freeze=True), run("0", freeze=True)
+    assert calls["n"] == 1                                       # frozen weights: the stand-alone pass
+    for a, b in zip(frozen_fused, frozen_plain):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-7
+    monkeypatch.setattr(ops, "_take_pending_bn", lambda g: None)      # a backward node that misses the record
+    with pytest.raises(Exception, match="deferred BatchNorm-backward"):
+        run("1")
+    ops._BN_DEFER["outstanding"], ops._BN_DEFER["armed"] = 0, False
+
+
 def test_functional_api(env):
     """Drop-in functions of models/GwcNet/submodule.py and disparity_estimators."""
     from stereo_toolbox_amd.disparity_estimators import (argmax_disparity_estimator, dominant_modal_disparity_estimator,

@@ -336,11 +336,29 @@ def features_psm(cx, x, p="feature_extraction"):
 
 
 # ----------------------------------------------------------------------------- whole models
-def gwcnet_forward(sd, left, right, maxdisp, use_concat_volume, training=False, return_ctx=False):
-    """GwcNet/gwcnet.py:171-224."""
+def feature_noise(eps, seed):
+    """Test helper: a `feature_hook` that multiplies the k-th feature map it sees by (1 + eps * N(0,1)) -- a relative
+    perturbation of the size of fp32 rounding / of the measured distance between two fp32 evaluations of the 2-D CNN.
+    Differentiable, so the 2-D CNN's parameter gradients respond too.  Used by the train-parity tests to measure how far
+    the EXACT (fp64) gradients of a test configuration move under rounding-sized changes (tests/test_models.py)."""
+    state = {"k": 0}
+
+    def hook(t):
+        g = torch.Generator().manual_seed(1000 * seed + state["k"])
+        state["k"] += 1
+        return t * (1 + eps * torch.randn(t.shape, generator=g, dtype=torch.float64).to(t.dtype))
+    return hook
+
+
+def gwcnet_forward(sd, left, right, maxdisp, use_concat_volume, training=False, return_ctx=False, feature_hook=None):
+    """GwcNet/gwcnet.py:171-224.  `feature_hook` (tests): applied to every 1/4-resolution feature map (see feature_noise)."""
     cx = Ctx(sd, training)
     gl, cl = features_gwc(cx, left, use_concat_volume)
     gr, cr = features_gwc(cx, right, use_concat_volume)
+    if feature_hook is not None:
+        gl, gr = feature_hook(gl), feature_hook(gr)
+        if cl is not None:
+            cl, cr = feature_hook(cl), feature_hook(cr)
     out = gwcnet_aggregate(cx, gl, gr, cl, cr, maxdisp, left.shape[2], left.shape[3])
     return (out, cx) if return_ctx else out
 
@@ -404,31 +422,52 @@ def acv_patch_volume(sd, gwc_volume):
 
 
 def acvnet_forward(sd, left, right, maxdisp, attn_weights_only=False, freeze_attn_weights=False,
-                   training=False, return_ctx=False):
-    """ACVNet/acv.py:162-253."""
+                   training=False, return_ctx=False, feature_hook=None):
+    """ACVNet/acv.py:162-253.  `feature_hook` (tests): applied to both gwc feature maps (see feature_noise)."""
     cx = Ctx(sd, training)
     H, W = left.shape[2], left.shape[3]
-
-    def att_branch():
+    if freeze_attn_weights:       # acv.py:164-176: the feature CNN belongs to the frozen attention branch
+        with torch.no_grad():
+            gl, _ = features_gwc(cx, left, False)
+            gr, _ = features_gwc(cx, right, False)
+    else:
         gl, _ = features_gwc(cx, left, False)
         gr, _ = features_gwc(cx, right, False)
+    if feature_hook is not None:
+        gl, gr = feature_hook(gl), feature_hook(gr)
+    out = acvnet_aggregate(cx, gl, gr, maxdisp, H, W, attn_weights_only, freeze_attn_weights)
+    return (out, cx) if return_ctx else out
+
+
+def acv_concat_features(cx, g):
+    """ACVNet/acv.py:104-107,192-194: `concatconv` on the 320-channel gwc feature."""
+    c = F.relu(convbn_2d(cx, g, "concatconv.0", 1, 1, 1))
+    return F.conv2d(c, _w2d(cx.sd["concatconv.2.weight"]))
+
+
+def acvnet_aggregate(cx, gl, gr, maxdisp, H, W, attn_weights_only=False, freeze_attn_weights=False, cl=None, cr=None):
+    """ACVNet/acv.py:166-253 behind the feature extractor: everything from the 1/4-resolution gwc features on.  `cl` / `cr`
+    (optional) replace the `concatconv` outputs -- the cut used by the isolation tests, which hand BOTH implementations the
+    same 2-D features."""
+    sd, training = cx.sd, cx.training
+
+    def att_branch():
         gwc = build_gwc_volume(gl, gr, maxdisp // 4, 40)
         pv = acv_patch_volume(sd, gwc)
         ca = dres1(cx, pv, "dres1_att_")
         ca = hourglass_gwc(cx, ca, "dres2_att_", attention=attention_block)
-        return gl, gr, classif(cx, ca, "classif_att_")
+        return classif(cx, ca, "classif_att_")
 
     if freeze_attn_weights:
         with torch.no_grad():
-            gl, gr, att = att_branch()
+            att = att_branch()
     else:
-        gl, gr, att = att_branch()
+        att = att_branch()
 
     if not attn_weights_only:
-        def concatconv(g):
-            c = F.relu(convbn_2d(cx, g, "concatconv.0", 1, 1, 1))
-            return F.conv2d(c, _w2d(sd["concatconv.2.weight"]))
-        cvol = build_concat_volume(concatconv(gl), concatconv(gr), maxdisp // 4, mask_left=False)
+        if cl is None:
+            cl, cr = acv_concat_features(cx, gl), acv_concat_features(cx, gr)
+        cvol = build_concat_volume(cl, cr, maxdisp // 4, mask_left=False)
         ac = F.softmax(att, dim=2) * cvol
         cost0 = dres0(cx, ac)
         cost0 = dres1(cx, cost0) + cost0
@@ -442,12 +481,10 @@ def acvnet_forward(sd, left, right, maxdisp, attn_weights_only=False, freeze_att
         if not attn_weights_only:
             preds += [regression_head(classif(cx, o, f"classif{i}"), maxdisp, H, W)
                       for i, o in enumerate((cost0, out1, out2))]
-        return (preds, cx) if return_ctx else preds
+        return preds
     if attn_weights_only:
-        pred = regression_head(att, maxdisp, H, W)
-    else:
-        pred = regression_head(classif(cx, out2, "classif2"), maxdisp, H, W)
-    return (pred, cx) if return_ctx else pred
+        return regression_head(att, maxdisp, H, W)
+    return regression_head(classif(cx, out2, "classif2"), maxdisp, H, W)
 
 
 # ----------------------------------------------------------------------------- loss used by bench/tests

@@ -246,6 +246,8 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     defer = (residual is None and want and relu in (0, 1, False, True) and not _is_transposed(conv) and _conv_cfg(conv) == (3, 1)
              and conv.weight.shape[0] % 32 == 0 and conv.weight.shape[1] % 32 == 0 and not st1.get("sync")
              and os.environ.get("STX_BN_BWD_IN_WGRAD", "1") != "0")
+    if defer:
+        ops.bn_defer_reset_if_stale()
     return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None, 1, defer)
 
 

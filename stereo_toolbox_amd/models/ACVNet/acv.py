@@ -93,9 +93,7 @@ class ACVNet(nn.Module):
             self._dil[key] = (one, two)
         return self._dil[key]
 
-    def _attention_branch(self, left, right):
-        fl, fr = run_pair(self.feature_extraction, left, right, self.training)
-        gl, gr = fl["gwc_feature"], fr["gwc_feature"]
+    def _attention_branch(self, gl, gr):
         gwc = ops.cost_volume(gl, gr, None, None, self.maxdisp // 4, self.num_groups)      # [B,D,H,W,40]
         d1, d2 = self._dilations(gwc.device)
         v = ops.dwconv_hw(gwc, self.patch.weight.reshape(40, 9), d1)
@@ -105,23 +103,36 @@ class ACVNet(nn.Module):
         t = convbn_block(pv, self.dres1_att_[0], relu=True)
         ca = convbn_block(t, self.dres1_att_[2], relu=False)
         ca = self.dres2_att_(ca)
-        att = run_classifier(self.classif_att_, ca)       # [B, D', H', W']
-        return gl, gr, att
+        return run_classifier(self.classif_att_, ca)      # [B, D', H', W']
 
     def forward(self, left, right):
         with deferred_bn_counters():
-            return self._forward(left, right)
+            H, W = left.shape[2], left.shape[3]
+            if self.freeze_attn_weights:                  # acv.py:164-176: the extractor belongs to the frozen branch
+                with torch.no_grad():
+                    fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+            else:
+                fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+            return self._aggregate(fl["gwc_feature"], fr["gwc_feature"], H, W)
 
-    def _forward(self, left, right):
-        H, W = left.shape[2], left.shape[3]
+    def aggregate(self, gl, gr, H, W, concat_left=None, concat_right=None):
+        """Everything behind the feature extractor (reference acv.py:166-253) from the two 320-channel 1/4-resolution
+        feature maps; `concat_left` / `concat_right` (optional) replace the `concatconv` outputs.  The cut the parity
+        isolation tests use (the stock 2-D CNN on one side, the hand-written path on the other), like
+        GwcNet.aggregate / PSMNet.aggregate."""
+        with deferred_bn_counters():
+            return self._aggregate(gl, gr, H, W, concat_left, concat_right)
+
+    def _aggregate(self, gl, gr, H, W, cl=None, cr=None):
         if self.freeze_attn_weights:
             with torch.no_grad():
-                gl, gr, att = self._attention_branch(left, right)
+                att = self._attention_branch(gl, gr)
         else:
-            gl, gr, att = self._attention_branch(left, right)
+            att = self._attention_branch(gl, gr)
 
         if not self.attn_weights_only:
-            cl, cr = run_head2d(self.concatconv, gl), run_head2d(self.concatconv, gr)
+            if cl is None:
+                cl, cr = run_head2d(self.concatconv, gl), run_head2d(self.concatconv, gr)
             if torch.is_grad_enabled() and att.requires_grad:
                 prob = torch.softmax(att, dim=1)          # softmax over D' (acv.py:196), tiny tensor
             else:

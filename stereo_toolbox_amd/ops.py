@@ -293,6 +293,15 @@ def _defer_pending_bn(g, pend):
         torch.autograd.Variable._execution_engine.queue_callback(_bn_defer_check)
 
 
+def bn_defer_reset_if_stale():
+    """Called from the FORWARD side of a deferring block (aggregation.conv_block): a backward pass that died with an exception
+    after a deferral (out of memory, a user hook) never ran its end-of-pass callback and left the counters armed -- the
+    safety net would stay off for the rest of the process.  Outside a backward pass nothing can be legitimately
+    outstanding, so the state is reset."""
+    if _BN_DEFER["armed"] and torch._C._current_graph_task_id() == -1:
+        _BN_DEFER["outstanding"], _BN_DEFER["armed"] = 0, False
+
+
 def _take_pending_bn(g):
     """The deferred-BatchNorm record BnActFn.backward attached to gradient tensor `g`, if any (it travels ON the tensor object:
     no global table to leak when a backward pass is interrupted, nothing shared between threads)."""
@@ -845,16 +854,25 @@ class BnActFn(torch.autograd.Function):
         _call("stx_bn_bwd_reduce2", _p(gy), _p(y), _p(z1), _p(m1), _p(i1), _p(z2) if ctx.two else None,
               _p(m2) if ctx.two else None, _p(i2) if ctx.two else None, _p(sc1), _p(sh1), _p(sc2), _p(sh2), _p(part),
               _p(sums_all), nvox, C, int(ctx.relu), G)
+        if not ctx.needs_input_grad[0] and not ctx.two and not ctx.has_res:
+            # nobody differentiates z1 (frozen convolution weight AND an input without gradient, e.g. a BatchNorm-only
+            # fine-tune behind a frozen backbone): only the gamma / beta gradients are wanted -- no apply pass, and in
+            # particular no deferred record that no convolution backward would ever consume
+            tot = sums_all[G] if G > 1 else sums_all[0]
+            return (None, tot[1], tot[0], None, None, None, None, None, None, None, None, None)
         if (ctx.defer and not ctx.two and not ctx.has_res and ctx.relu in (0, 1) and ctx.train1 and not ctx.sync and G == 1
                 and (not ctx.relu or ctx.remask)):
+            # the record travels on a FRESH alias of the gradient: only the node that receives this very return value (z1's
+            # producer) can see it -- `gy` itself may also be delivered to other nodes by an add's fan-out
+            alias = gy.view_as(gy)
             pend = _PendingBn()
-            pend.g, pend.z, pend.scale, pend.shift, pend.mean, pend.invstd = gy, z1, sc1, sh1, m1, i1
+            pend.g, pend.z, pend.scale, pend.shift, pend.mean, pend.invstd = alias, z1, sc1, sh1, m1, i1
             pend.gamma, pend.sums, pend.inv_n, pend.act = gamma1, sums, 1.0 / nvox, int(ctx.relu)
             if pend.scale is None:                     # (no activation: the mask operands were not saved; any finite pair does)
                 pend.scale = pend.shift = m1
-            _defer_pending_bn(gy, pend)
+            _defer_pending_bn(alias, pend)
             tot = sums_all[0]
-            return (gy, tot[1], tot[0], None, None, None, None, None, None, None, None, None)
+            return (alias, tot[1], tot[0], None, None, None, None, None, None, None, None, None)
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if ctx.two else None
         gres = torch.empty_like(z1) if (ctx.has_res and ctx.relu) else None

@@ -74,7 +74,9 @@ PRED_FACTOR = 1.5     # full-size train steps (achieved 0.5-0.7 x, profiles/r03_
 PRED_FACTOR_SMALL = 2.0   # 64x128 / B=2 shapes: a handful of voxels per channel at the 1/16 level (achieved 1.50 x on the GPU)
 
 
-GRAD_FACTOR_SMALL_GPU = 8.0   # the 64x128 / B=2 test shapes on the GPU: the 1/16-level layers normalise over a few hundred voxels.
+GRAD_FACTOR_SMALL_GPU = 6.0   # (round 5: back from 8 to round 3's 6; what a flat factor cannot bound is bounded by the MEASURED sensitivity
+                              # of the exact gradients instead -- _sensitivity below.)
+                              # the 64x128 / B=2 test shapes on the GPU: the 1/16-level layers normalise over a few hundred voxels.
                               # Round 4 isolated the ratio (test_gwcnet_gc_train_grads_hand_written_path_isolated): the hand-written
                               # path ALONE, on oracle features, is a deterministic 4.2e-3 of the tensor's max from fp64 (emulator:
                               # 4.7e-3) -- fp32 summation order of the weight-gradient chains, amplified by the tiny-batch BatchNorms;
@@ -82,7 +84,37 @@ GRAD_FACTOR_SMALL_GPU = 8.0   # the 64x128 / B=2 test shapes on the GPU: the 1/1
                               # rounds 3-4 (2-D CNN weights the worst tensors).  The benchmarked shapes hold GRAD_FACTOR (1.0-1.8 x)
 
 
-def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=None, factor=None):
+ENV_EPS = 3e-6       # relative size of the feature perturbation behind the sensitivity envelope: what two fp32 evaluations of the
+                     # 2-D CNN differ by (MIOpen vs oneDNN features: 1.0-1.8e-6 rms, 3e-6 of the max -- profiles/
+                     # r03_parity_isolation_callE.jsonl), i.e. a few fp32 ulps
+ENV_DRAWS = 2
+ENV_FACTOR = 3.0     # a gradient tensor may be this many times the largest response to one such perturbation away from fp64
+ENV_CAP = 0.5        # ... but never more than half the tensor's max: wrong wiring / signs / missing terms show as >= 100 %
+
+
+def _sensitivity(run64_grads, base64):
+    """Sensitivity envelope of a train-step test configuration (round 5, profiles/r05_toy_shape_grad_sensitivity.txt).
+    `run64_grads(hook)` evaluates the ORACLE in fp64 with `hook` applied to the 1/4-resolution features and returns
+    {name: gradient}; the envelope of a tensor is the largest max-abs change of its exact gradient over ENV_DRAWS draws of
+    a relative feature perturbation of ENV_EPS (O.feature_noise).  Why: at the 64x128 / B=2 shapes the 1/16-level
+    BatchNorms see 256 voxels per channel and the exact gradients of these random-weight networks respond to rounding-
+    sized input changes with a gain of ~1e4, plus jumps where a pre-activation sits within rounding of 0 -- in exact
+    arithmetic a 1e-6 perturbation moves `dres2.conv6.0.weight` of ACVNet by 5.8 % of its max and a 1e-5 one moves
+    `dres2.conv4.0.0.weight` by 20 % (the tensor that failed the driver's round-4 run at 18 %); the host emulator, a
+    bit-exact model of the kernels, lands on the same 5.8 % from its fp32 summation order alone.  A flat factor on the
+    fp32 oracle's own distance from fp64 cannot bound that; the measured response of the exact gradient can."""
+    env = {}
+    for k in range(ENV_DRAWS):
+        got = run64_grads(O.feature_noise(ENV_EPS, k + 1))
+        for name, g in got.items():
+            if g is None or base64.get(name) is None:
+                continue
+            d = (g - base64[name]).abs().max().item()
+            env[name] = max(env.get(name, 0.0), d)
+    return env
+
+
+def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=None, factor=None, sens=None):
     """Gradient parity.  With an fp64 evaluation of the oracle available the tolerance is calibrated: the product may be
     at most GRAD_FACTOR x as far from fp64 as the fp32 oracle itself is, with `rtol` of the tensor's max as the floor.
     (Train-mode BN backward subtracts batch means -- catastrophic cancellation for small-magnitude gradients -- so the
@@ -95,7 +127,7 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
         rtol = 1e-2 if next(model.parameters()).is_cuda else 2e-3
     worst = 0.0
     worst_ratio, worst_key = 0.0, None
-    n = 0
+    n = n_env = 0
     for k, p in model.named_parameters():
         if skip_prefix and k.startswith(skip_prefix):
             continue
@@ -109,6 +141,10 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
             e_prod = (p.grad.cpu().double() - r64).abs().max().item()
             e_orc = (r.double() - r64).abs().max().item()
             tol = max(rtol * scale, factor * e_orc) + 1e-6
+            if sens is not None:
+                if e_prod > tol:
+                    n_env += 1                 # tensors that needed the envelope branch
+                tol = max(tol, min(ENV_FACTOR * sens.get(k, 0.0), ENV_CAP * scale))
             ratio = e_prod / max(e_orc, rtol * scale / factor, 1e-30)
             if ratio > worst_ratio:
                 worst_ratio, worst_key = ratio, k
@@ -119,7 +155,11 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
         assert e_prod <= tol, f"{k}: grad err {e_prod:.3e} vs scale {scale:.3e} (tol {tol:.3e})"
         n += 1
     if log is not None:
-        log(worst_rel_to_max=worst, worst_ratio_to_oracle_fp32_error=worst_ratio, worst_ratio_tensor=worst_key, tensors=n)
+        extra = {} if sens is None else {"tensors_bound_by_sensitivity_envelope": n_env,
+                                         "largest_envelope_rel_to_max": max(
+                                             (v / (ref_sd[k_].grad.abs().max().item() + 1e-30) for k_, v in sens.items()
+                                              if k_ in ref_sd and ref_sd[k_].grad is not None), default=0.0)}
+        log(worst_rel_to_max=worst, worst_ratio_to_oracle_fp32_error=worst_ratio, worst_ratio_tensor=worst_key, tensors=n, **extra)
     return n, worst
 
 
@@ -162,8 +202,16 @@ def test_gwcnet_gc_train_parity(env, parity_log):
     O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
     _check_preds(preds, rp, rp64)
     assert abs(loss.item() - rl.item()) < 1e-4 * max(1.0, abs(rl.item()))
+    sens = None
+    if env.name == "hip":
+        def run64(hook):
+            s_ = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            O.smooth_l1_multi(O.gwcnet_forward(s_, left.double(), right.double(), D, True, training=True, feature_hook=hook),
+                              gt.double(), D, LOSS_W).backward()
+            return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
+        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
     n, worst = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"gwcnet_gc_train_grads[{env.name}]", **f),
-                            factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None)
+                            factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens)
     assert n > 250
     msd = m.state_dict()
     for k, v in cx.new_stats.items():   # BN running statistics updated like torch's
@@ -222,9 +270,27 @@ def test_gwcnet_gc_train_grads_hand_written_path_isolated(parity_log):
     dfe = [t.cuda().requires_grad_() for t in feats]
     preds = m.aggregate({"gwc_feature": dfe[0], "concat_feature": dfe[2]}, {"gwc_feature": dfe[1], "concat_feature": dfe[3]}, H, W)
     masked_smooth_l1_multi(preds, gt.cuda(), D, LOSS_W).backward()
-    worst, worst_key, n = 0.0, None, 0
+    def run64(hook):
+        s_ = {k: (v.detach().clone().double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
+              for k, v in sd.items()}
+        f_ = [t.detach().clone().double().requires_grad_() for t in feats]
+        h_ = [hook(t) for t in f_]
+        O.smooth_l1_multi(O.gwcnet_aggregate(O.Ctx(s_, True), h_[0], h_[1], h_[2], h_[3], D, H, W), gt.double(), D, LOSS_W).backward()
+        out = {k: v.grad for k, v in s_.items() if v.is_floating_point()}
+        out.update({f"d_feature[{i}]": f_[i].grad for i in range(4)})
+        return out
+    base = {k: v.grad for k, v in r64.items() if v.is_floating_point()}
+    base.update({f"d_feature[{i}]": f64[i].grad for i in range(4)})
+    sens = _sensitivity(run64, base)
     items = [(k, p.grad, r32[k].grad, r64[k].grad) for k, p in m.named_parameters() if not k.startswith("feature_extraction.")]
     items += [(f"d_feature[{i}]", dfe[i].grad, f32[i].grad, f64[i].grad) for i in range(4)]
+    _check_isolated(items, sens, "gwcnet_gc_train_grads_hand_written_path[hip]", parity_log, 100)
+
+
+def _check_isolated(items, sens, name, parity_log, n_min):
+    """Gradients of the hand-written path alone (same features on both sides): every tensor within
+    max(RTOL_HAND_WRITTEN_GPU x its max, GRAD_FACTOR x the fp32 oracle's own distance from fp64, the sensitivity envelope)."""
+    worst, worst_key, n, n_env = 0.0, None, 0, 0
     bad = []
     for k, g, g32, g64 in items:
         assert g is not None and g32 is not None, k
@@ -233,13 +299,75 @@ def test_gwcnet_gc_train_grads_hand_written_path_isolated(parity_log):
         e_orc = (g32.double() - g64).abs().max().item()
         if e_prod / (scale + 1e-30) > worst:
             worst, worst_key = e_prod / (scale + 1e-30), k
-        if e_prod > max(RTOL_HAND_WRITTEN_GPU * scale, GRAD_FACTOR * e_orc) + 1e-9:
-            bad.append((k, e_prod / (scale + 1e-30), e_orc / (scale + 1e-30)))
+        tol = max(RTOL_HAND_WRITTEN_GPU * scale, GRAD_FACTOR * e_orc) + 1e-9
+        if e_prod > tol:
+            n_env += 1
+        tol = max(tol, min(ENV_FACTOR * sens.get(k, 0.0), ENV_CAP * scale))
+        if e_prod > tol:
+            bad.append((k, e_prod / (scale + 1e-30), e_orc / (scale + 1e-30), sens.get(k, 0.0) / (scale + 1e-30)))
         n += 1
-    parity_log("gwcnet_gc_train_grads_hand_written_path[hip]", worst_rel_to_max=worst, worst_tensor=worst_key, tensors=n,
-               rtol=RTOL_HAND_WRITTEN_GPU)
-    assert n >= 100          # every parameter behind the 2-D CNN + the four feature-map gradients
+    parity_log(name, worst_rel_to_max=worst, worst_tensor=worst_key, tensors=n, rtol=RTOL_HAND_WRITTEN_GPU,
+               tensors_bound_by_sensitivity_envelope=n_env)
+    assert n >= n_min
     assert not bad, bad[:5]
+
+
+def test_acvnet_train_grads_hand_written_path_isolated(env, parity_log):
+    """The ACVNet twin of the test above: `ACVNet.aggregate()` -- gwc volume, patch convolutions, attention
+    branch, attention-weighted concat volume, two hourglasses with the windowed attention block, four heads, forward AND
+    backward -- on the ORACLE's 320-channel features against the oracle's 3-D path on the same features: every parameter
+    gradient behind the feature extractor (incl. `concatconv`, a stock 2-D head, and the stock-torch attention blocks) and the
+    gradients handed back to the two feature maps.  Run TWICE: the two runs must agree bit for bit (no atomics / no
+    algorithm choice anywhere behind the feature maps -- rocBLAS's batched GEMMs of the attention block included)."""
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    from stereo_toolbox_amd.models import ACVNet
+    H, W, D, B = (16, 64, 64, 1) if env.name == "emu" else (64, 128, 64, 2)
+    dev = env.device
+    m, sd = _filled(ACVNet, D)
+    m = m.to(dev).train()
+    left, right = synthetic_tensor((B, 3, H, W), 1), synthetic_tensor((B, 3, H, W), 2)
+    gt = synthetic_tensor((B, H, W), 3, lo=0.0, hi=float(D - 2))
+    with torch.no_grad():
+        cxf = O.Ctx({k: v.clone() for k, v in sd.items()}, True)
+        feats = [O.features_gwc(cxf, left, False)[0], O.features_gwc(cxf, right, False)[0]]
+
+    def run_oracle(dtype, hook=None):
+        s_ = {k: (v.detach().clone().to(dtype).requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
+              for k, v in sd.items()}
+        f_ = [t.detach().clone().to(dtype).requires_grad_() for t in feats]
+        h_ = f_ if hook is None else [hook(t) for t in f_]
+        preds = O.acvnet_aggregate(O.Ctx(s_, True), h_[0], h_[1], D, H, W)
+        O.smooth_l1_multi(preds, gt.to(dtype), D, LOSS_W).backward()
+        return s_, f_
+    r32, f32 = run_oracle(torch.float32)
+    r64, f64 = run_oracle(torch.float64)
+
+    def run_product():
+        m.zero_grad(set_to_none=True)
+        dfe = [t.clone().to(dev).requires_grad_() for t in feats]
+        with env.ctx():
+            preds = m.aggregate(dfe[0], dfe[1], H, W)
+            masked_smooth_l1_multi(preds, gt.to(dev), D, LOSS_W).backward()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, [t.grad for t in dfe]
+    g1, d1 = run_product()
+    g2, d2 = run_product()
+    differ = [k for k in g1 if not torch.equal(g1[k], g2[k])] + [f"d_feature[{i}]" for i in range(2) if not torch.equal(d1[i], d2[i])]
+    parity_log(f"acvnet_hand_written_path_run_to_run[{env.name}]", tensors=len(g1) + 2, not_bitwise_equal=len(differ), first=differ[:3])
+    assert not differ, differ[:5]
+
+    def run64(hook):
+        s_, f_ = run_oracle(torch.float64, hook)
+        out = {k: v.grad for k, v in s_.items() if v.is_floating_point()}
+        out.update({f"d_feature[{i}]": f_[i].grad for i in range(2)})
+        return out
+    base = {k: v.grad for k, v in r64.items() if v.is_floating_point()}
+    base.update({f"d_feature[{i}]": f64[i].grad for i in range(2)})
+    sens = _sensitivity(run64, base)
+    items = [(k, g1[k], r32[k].grad, r64[k].grad) for k, _ in m.named_parameters() if not k.startswith("feature_extraction.")]
+    items += [(f"d_feature[{i}]", d1[i], f32[i].grad, f64[i].grad) for i in range(2)]
+    _check_isolated(items, sens, f"acvnet_train_grads_hand_written_path[{env.name}]", parity_log, 128)
 
 
 def _acv_shape(env):
@@ -285,8 +413,16 @@ def test_acvnet_train_parity(env, parity_log):
     O.smooth_l1_multi(rp64, gt.double(), D, LOSS_W).backward()
     assert len(preds) == 4          # [pred_attention, pred0, pred1, pred2] (acv.py:235)
     _check_preds(preds, rp, rp64)
+    sens = None
+    if env.name == "hip":
+        def run64(hook):
+            s_ = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+            O.smooth_l1_multi(O.acvnet_forward(s_, left.double(), right.double(), D, training=True, feature_hook=hook),
+                              gt.double(), D, LOSS_W).backward()
+            return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
+        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
     n, _ = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"acvnet_train_grads[{env.name}]", **f),
-                        factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None)
+                        factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens)
     assert n > 280
 
 
@@ -443,10 +579,34 @@ def test_bn_backward_in_weight_gradient_matches_separate_pass(env, monkeypatch):
     assert calls["n"] == 1                                       # frozen weights: the stand-alone pass
     for a, b in zip(frozen_fused, frozen_plain):
         assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-7
+    # BatchNorm-only fine-tune: frozen convolution weight AND an input without gradient -- nobody differentiates z, so there
+    # is no record to consume; gamma / beta gradients equal the stand-alone pass's (this used to raise)
+    def run_bn_only(flag):
+        monkeypatch.setenv("STX_BN_BWD_IN_WGRAD", flag)
+        torch.manual_seed(10)
+        blk = convbn_3d(32, 32, 3, 1, 1)
+        with env.ctx():
+            blk = blk.to(env.device).train()
+            blk[0].weight.requires_grad_(False)
+            convbn_block(x0.to(env.device), blk, relu=True).backward(g0.to(env.device))
+            assert blk[0].weight.grad is None
+            return [blk[1].weight.grad.cpu(), blk[1].bias.grad.cpu()]
+    for a, b in zip(run_bn_only("1"), run_bn_only("0")):
+        assert torch.equal(a, b)
+    for a, b in zip(run_bn_only("1"), frozen_plain[1:3]):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item() + 1e-7
+    assert ops._BN_DEFER == {"outstanding": 0, "armed": False}
+    orig_take = ops._take_pending_bn
     monkeypatch.setattr(ops, "_take_pending_bn", lambda g: None)      # a backward node that misses the record
     with pytest.raises(Exception, match="deferred BatchNorm-backward"):
         run("1")
-    ops._BN_DEFER["outstanding"], ops._BN_DEFER["armed"] = 0, False
+    monkeypatch.setattr(ops, "_take_pending_bn", orig_take)
+    # a backward pass that dies after a deferral leaves the counters armed; the next forward of a deferring block resets them
+    ops._BN_DEFER["outstanding"], ops._BN_DEFER["armed"] = 3, True
+    again = run("1")
+    assert ops._BN_DEFER == {"outstanding": 0, "armed": False}
+    for a, b in zip(again, fused):
+        assert torch.equal(a, b)
 
 
 def test_functional_api(env):

@@ -276,6 +276,32 @@ int stx_sampled_volume_bwd(const float* gvol, const float* Lg, const float* Rg, 
                            const float* samples, float* gLg, float* gRg, float* gLc, float* gRc, int B, int H, int W,
                            int S, int CTp, void* stream);
 
+/* ---- refine2d.hip: 2-D helpers of the PCWNet / CFNet family -------------------------------------
+ * warp(x, disp) (models/PCWNet/submodule.py:137-176): x [B][C][H][W] (right-view features), disp [B][1][H][W] ->
+ * out [B][C][H][W] = grid_sample(x, grid(w - disp, h)) (bilinear, zeros outside, the reference's (W-1)/(H-1) grid under
+ * align_corners=False) * (in-image weight sum >= 0.999).  Backward: gx (cleared inside, float atomics like torch's own
+ * grid-sampler backward; may be NULL) and gdisp [B][1][H][W] (may be NULL); the validity mask is a constant. */
+int stx_warp_fwd(const float* x, const float* disp, float* out, int B, int C, int H, int W, void* stream);
+int stx_warp_bwd(const float* gout, const float* x, const float* disp, float* gx, float* gdisp, int B, int C, int H, int W,
+                 void* stream);
+/* build_corrleation_volume(ref, tgt, maxdisp, groups) (models/PCWNet/submodule.py:121-135, dup CFNet/submodule.py:181-195):
+ * ref, tgt [B][C][H][W] -> vol [B][groups][2*maxdisp+1][H][W]; slice maxdisp+i, i >= 0: mean over the group's channels of
+ * ref[w] * tgt[w-i] at w >= i, 0 elsewhere; slice maxdisp-n, n >= 1 (literal semantics of the reference's `[..., :-i]` with
+ * negative i): the FIRST n columns of ref against the LAST n columns of tgt, 0 elsewhere.  Every element of vol is written.
+ * maxdisp <= min(48, W).  Backward: gref / gtgt [B][C][H][W] fully written (either may be NULL), deterministic. */
+int stx_corr_volume_fwd(const float* ref, const float* tgt, float* vol, int B, int C, int H, int W, int maxdisp, int groups,
+                        void* stream);
+int stx_corr_volume_bwd(const float* gvol, const float* ref, const float* tgt, float* gref, float* gtgt, int B, int C, int H,
+                        int W, int maxdisp, int groups, void* stream);
+/* disparity_variance(x, maxdisp, disparity) (models/CFNet/submodule.py:128-134; samples == NULL): out[b][i] =
+ * sum_d x[b][d][i] * (d - disp[b][i])^2, and disparity_variance_confidence(x, samples, disparity) (:136-140; samples
+ * [B][D][HW]): sum_d x * (disp - samples)^2.  x [B][D][HW], disp / out [B][HW].  Backward: gx, gdisp, gsamples (each may
+ * be NULL). */
+int stx_disparity_variance_fwd(const float* x, const float* disp, const float* samples, float* out, int B, int D, int HW,
+                               void* stream);
+int stx_disparity_variance_bwd(const float* g, const float* x, const float* disp, const float* samples, float* gx, float* gdisp,
+                               float* gsamples, int B, int D, int HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

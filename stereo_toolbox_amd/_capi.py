@@ -76,6 +76,13 @@ SIGNATURES = {
     "stx_ac_volume_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     # preprocess.hip
     "stx_pad_normalize_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    # refine2d.hip
+    "stx_warp_fwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "stx_warp_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "stx_corr_volume_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "stx_corr_volume_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "stx_disparity_variance_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "stx_disparity_variance_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "stx_sampled_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_sampled_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     # bn.hip

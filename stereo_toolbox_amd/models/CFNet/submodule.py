@@ -2,7 +2,7 @@
 
 The dense volume builders, the 3-D convolutions, Mish on volumes and the regressions run on the HIP kernels (the
 multi-scale volumes of CFNet are GwcNet volumes at 1/8, 1/16 and 1/32 resolution).  The cascade's per-pixel search
-range machinery (variance, uniform sampler) acts on small 2-D maps and stays stock torch; the sampled cost volumes of
+range machinery: the variance is a HIP kernel (csrc/refine2d.hip), the uniform sampler a handful of 2-D torch ops; the sampled cost volumes of
 the two cascade stages (`SpatialTransformer` gather + `groupwise_correlation_4D` + `cat`) are one HIP kernel
 (`ops.sampled_volume`, csrc/sampled_volume.hip, forward + backward).
 """
@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import ops
 from ..PCWNet.submodule import (BasicBlock, FMish, Mish, build_concat_volume, build_gwc_volume, convbn,  # noqa: F401
                                 convbn_3d, disparity_regression, groupwise_correlation, make_layer)
 
@@ -50,16 +51,16 @@ class pyramidPooling(nn.Module):
 
 
 def disparity_variance(x, maxdisp, disparity):
-    """reference submodule.py:128-134: sum_d p_d (d - disparity)^2 -> [B,1,H,W]."""
+    """reference submodule.py:128-134: sum_d p_d (d - disparity)^2 -> [B,1,H,W] (csrc/refine2d.hip, one pass)."""
     assert len(x.shape) == 4
-    d = torch.arange(0, maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
-    return torch.sum(x * (d - disparity) ** 2, 1, keepdim=True)
+    assert x.shape[1] == maxdisp, "the reference broadcasts arange(maxdisp) against x: the D axes must agree"
+    return ops.disparity_variance(x, disparity)
 
 
 def disparity_variance_confidence(x, disparity_samples, disparity):
-    """reference submodule.py:136-140."""
+    """reference submodule.py:136-140: sum_d p_d (disparity - sample_d)^2 -> [B,1,H,W]."""
     assert len(x.shape) == 4
-    return torch.sum(x * (disparity - disparity_samples) ** 2, 1, keepdim=True)
+    return ops.disparity_variance(x, disparity, disparity_samples)
 
 
 def groupwise_correlation_4D(fea1, fea2, num_groups):

@@ -2,7 +2,7 @@
 
 The volume builders and the regression run on the HIP kernels (same entry points as GwcNet: the multi-scale volumes of
 PCWNet are the GwcNet volumes at 1/4, 1/8, 1/16 and 1/32 resolution); Mish is `ops.mish`; the 2-D refinement helpers
-(`warp`, the +-24-disparity `build_corrleation_volume`) act on small full-resolution 2-D maps and stay stock torch ops.
+(`warp`, the +-24-disparity `build_corrleation_volume`) are HIP kernels too (csrc/refine2d.hip, round 5).
 """
 import torch
 import torch.nn as nn
@@ -62,37 +62,16 @@ def make_layer(inplanes, planes, blocks, stride, pad, dilation):
 
 def build_corrleation_volume(refimg_fea, targetimg_fea, maxdisp, num_groups):
     """reference submodule.py:121-135 (sic): group-wise correlation for disparities -maxdisp..+maxdisp
-    -> [B, G, 2*maxdisp+1, H, W]; entry i+maxdisp pairs ref[w] with target[w - i] for i >= 0."""
-    B, C, H, W = refimg_fea.shape
-    assert C % num_groups == 0
-    cpg = C // num_groups
-    vol = refimg_fea.new_zeros(B, num_groups, 2 * maxdisp + 1, H, W)
-    for i in range(-maxdisp, maxdisp + 1):
-        if i > 0:
-            prod = refimg_fea[..., i:] * targetimg_fea[..., :-i]
-            vol[:, :, i + maxdisp, :, i:] = prod.view(B, num_groups, cpg, H, W - i).mean(2)
-        elif i < 0:
-            # literal reference semantics (`[:, :, :, :-i]` with negative i is the FIRST |i| columns): the first |i|
-            # reference columns meet the LAST |i| target columns; all other columns of these slices stay zero
-            n = -i
-            prod = refimg_fea[..., :n] * targetimg_fea[..., W - n:]
-            vol[:, :, i + maxdisp, :, :n] = prod.view(B, num_groups, cpg, H, n).mean(2)
-        else:
-            vol[:, :, maxdisp] = (refimg_fea * targetimg_fea).view(B, num_groups, cpg, H, W).mean(2)
-    return vol
+    -> [B, G, 2*maxdisp+1, H, W]; entry i+maxdisp pairs ref[w] with target[w - i] for i >= 0; for i < 0 the literal reference
+    semantics (`[:, :, :, :-i]` with negative i is the FIRST |i| columns): the first |i| reference columns meet the LAST |i|
+    target columns, all other columns of those slices stay zero.  One HIP kernel pair (csrc/refine2d.hip), differentiable."""
+    assert refimg_fea.shape[1] % num_groups == 0          # reference submodule.py:102 (groupwise_correlation)
+    return ops.corr_volume(refimg_fea, targetimg_fea, maxdisp, num_groups)
 
 
 def warp(x, disp):
     """reference submodule.py:137-176: sample x (right view features) at column w - disp (bilinear, zeros outside,
     grid_sample's default align_corners=False on a grid normalised with W-1 / H-1 as the reference does), then zero
-    every pixel whose sampling footprint left the image (validity mask < 0.999)."""
-    B, C, H, W = x.shape
-    xx = torch.arange(W, device=x.device, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
-    yy = torch.arange(H, device=x.device, dtype=torch.float32).view(1, 1, H, 1).expand(B, 1, H, W)
-    gx = 2.0 * (xx - disp) / max(W - 1, 1) - 1.0
-    gy = 2.0 * yy / max(H - 1, 1) - 1.0
-    grid = torch.cat((gx, gy), 1).permute(0, 2, 3, 1)
-    out = F.grid_sample(x, grid, align_corners=False)
-    mask = F.grid_sample(torch.ones_like(x), grid, align_corners=False)
-    mask = (mask >= 0.999).to(x.dtype)
-    return out * mask
+    every pixel whose sampling footprint left the image (validity mask < 0.999).  HIP kernel (csrc/refine2d.hip): the
+    footprint is computed once per pixel for all channels; differentiable in x and disp."""
+    return ops.warp(x, disp)

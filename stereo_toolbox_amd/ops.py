@@ -1039,6 +1039,122 @@ class _NoCtx:
         pass
 
 
+# --------------------------------------------------------------------------------------- PCWNet / CFNet 2-D helpers (row f-1)
+class WarpFn(torch.autograd.Function):
+    """reference PCWNet/submodule.py:137-176 (`warp`): stx_warp_fwd / stx_warp_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, disp):
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        _call("stx_warp_fwd", _p(x), _p(disp), _p(out), B, C, H, W)
+        ctx.save_for_backward(x, disp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, disp = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gd = torch.empty_like(disp) if ctx.needs_input_grad[1] else None
+        _call("stx_warp_bwd", _p(g), _p(x), _p(disp), _p(gx), _p(gd), B, C, H, W)
+        return gx, gd
+
+
+def warp(x, disp):
+    """x [B,C,H,W] sampled at column w - disp[B,1,H,W] (bilinear, the reference's grid), zeroed where the footprint leaves
+    the image.  Differentiable in x and disp like the reference."""
+    x, disp = x.contiguous(), disp.contiguous()
+    _chk(x, "x", 4)
+    _chk(disp, "disp", 4)
+    if disp.shape != (x.shape[0], 1, x.shape[2], x.shape[3]):
+        raise StxError(f"warp: disp {tuple(disp.shape)} does not match x {tuple(x.shape)}")
+    if torch.is_grad_enabled() and (x.requires_grad or disp.requires_grad):
+        return WarpFn.apply(x, disp)
+    return WarpFn.forward(_NoCtx(), x, disp)
+
+
+class CorrVolumeFn(torch.autograd.Function):
+    """reference PCWNet/submodule.py:121-135 (`build_corrleation_volume`): stx_corr_volume_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, ref, tgt, maxdisp, groups):
+        B, C, H, W = ref.shape
+        vol = torch.empty(B, groups, 2 * maxdisp + 1, H, W, dtype=torch.float32, device=ref.device)
+        _call("stx_corr_volume_fwd", _p(ref), _p(tgt), _p(vol), B, C, H, W, maxdisp, groups)
+        ctx.save_for_backward(ref, tgt)
+        ctx.cfg = (maxdisp, groups)
+        return vol
+
+    @staticmethod
+    def backward(ctx, g):
+        ref, tgt = ctx.saved_tensors
+        B, C, H, W = ref.shape
+        g = g.contiguous()
+        gr = torch.empty_like(ref) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(tgt) if ctx.needs_input_grad[1] else None
+        _call("stx_corr_volume_bwd", _p(g), _p(ref), _p(tgt), _p(gr), _p(gt), B, C, H, W, *ctx.cfg)
+        return gr, gt, None, None
+
+
+def corr_volume(ref, tgt, maxdisp, groups):
+    """[B,C,H,W] x 2 -> [B, groups, 2*maxdisp+1, H, W] (see include/stx_hip.h for the slice semantics)."""
+    ref, tgt = ref.contiguous(), tgt.contiguous()
+    _chk(ref, "ref", 4)
+    _chk(tgt, "tgt", 4)
+    if ref.shape != tgt.shape:
+        raise StxError(f"corr_volume: ref {tuple(ref.shape)} vs tgt {tuple(tgt.shape)}")
+    if torch.is_grad_enabled() and (ref.requires_grad or tgt.requires_grad):
+        return CorrVolumeFn.apply(ref, tgt, int(maxdisp), int(groups))
+    return CorrVolumeFn.forward(_NoCtx(), ref, tgt, int(maxdisp), int(groups))
+
+
+class DisparityVarianceFn(torch.autograd.Function):
+    """reference CFNet/submodule.py:128-140 (`disparity_variance`, `disparity_variance_confidence`)."""
+
+    @staticmethod
+    def forward(ctx, x, disp, samples):
+        B, D = x.shape[0], x.shape[1]
+        HW = x.shape[2] * x.shape[3]
+        out = torch.empty(B, 1, x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+        _call("stx_disparity_variance_fwd", _p(x), _p(disp), _p(samples), _p(out), B, D, HW)
+        ctx.save_for_backward(x, disp, samples)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, disp, samples = ctx.saved_tensors
+        B, D = x.shape[0], x.shape[1]
+        HW = x.shape[2] * x.shape[3]
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        gx = torch.empty_like(x) if need[0] else None
+        gd = torch.empty_like(disp) if need[1] else None
+        gs = torch.empty_like(samples) if (samples is not None and need[2]) else None
+        if gx is None and gd is None and gs is None:
+            return None, None, None
+        _call("stx_disparity_variance_bwd", _p(g), _p(x), _p(disp), _p(samples), _p(gx), _p(gd), _p(gs), B, D, HW)
+        return gx, gd, gs
+
+
+def disparity_variance(x, disp, samples=None):
+    """sum_d x_d (d - disp)^2 (samples None) or sum_d x_d (disp - samples_d)^2 -> [B,1,H,W]."""
+    x, disp = x.contiguous(), disp.contiguous()
+    _chk(x, "x", 4)
+    _chk(disp, "disparity", 4)
+    if disp.shape != (x.shape[0], 1, x.shape[2], x.shape[3]):
+        raise StxError(f"disparity_variance: disparity {tuple(disp.shape)} does not match x {tuple(x.shape)}")
+    if samples is not None:
+        samples = samples.contiguous()
+        _chk(samples, "samples", 4)
+        if samples.shape != x.shape:
+            raise StxError(f"disparity_variance: samples {tuple(samples.shape)} vs x {tuple(x.shape)}")
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, disp, samples)):
+        return DisparityVarianceFn.apply(x, disp, samples)
+    return DisparityVarianceFn.forward(_NoCtx(), x, disp, samples)
+
+
 class AcVolumeFn(torch.autograd.Function):
     """ACVNet attention concat volume: softmax(att, dim=2) * concat_volume (acv.py:196), left half
     unmasked (ACVNet/submodule.py:180-191).  prob: [B, D, H, W] softmax probabilities."""

@@ -234,6 +234,12 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetc
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 static inline float __fdividef(float a, float b) { return a / b; }
+// round-to-nearest single operations that must not be contracted into FMAs (the host build compiles with -ffp-contract=off
+// semantics for these through volatile temporaries)
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }   // callers pass wave-uniform values
 
 namespace hipemu {

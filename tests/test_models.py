@@ -315,10 +315,15 @@ def _check_isolated(items, sens, name, parity_log, n_min):
 def test_acvnet_train_grads_hand_written_path_isolated(env, parity_log):
     """The ACVNet twin of the test above: `ACVNet.aggregate()` -- gwc volume, patch convolutions, attention
     branch, attention-weighted concat volume, two hourglasses with the windowed attention block, four heads, forward AND
-    backward -- on the ORACLE's 320-channel features against the oracle's 3-D path on the same features: every parameter
-    gradient behind the feature extractor (incl. `concatconv`, a stock 2-D head, and the stock-torch attention blocks) and the
-    gradients handed back to the two feature maps.  Run TWICE: the two runs must agree bit for bit (no atomics / no
-    algorithm choice anywhere behind the feature maps -- rocBLAS's batched GEMMs of the attention block included)."""
+    backward -- on the ORACLE's 320-channel gwc features and 32-channel `concatconv` outputs, against the oracle's 3-D path on
+    the same features: every parameter gradient behind the two stock 2-D pieces (the stock-torch attention blocks included) and
+    the gradients handed back to the four feature maps.  Run TWICE: the two runs must agree bit for bit.
+    Attribution behind this cut (GPU calls A / B of round 5, profiles/r05_acv_determinism_callB.jsonl): with `concatconv` inside
+    the cut all 128 tensors differed between two runs of the same binary on the same inputs; run alone, the attention block
+    (rocBLAS batched GEMMs, softmax, F.linear), the patch convolutions and the attention-weighted volume are bit-for-bit
+    reproducible and `concatconv` is not -- MIOpen's 3x3 / 1x1 convolutions return a FORWARD output that differs by 3.6e-7
+    relative from call to call; that alone moved `dres2.conv6.0.weight` by 0.7 % of its max between two runs (the sensitivity
+    `_sensitivity` measures, observed on the chip).  With the cut behind `concatconv`, 124 of 124 tensors are bitwise equal."""
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi
     from stereo_toolbox_amd.models import ACVNet
     H, W, D, B = (16, 64, 64, 1) if env.name == "emu" else (64, 128, 64, 2)
@@ -330,44 +335,40 @@ def test_acvnet_train_grads_hand_written_path_isolated(env, parity_log):
     with torch.no_grad():
         cxf = O.Ctx({k: v.clone() for k, v in sd.items()}, True)
         feats = [O.features_gwc(cxf, left, False)[0], O.features_gwc(cxf, right, False)[0]]
+        feats += [O.acv_concat_features(cxf, feats[0]), O.acv_concat_features(cxf, feats[1])]
+    names = [f"d_feature[{i}]" for i in range(4)]
 
     def run_oracle(dtype, hook=None):
         s_ = {k: (v.detach().clone().to(dtype).requires_grad_("running" not in k) if v.is_floating_point() else v.clone())
               for k, v in sd.items()}
         f_ = [t.detach().clone().to(dtype).requires_grad_() for t in feats]
         h_ = f_ if hook is None else [hook(t) for t in f_]
-        preds = O.acvnet_aggregate(O.Ctx(s_, True), h_[0], h_[1], D, H, W)
+        preds = O.acvnet_aggregate(O.Ctx(s_, True), h_[0], h_[1], D, H, W, cl=h_[2], cr=h_[3])
         O.smooth_l1_multi(preds, gt.to(dtype), D, LOSS_W).backward()
-        return s_, f_
-    r32, f32 = run_oracle(torch.float32)
-    r64, f64 = run_oracle(torch.float64)
+        out = {k: v.grad for k, v in s_.items() if v.is_floating_point() and v.grad is not None}
+        out.update({n: f_[i].grad for i, n in enumerate(names)})
+        return out
+    r32, r64 = run_oracle(torch.float32), run_oracle(torch.float64)
 
     def run_product():
         m.zero_grad(set_to_none=True)
         dfe = [t.clone().to(dev).requires_grad_() for t in feats]
         with env.ctx():
-            preds = m.aggregate(dfe[0], dfe[1], H, W)
+            preds = m.aggregate(dfe[0], dfe[1], H, W, concat_left=dfe[2], concat_right=dfe[3])
             masked_smooth_l1_multi(preds, gt.to(dev), D, LOSS_W).backward()
         if dev.type == "cuda":
             torch.cuda.synchronize()
-        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, [t.grad for t in dfe]
-    g1, d1 = run_product()
-    g2, d2 = run_product()
-    differ = [k for k in g1 if not torch.equal(g1[k], g2[k])] + [f"d_feature[{i}]" for i in range(2) if not torch.equal(d1[i], d2[i])]
-    parity_log(f"acvnet_hand_written_path_run_to_run[{env.name}]", tensors=len(g1) + 2, not_bitwise_equal=len(differ), first=differ[:3])
-    assert not differ, differ[:5]
-
-    def run64(hook):
-        s_, f_ = run_oracle(torch.float64, hook)
-        out = {k: v.grad for k, v in s_.items() if v.is_floating_point()}
-        out.update({f"d_feature[{i}]": f_[i].grad for i in range(2)})
+        out = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        out.update({n: dfe[i].grad for i, n in enumerate(names)})
         return out
-    base = {k: v.grad for k, v in r64.items() if v.is_floating_point()}
-    base.update({f"d_feature[{i}]": f64[i].grad for i in range(2)})
-    sens = _sensitivity(run64, base)
-    items = [(k, g1[k], r32[k].grad, r64[k].grad) for k, _ in m.named_parameters() if not k.startswith("feature_extraction.")]
-    items += [(f"d_feature[{i}]", d1[i], f32[i].grad, f64[i].grad) for i in range(2)]
-    _check_isolated(items, sens, f"acvnet_train_grads_hand_written_path[{env.name}]", parity_log, 128)
+    g1, g2 = run_product(), run_product()
+    differ = [k for k in g1 if not torch.equal(g1[k], g2[k])]
+    parity_log(f"acvnet_hand_written_path_run_to_run[{env.name}]", tensors=len(g1), not_bitwise_equal=len(differ), first=differ[:3])
+    assert not differ, differ[:5]
+    assert set(g1) == set(r32), set(g1) ^ set(r32)          # the same tensors receive gradients on both sides
+    sens = _sensitivity(lambda hook: run_oracle(torch.float64, hook), r64)
+    _check_isolated([(k, g1[k], r32[k], r64[k]) for k in g1], sens, f"acvnet_train_grads_hand_written_path[{env.name}]",
+                    parity_log, 126)
 
 
 def _acv_shape(env):

@@ -823,6 +823,17 @@ def _cf_classif(cx, x, p):
     return F.conv3d(mish(convbn_3d(cx, x, p + ".0")), cx.sd[p + ".2.weight"], None, 1, 1).squeeze(1)
 
 
+def cf_disparity_variance(x, maxdisp, disparity):
+    """CFNet/submodule.py:128-134."""
+    d = torch.arange(0, maxdisp, dtype=x.dtype, device=x.device).view(1, maxdisp, 1, 1)
+    return torch.sum(x * (d - disparity) ** 2, 1, keepdim=True)
+
+
+def cf_disparity_variance_confidence(x, disparity_samples, disparity):
+    """CFNet/submodule.py:136-140."""
+    return torch.sum(x * (disparity - disparity_samples) ** 2, 1, keepdim=True)
+
+
 def cf_sampled_volume(left, right, samples, num_groups):
     """CFNet/submodule.py:306-350 (`SpatialTransformer`) + cfnet.py:479-497 (`cost_volume_generator`): right features
     gathered at column w - sample (clamped index; zero where the un-clamped column leaves the image), then either

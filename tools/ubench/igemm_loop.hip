@@ -180,6 +180,79 @@ void run8(const float* w, const float* x, float* out) {
            mfmas * 4096 / ms / 1e9 / 157.3, ms);
 }
 
+// Wave mapping variant (round 5): a wave owns TWO 32-voxel rows and ONE 32-column block of the outputs (MT = 2, NT = 1) instead
+// of one row and two blocks: per tap 1 global_load_dwordx4 of packed weights (ring, two taps ahead) + 2 ds_read_b128 of the
+// tile for the same 8 MFMAs -- half the weight loads per MFMA (the waves of a pair still fetch the same half).
+template <int BAR>
+__global__ __launch_bounds__(256) void kmap(float* out, const float* __restrict__ w, const float* __restrict__ x, int tiles) {
+    extern __shared__ float lds[];
+    float* tile = lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 13200; i += 256) tile[i] = x[i];
+    __syncthreads();
+    f32x16 acc0, acc1;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    const float* abase0 = tile + (((wave >> 1) * 2 + 0) * 66 + (lane & 31)) * 8 + 4 * (lane >> 5);
+    const float* abase1 = tile + (((wave >> 1) * 2 + 1) * 66 + (lane & 31)) * 8 + 4 * (lane >> 5);
+    float sink = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        for (int c = 0; c < CHUNKS; ++c) {
+            const float* wq = w + (size_t)c * 512 + (wave & 1) * 256 + lane * 4;
+            const int wstride = 2048;
+            float4 b[3], a[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) b[u] = *(const float4*)(wq + u * wstride);
+            a[0][0] = *(const float4*)abase0; a[0][1] = *(const float4*)abase1;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 2 < TAPS) b[(tap + 2) % 3] = *(const float4*)(wq + (tap + 2) * wstride);
+                if (tap + 1 < TAPS) {
+                    const int o = ((tap + 1) % 9) * 264 + ((tap + 1) / 9) * 2640;
+                    a[(tap + 1) & 1][0] = *(const float4*)(abase0 + o);
+                    a[(tap + 1) & 1][1] = *(const float4*)(abase1 + o);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float4 a0 = a[tap & 1][0], a1 = a[tap & 1][1], bv = b[tap % 3];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bv.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bv.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bv.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bv.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bv.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bv.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bv.w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bv.w, acc1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (BAR) { __syncthreads(); __syncthreads(); }
+        }
+        sink += acc0[0] + acc1[0];
+    }
+    float s = sink;
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+template <int BAR>
+void runmap(int per_cu, const float* w, const float* x, float* out) {
+    const int tiles = 12;
+    const size_t lds = (size_t)(160 * 1024 / per_cu) & ~(size_t)1023;
+    hipFuncSetAttribute((const void*)kmap<BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(256 * per_cu), blk(256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kmap<BAR>), grid, blk, lds, 0, out, w, x, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kmap<BAR>), grid, blk, lds, 0, out, w, x, tiles);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double mfmas = (double)grid.x * 4 * tiles * CHUNKS * TAPS * 8;
+    printf("MT=2 NT=1 mapping, bar=%d wg/CU=%d : %6.1f TFLOP/s  %.3f of 157.3 (%.3f ms)\n", BAR, per_cu, mfmas * 4096 / ms / 1e9,
+           mfmas * 4096 / ms / 1e9 / 157.3, ms);
+}
+
 int main() {
     const size_t nw = 1 << 18, nx = 1 << 24;
     float* h = (float*)malloc(nx * 4);
@@ -195,5 +268,7 @@ int main() {
     for (int pc = 1; pc <= 2; ++pc) run<0, 0, 1>(pc, w, x, out);
     for (int pc = 1; pc <= 2; ++pc) run<1, 1, 1>(pc, w, x, out);
     run8<0>(w, x, out); run8<1>(w, x, out);
+    for (int pc = 1; pc <= 4; ++pc) runmap<0>(pc, w, x, out);
+    for (int pc = 2; pc <= 4; pc += 2) runmap<1>(pc, w, x, out);
     return 0;
 }

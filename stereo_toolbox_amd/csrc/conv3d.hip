@@ -180,31 +180,35 @@ __device__ __forceinline__ void conv_epilogue_block(const ConvArgs& a, const f32
 }
 
 // Reduce per-lane stats (channel = lane&31 within column block nt) over the workgroup and write
-// the partial slab row.  `red` = LDS scratch of 4*NT*32*2 floats.
-template <int NT>
-__device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[NT], float (&s2)[NT], float* red,
+// the partial slab row.  `red` = LDS scratch of 4*NT*32*2 floats.  NT = column blocks of the workgroup; WN = waves side by side
+// along N (wave w owns blocks (w % WN) * NT/WN ... of rows group w / WN; WN = 1: every wave owns all blocks of its rows).
+template <int NT, int WN = 1>
+__device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[NT / WN], float (&s2)[NT / WN], float* red,
                                                  int tid, size_t slab) {
+    constexpr int NTW = NT / WN;
     const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
         s1[nt] += __shfl_xor(s1[nt], 32);
         s2[nt] += __shfl_xor(s2[nt], 32);
     }
     __syncthreads();   // LDS tile no longer read by anyone
     if (lane < 32) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            red[((wave * NT + nt) * 32 + lane) * 2 + 0] = s1[nt];
-            red[((wave * NT + nt) * 32 + lane) * 2 + 1] = s2[nt];
+        for (int nt = 0; nt < NTW; ++nt) {
+            red[((wave * NTW + nt) * 32 + lane) * 2 + 0] = s1[nt];
+            red[((wave * NTW + nt) * 32 + lane) * 2 + 1] = s2[nt];
         }
     }
     __syncthreads();
     if (tid < NT * 32 && tid < a.Cout) {
+        const int nb = tid >> 5, wcol = nb / NTW, ntl = nb - wcol * NTW;
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            t1 += red[((w * NT) * 32 + tid) * 2 + 0];
-            t2 += red[((w * NT) * 32 + tid) * 2 + 1];
+        for (int wr = 0; wr < 4 / WN; ++wr) {
+            const int w = wr * WN + wcol;
+            t1 += red[((w * NTW + ntl) * 32 + (tid & 31)) * 2 + 0];
+            t2 += red[((w * NTW + ntl) * 32 + (tid & 31)) * 2 + 1];
         }
         a.stats[slab * 2 * a.Cout + tid] = t1;
         a.stats[slab * 2 * a.Cout + a.Cout + tid] = t2;
@@ -217,7 +221,8 @@ __device__ __forceinline__ void conv_write_stats(const ConvArgs& a, float (&s1)[
 // `wq_next`).  One tap is 4 MT NT NQC MFMAs = 0.2-0.4 us of matrix work per wave, an L2 round trip 0.5-0.8 us: with the weights
 // only one tap ahead (rounds 1-2) every tap ended in an s_waitcnt that the two or three other waves of the SIMD could not
 // always cover -- these kernels sat at 0.47-0.71 of the MFMA peak while the weights-in-LDS march kernel reached 0.84.
-template <int S, int MT, int NT, int NQC, int EH, int EWS, int EWH, int VS>
+// NTT = column blocks of the packed weight layout (strides); NT = the blocks this wave multiplies (`wq` points at its first).
+template <int S, int MT, int NT, int NQC, int EH, int EWS, int EWH, int VS, int NTT = NT>
 __device__ __forceinline__ void conv_chunk_taps27(const float* tile, const int (&abase)[MT], const float* wq, const float* wq_next,
                                                   int NQ, f32x16 (&acc)[MT][NT], float4 (&bq)[3][NQC][NT]) {
     constexpr int T = 27;
@@ -231,11 +236,11 @@ __device__ __forceinline__ void conv_chunk_taps27(const float* tile, const int (
             for (int m = 0; m < MT; ++m) av[buf][q][m] = stx_ld4(tile + abase[m] + toff + q * 8);
     };
     auto load_b = [&](const float* w, int tap, int slot) {
-        const float* wtap = w + (size_t)tap * NQ * NT * 256;
+        const float* wtap = w + (size_t)tap * NQ * NTT * 256;
 #pragma unroll
         for (int q = 0; q < NQC; ++q)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[slot][q][nt] = stx_ld4(wtap + (size_t)(q * NT + nt) * 256);
+            for (int nt = 0; nt < NT; ++nt) bq[slot][q][nt] = stx_ld4(wtap + (size_t)(q * NTT + nt) * 256);
     };
     load_a(0, 0);
 #pragma unroll
@@ -260,21 +265,26 @@ __device__ __forceinline__ void conv_chunk_taps27(const float* tile, const int (
     }
 }
 // the ring's first two sets (taps 0 and 1 of a kernel's first chunk)
-template <int NT, int NQC>
+template <int NT, int NQC, int NTT = NT>
 __device__ __forceinline__ void conv_ring_prologue(const float* wq, int NQ, float4 (&bq)[3][NQC][NT]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q = 0; q < NQC; ++q)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[t][q][nt] = stx_ld4(wq + (size_t)t * NQ * NT * 256 + (size_t)(q * NT + nt) * 256);
+            for (int nt = 0; nt < NT; ++nt) bq[t][q][nt] = stx_ld4(wq + (size_t)t * NQ * NTT * 256 + (size_t)(q * NTT + nt) * 256);
 }
 
 // ------------------------------------------------------------------------------------------
 // Direct convolution, kernel KS^3 (pad KS/2), stride S.
 // VPAD: LDS padding per staged voxel in floats (4 = conflict-free operand reads; 0 = the opt-in dense layout of the
 // stride-2 kernel, whose 5 x 5 x 66-voxel halo tile then takes 53 KB instead of 79 KB -> three workgroups per CU)
-template <int KS, int S, int TD, int TH, int NT, int CK, int VPAD = 4>
+// WN: waves side by side along N (round 5).  WN = 1: a wave owns MT rows of 32 voxels and ALL NT column blocks -- per tap NT
+// packed-weight loads (L2) and one tile read per NQC x 4 x MT x NT MFMAs.  WN = 2 (64 output channels): a wave owns TWICE the rows and
+// HALF the blocks: half the weight loads per MFMA, twice the (cheap, LDS) tile reads.  The tap loop in isolation
+// (tools/ubench/igemm_loop, GPU call F of round 5): 0.71-0.745 of the fp32-MFMA peak with one row x two blocks at any occupancy,
+// 0.80-0.85 with two rows x one block -- what the weights-in-LDS variant reaches (0.84), without its 55 KB of LDS.
+template <int KS, int S, int TD, int TH, int NT, int CK, int VPAD = 4, int WN = 1>
 // (occupancy hint: without it hipcc spends 132-180 VGPRs on the 1-2 column-block variants and two workgroups share a CU;
 //  with it the 8- and 16-channel chunk variants take 101 without spilling and four do -- GPU call T: 64->64 L1
 //  0.486 -> 0.430 ms with 8-channel chunks)
@@ -283,10 +293,12 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;
     constexpr int EWS = (S == 2) ? 2 * EWH : EW;     // LDS slots per row (S=2: even/odd de-interleaved)
-    constexpr int MT = TD * TH / 4;
+    constexpr int MT = TD * TH / 4 * WN;             // rows of 32 voxels per wave
+    constexpr int NTW = NT / WN;                     // column blocks per wave
     constexpr int VS = CK + VPAD;
     constexpr int NF4 = CK / 4;
     static_assert(TD * TH % 4 == 0, "tile must split over 4 waves");
+    static_assert(NT % WN == 0 && 4 % WN == 0 && (WN == 1 || KS == 3), "wave grid");
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);
 
@@ -299,15 +311,16 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
     const int NQ = a.Cin / 8;
     constexpr int T = KS * KS * KS, NQC = CK / 8;
 
-    f32x16 acc[MT][NT];
+    const int wrow = wave / WN, wcol = wave % WN;    // (WN = 1: wrow = wave, wcol = 0)
+    f32x16 acc[MT][NTW];
     int abase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int mtile = wave * MT + m;
+        const int mtile = wrow * MT + m;
         const int td = mtile / TH, th = mtile % TH;
         abase[m] = ((td * S * EH + th * S) * EWS + i) * VS + 4 * half;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16();
+        for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = zero16();
     }
 
     using HM = HaloMap<ED, EH, EW, NF4>;
@@ -324,8 +337,9 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
     float4 stg[NST];
 #pragma unroll
     for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, vo[k], 0u);
-    float4 bring[3][NQC][NT];                        // packed weights, two taps ahead (3x3x3: conv_chunk_taps27)
-    if constexpr (KS == 3) conv_ring_prologue<NT, NQC>(a.wp + (size_t)lane * 4, NQ, bring);
+    float4 bring[3][NQC][NTW];                       // packed weights, two taps ahead (3x3x3: conv_chunk_taps27)
+    const float* wbase = a.wp + (size_t)lane * 4 + (size_t)wcol * NTW * 256;          // this wave's first column block
+    if constexpr (KS == 3) conv_ring_prologue<NTW, NQC, NT>(wbase, NQ, bring);
 
     for (int c0 = 0; c0 < a.Cin; c0 += CK) {
         __syncthreads();                             // every wave is done reading the previous chunk's tile
@@ -344,10 +358,10 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
 #pragma unroll
             for (int k = 0; k < NST; ++k) stg[k] = stx_buf_ld4(xrs, more ? vo[k] : STX_BUF_OOB, (unsigned)(c0 + CK) * 4u);
         }
-        const float* wq = a.wp + ((size_t)(c0 / 8) * NT * 64 + lane) * 4;
+        const float* wq = wbase + (size_t)(c0 / 8) * NT * 256;
         if constexpr (KS == 3) {
-            conv_chunk_taps27<S, MT, NT, NQC, EH, EWS, EWH, VS>(tile, abase, wq, c0 + CK < a.Cin ? wq + (size_t)NQC * NT * 256 : nullptr,
-                                                               NQ, acc, bring);
+            conv_chunk_taps27<S, MT, NTW, NQC, EH, EWS, EWH, VS, NT>(tile, abase, wq,
+                                                                     c0 + CK < a.Cin ? wq + (size_t)NQC * NT * 256 : nullptr, NQ, acc, bring);
         } else {
             // 1x1x1: both operands one step ahead in registers (A from the LDS tile, B = packed weights from L2); the
             // scheduling fences keep "issue the next loads, then this step's MFMAs"
@@ -389,25 +403,25 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
         }
     }
 
-    float s1[NT], s2[NT];
+    float s1[NTW], s2[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    for (int nt = 0; nt < NTW; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int mtile = wave * MT + m;
+        const int mtile = wrow * MT + m;
         const int od = od0 + mtile / TH, oh = oh0 + mtile % TH;
         int nrows = (od < a.Do && oh < a.Ho) ? (a.Wo - ow0) : 0;
         nrows = nrows > 32 ? 32 : nrows;
         const size_t vox0 = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow0;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = nt * 32 + i;
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n = (wcol * NTW + nt) * 32 + i;
             const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
             const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
             conv_epilogue_block(a, acc[m][nt], vox0, 1, nrows, n, sc, bs, lane, s1[nt], s2[nt]);
         }
     }
-    if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    if (a.stats) conv_write_stats<NT, WN>(a, s1, s2, tile, tid, (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -420,7 +434,9 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
 // sequence; the halo tile of item i+1 is loaded global -> registers right before the MFMA loop of item i and only
 // written to LDS after it, between the two barriers that separate the items.  The global-memory latency of the
 // staging is therefore always covered by a full tap loop; what stays exposed is the register -> LDS copy.
-template <int KS, int S, int TD, int TH, int NT, int CK>
+// WN: waves side by side along N, as in conv3d_igemm_kernel (128 output channels: WN = 2 -> two rows x two blocks per wave,
+// WN = 4 -> four rows x one block).
+template <int KS, int S, int TD, int TH, int NT, int CK, int WN = 1>
 // (occupancy hint for the stride-1 8-channel-chunk variants only: 328 -> 221 VGPRs without spilling; the stride-2 ones
 //  spill under the same cap and measured 0.152 -> 0.205 ms on 64->128, GPU call U)
 __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void conv3d_pgemm_kernel(ConvArgs a, int ntiles_total) {
@@ -428,13 +444,15 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
     constexpr int ED = (TD - 1) * S + KS, EH = (TH - 1) * S + KS, EW = 31 * S + KS;
     constexpr int EWH = (EW + 1) / 2;
     constexpr int EWS = (S == 2) ? 2 * EWH : EW;
-    constexpr int MT = TD * TH / 4;
+    constexpr int MT = TD * TH / 4 * WN;
+    constexpr int NTW = NT / WN;
     constexpr int VS = CK + 4;
     constexpr int NF4 = CK / 4;
     constexpr int NE = ED * EH * EW * NF4;                       // float4 elements of a staged tile
     constexpr int NST = (NE + CONV_THREADS - 1) / CONV_THREADS;  // per thread
     constexpr int T = KS * KS * KS, NQC = CK / 8;
     static_assert(TD * TH % 4 == 0, "tile must split over 4 waves");
+    static_assert(NT % WN == 0 && 4 % WN == 0, "wave grid");
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);
 
@@ -447,10 +465,11 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
     const int t_lo = __builtin_amdgcn_readfirstlane((int)((long long)ntiles_total * wg / gridDim.x));
     const int t_hi = __builtin_amdgcn_readfirstlane((int)((long long)ntiles_total * (wg + 1) / gridDim.x));
 
+    const int wrow = wave / WN, wcol = wave % WN;
     int abase[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int mtile = wave * MT + m;
+        const int mtile = wrow * MT + m;
         const int td = mtile / TH, th = mtile % TH;
         abase[m] = ((td * S * EH + th * S) * EWS + i) * VS + 4 * half;
     }
@@ -486,21 +505,22 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
         }
     };
 
-    float s1[NT], s2[NT];
+    float s1[NTW], s2[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
-    f32x16 acc[MT][NT];
-    float4 bring[3][NQC][NT];                        // packed weights, two taps ahead (conv_chunk_taps27)
+    for (int nt = 0; nt < NTW; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+    f32x16 acc[MT][NTW];
+    float4 bring[3][NQC][NTW];                       // packed weights, two taps ahead (conv_chunk_taps27)
     static_assert(KS == 3, "the pipelined kernel serves 3x3x3 only");
+    const float* wbase = a.wp + (size_t)lane * 4 + (size_t)wcol * NTW * 256;          // this wave's first column block
     if (t_lo < t_hi) {
         load_item(t_lo, 0);
-        conv_ring_prologue<NT, NQC>(a.wp + (size_t)lane * 4, NQ, bring);
+        conv_ring_prologue<NTW, NQC, NT>(wbase, NQ, bring);
     }
     for (int t = t_lo; t < t_hi; ++t) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = zero16();
+            for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = zero16();
         for (int ch = 0; ch < nchunk; ++ch) {
             __syncthreads();                   // every wave is done reading the previous item's tile
             store_item();
@@ -510,30 +530,30 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
                 const int ntl = ch + 1 < nchunk ? t : t + 1;
                 if (ntl < t_hi) load_item(ntl, nch * CK);
             }
-            const float* wq = a.wp + ((size_t)(ch * (CK / 8)) * NT * 64 + lane) * 4;
+            const float* wq = wbase + (size_t)(ch * (CK / 8)) * NT * 256;
             // (the weight ring runs on across chunks AND tiles: behind a tile's last chunk come the first taps of chunk 0)
-            const float* wq_next = ch + 1 < nchunk ? wq + (size_t)NQC * NT * 256 : (t + 1 < t_hi ? a.wp + (size_t)lane * 4 : nullptr);
-            conv_chunk_taps27<S, MT, NT, NQC, EH, EWS, EWH, VS>(tile, abase, wq, wq_next, NQ, acc, bring);
+            const float* wq_next = ch + 1 < nchunk ? wq + (size_t)NQC * NT * 256 : (t + 1 < t_hi ? wbase : nullptr);
+            conv_chunk_taps27<S, MT, NTW, NQC, EH, EWS, EWH, VS, NT>(tile, abase, wq, wq_next, NQ, acc, bring);
         }
         int b, od0, oh0, ow0;
         tile_origin(t, b, od0, oh0, ow0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const int mtile = wave * MT + m;
+            const int mtile = wrow * MT + m;
             const int od = od0 + mtile / TH, oh = oh0 + mtile % TH;
             int nrows = (od < a.Do && oh < a.Ho) ? (a.Wo - ow0) : 0;
             nrows = nrows > 32 ? 32 : nrows;
             const size_t vox0 = (((size_t)b * a.Do + od) * a.Ho + oh) * a.Wo + ow0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = nt * 32 + i;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = (wcol * NTW + nt) * 32 + i;
                 const float sc = (a.scale && n < a.Cout) ? a.scale[n] : 1.f;
                 const float bs = (a.bias && n < a.Cout) ? a.bias[n] : 0.f;
                 conv_epilogue_block(a, acc[m][nt], vox0, 1, nrows, n, sc, bs, lane, s1[nt], s2[nt]);
             }
         }
     }
-    if (a.stats) conv_write_stats<NT>(a, s1, s2, tile, tid, (size_t)blockIdx.x);
+    if (a.stats) conv_write_stats<NT, WN>(a, s1, s2, tile, tid, (size_t)blockIdx.x);
 }
 
 // (1x1x1 convolutions -- the hourglass `redir` layers, HBM-bound -- go through the implicit-GEMM kernel with 32-channel chunks.
@@ -1364,6 +1384,11 @@ int conv_dispatch(const ConvArgs& a, int NT, int CK, dim3 grid, hipStream_t st) 
     if (NT == NT_ && CK == CK_)                                                                                    \
         return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, NT_, CK_>, grid, lds, st, a);
     if constexpr (KS == 1) { CONV_CASE(1, 32) CONV_CASE(2, 32) CONV_CASE(4, 32) }      // (conv_pick_ck: 3x3x3 takes 8-channel chunks only)
+    if constexpr (KS == 3) {
+        // 64 output channels: two rows x one column block per wave (STX_CONV_WN, see the kernel's comment)
+        if (NT == 2 && CK == 8 && stx_tune(STX_TUNE_CONV_WN) >= 2)
+            return launch_with_lds(conv3d_igemm_kernel<KS, S, CONV_TD, CONV_TH, 2, 8, 4, 2>, grid, lds, st, a);
+    }
     CONV_CASE(1, 8) CONV_CASE(2, 8) CONV_CASE(4, 8)
 #undef CONV_CASE
     return stx_set_error(STX_ERR_ARG, "conv3d: unsupported NT=%d CK=%d", NT, CK);
@@ -1542,6 +1567,16 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
         {
             // this kernel writes row blockIdx.x of the stats slab
             const size_t lds = stride == 1 ? conv_lds_bytes<3, 1>(8, 4) : conv_lds_bytes<3, 2>(8, 4);
+            // (STX_CONV_WN: 2 = the default, only the 64-channel kernels change their wave grid; 3 / 4 = this kernel as two rows x two
+            //  blocks / four rows x one block per wave: 0.242 / 0.239 vs 0.235 ms on 128->128 L2 -- no gain, kept as switches)
+            const int wn = stx_tune(STX_TUNE_CONV_WN) == 4 ? 4 : (stx_tune(STX_TUNE_CONV_WN) == 3 ? 2 : 1);
+            if (wn >= 4)
+                rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8, 4>, lds, st, a, (int)nt_all, plan.pgrid)
+                                 : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8, 4>, lds, st, a, (int)nt_all, plan.pgrid);
+            else if (wn >= 2)
+                rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8, 2>, lds, st, a, (int)nt_all, plan.pgrid)
+                                 : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8, 2>, lds, st, a, (int)nt_all, plan.pgrid);
+            else
             rc = stride == 1 ? launch_persistent(conv3d_pgemm_kernel<3, 1, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all, plan.pgrid)
                              : launch_persistent(conv3d_pgemm_kernel<3, 2, CONV_TD, CONV_TH, 4, 8>, lds, st, a, (int)nt_all, plan.pgrid);
             if (rc) return rc;
@@ -1552,6 +1587,9 @@ extern "C" int stx_conv3d_fwd(const float* x, const float* wp, float* out, const
     else if (ks == 3 && NT == 2 && stx_tune(STX_TUNE_CONV_S2_DENSE)) {
         // stride 2, 32 -> 64 (the first convolution of every hourglass): dense (un-padded) LDS tile, 53 KB: three workgroups
         // per CU instead of two (GPU call A of round 3: 0.332 -> 0.312 ms)
+        if (stx_tune(STX_TUNE_CONV_WN) >= 2)
+            rc = launch_with_lds(conv3d_igemm_kernel<3, 2, CONV_TD, CONV_TH, 2, 8, 0, 2>, grid, (size_t)5 * 5 * 66 * 8 * 4, st, a);
+        else
         rc = launch_with_lds(conv3d_igemm_kernel<3, 2, CONV_TD, CONV_TH, 2, 8, 0>, grid, (size_t)5 * 5 * 66 * 8 * 4, st, a);
     }
     else if (ks == 3) rc = conv_dispatch<3, 2>(a, NT, CK, grid, st);

@@ -152,6 +152,7 @@ enum StxTune {
     STX_TUNE_WGRAD_GRID,     // STX_WGRAD_GRID     0  weight gradient: split-K workgroups per channel-block pair (tests: many tiles per workgroup)
     STX_TUNE_CONV_L1_MARCH,  // STX_CONV_L1_MARCH  0  3x3x3 stride-1 64 -> 64: march kernel in 2 x 2 channel slices instead of the implicit-GEMM kernel
     STX_TUNE_CONV_S2_DENSE,  // STX_CONV_S2_DENSE  1  stride-2 32->64 conv: un-padded LDS tile (three workgroups per CU)
+    STX_TUNE_CONV_WN,        // STX_CONV_WN        2  implicit-GEMM 3x3x3 kernels, wave grid: 1 = one row x all column blocks per wave (rounds 1-4); 2 = 64 output channels as two rows x one block; 3 / 4 = also the 128-channel pipelined kernel as 2 x 2 / 4 x 1
     STX_TUNE_CV_OLD,         // STX_CV_OLD         0  cost volume forward: first-generation builders (fallback path) for every shape
     STX_TUNE_CV_GRID,        // STX_CV_GRID        0  cost volume forward: workgroups (tests: multi-unit runs)
     STX_TUNE_CV_PF,          // STX_CV_PF          0  cost volume forward: feature prefetch, 0 = default (1: one tile ahead), 2 = cache-line pairs through an LDS-DMA slot

@@ -417,6 +417,28 @@ def test_conv3d_fwd(be, case):
     _close(got3, F.mish(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("wn", [1, 2, 3, 4])
+def test_conv3d_wave_grid_variants(be, tune, wn):
+    """STX_CONV_WN: the implicit-GEMM 3x3x3 kernels with their four waves arranged (4 / WN rows groups) x (WN column-block groups)
+    -- 64 output channels: one row x two blocks (1) or two rows x one block (2, default; also 3, 4); 128 output channels
+    (pipelined kernel): 2 x 2 (3) or 4 x 1 (4).  Every arrangement against the reference convolution, statistics rows
+    included, ragged edges."""
+    tune("STX_CONV_WN", wn)
+    torch.manual_seed(11)
+    for B, Cin, Cout, D, H, W, s in ((1, 64, 64, 3, 5, 37, 1), (2, 32, 64, 5, 6, 70, 2), (1, 128, 128, 3, 4, 33, 1),
+                                    (1, 64, 128, 4, 6, 66, 2), (1, 64, 48, 2, 3, 20, 1)):
+        x = torch.randn(B, Cin, D, H, W)
+        w = torch.randn(Cout, Cin, 3, 3, 3) * 0.1
+        ref = F.conv3d(x, w, None, s, 1)
+        got, st = run_conv(be, x, w, 3, s, stats=True)
+        _close(got, ref)
+        _close(st[:, 0].sum(0), ref.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        _close(st[:, 1].sum(0), (ref ** 2).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        sc, bs, res = torch.rand(Cout) + 0.5, torch.randn(Cout), torch.randn_like(ref)
+        got2, _ = run_conv(be, x, w, 3, s, sc, bs, res, 1)
+        _close(got2, F.relu(ref * sc.view(1, -1, 1, 1, 1) + bs.view(1, -1, 1, 1, 1) + res))
+
+
 def test_conv3d_64_64_on_the_march_kernel(be, tune):
     """STX_CONV_L1_MARCH: the 64 -> 64 3x3x3 stride-1 layers (hourglass conv2 and its data gradient) as 2 x 2 channel slices
     of the march kernel -- K slices accumulate through the output tensor, the epilogue (BN statistics, affine, residual,

@@ -92,6 +92,9 @@ AB_SETS = [
     ("march kernel: no plane staging (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 1}),
     ("march kernel: no epilogue stores (ablation)", "conv_32_32_L0_fwd", {"STX_MARCH_ABLATE": 2}),
     ("64->64 L1 on the march kernel (2 x 2 channel slices)", "conv_64_64_L1_fwd", {"STX_CONV_L1_MARCH": 1}),
+    ("implicit GEMM: one row x all column blocks per wave (the wave grid of rounds 1-4)", "conv_64_64_L1_fwd,conv_32_64_s2_L0_fwd,conv_128_128_L2_fwd,conv_64_128_s2_L1_fwd", {"STX_CONV_WN": 1}),
+    ("implicit GEMM: 128 output channels as two rows x two blocks per wave", "conv_128_128_L2_fwd,conv_64_128_s2_L1_fwd", {"STX_CONV_WN": 3}),
+    ("implicit GEMM: 128 output channels as four rows x one block per wave", "conv_128_128_L2_fwd,conv_64_128_s2_L1_fwd", {"STX_CONV_WN": 4}),
     ("stride-2 32->64 with the padded LDS tile", "conv_32_64_s2_L0_fwd", {"STX_CONV_S2_DENSE": 0}),
     ("weight gradient 3x3x3 s1: tile kernel of rounds 1-3 instead of the march kernel", "conv_32_32_L0_wgrad,conv_64_32_L0_wgrad,conv_64_64_L1_wgrad,conv_128_128_L2_wgrad", {"STX_WGRAD_MARCH": 0}),
     ("weight gradient 3x3x3 s2 / transposed: tile kernel of rounds 1-3 instead of the parity-split march kernel", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_MARCH": 1}),

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(CONV_THREADS, NT <= 2 && CK <= 16 ? (S == 2 ? 3 : 4
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address math, no waterfall loops around the descriptors)
     const int i = lane & 31, half = lane >> 5;
     const int bid = xcd_remap(blockIdx.x, gridDim.x), b = blockIdx.y;
     const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(CONV_THREADS, (CK == 8 && S == 1) ? 2 : 1) void con
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar address math, no waterfall loops around the descriptors)
     const int i = lane & 31, half = lane >> 5;
     const int NQ = a.Cin / 8, nchunk = a.Cin / CK;
     const int tiles_per_b = a.nDt * a.nHt * a.nWt;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void conv3d_marchw_kernel(MarchArgs ma) {
     STX_DYN_SMEM(smem);
     float* wl = reinterpret_cast<float*>(smem);                      // [27][4][64][4]
     float* planes = wl + MW2_WFLOATS;                                // [2][MW2_SLOT]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (this kernel forces uniformity where it matters: explicit readfirstlanes below)
     const int i = lane & 31, half = lane >> 5;
     const int th = wave;                                             // row block of this wave
     auto n_lane = [&]() { return i; };                               // output channel of this lane
@@ -990,7 +990,11 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 3 : 2) void deconv3d_igemm_
     STX_DYN_SMEM(smem);
     float* tile = reinterpret_cast<float*>(smem);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform wave index (scalar address math, no waterfall loops around the 4 x NT output descriptors): -5.5 % on 64 -> 32
+    // (GPU call I of round 5); with 64 output channels the hoisted scalar state costs 100 spilled VGPRs under the 256-register
+    // cap (0.146 -> 0.204 ms), so that instantiation keeps the per-lane form
+    const int wave = NT == 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int i = lane & 31, half = lane >> 5;
     const int bid = xcd_remap(blockIdx.x, gridDim.x), b = blockIdx.y;
     const int wt = bid % a.nWt, ht = (bid / a.nWt) % a.nHt, dt = bid / (a.nWt * a.nHt);
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(NW * 64) void conv3d_wgrad_kernel(WgradArgs a) {
     float* ctile = ftile + ED * EH * EWS * 32;              // [NV][32]
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, half = lane >> 5;
     const int ncf = a.CF / 32;
     const int cfb = blockIdx.y % ncf, ccb = blockIdx.y / ncf;

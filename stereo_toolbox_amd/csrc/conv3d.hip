@@ -1047,10 +1047,13 @@ __global__ __launch_bounds__(CONV_THREADS, NT == 1 ? 3 : 2) void deconv3d_igemm_
     float s1[NT], s2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
-    const int mh = mh0 + th;
+    // (epilogue: wave-uniform copies of the wave's row / class set in every instantiation -- the output descriptors and row
+    //  offsets are scalar; the 64-channel kernel keeps the per-lane forms in its main loop, see above)
+    const int thu = __builtin_amdgcn_readfirstlane(th), csetu = __builtin_amdgcn_readfirstlane(cset);
+    const int mh = mh0 + thu;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int cls = cls_tab[cset][c];
+        const int cls = cls_tab[csetu][c];
         const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
         const int od = 2 * md0 + pd, oh = 2 * mh + ph, ow_first = 2 * mw0 + pw;
         int nrows = 0;

@@ -343,3 +343,74 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
         dist.all_reduce = orig
     assert len(calls) == 4 and all(c[1] for c in calls) and all(c[2] == dist.ReduceOp.AVG for c in calls)
     assert sum(c[0] for c in calls[:2]) == gs.flat.numel()
+
+
+class _BehindTheFeatures(nn.Module):
+    """GwcNet_GC from its 1/4-resolution features on (`aggregate`), as a module DDP / FlatGradSync can wrap: the features are
+    fixed buffers, so nothing of the stock 2-D CNN (MIOpen: not run-to-run reproducible) is in the graph and every gradient
+    behind them is a deterministic function of the inputs."""
+
+    def __init__(self, model, feats, H, W):
+        super().__init__()
+        self.model = model
+        for p in self.model.feature_extraction.parameters():
+            p.requires_grad_(False)
+        for i, f in enumerate(feats):
+            self.register_buffer(f"f{i}", f)
+        self.hw = (H, W)
+
+    def forward(self):
+        return self.model.aggregate({"gwc_feature": self.f0, "concat_feature": self.f2},
+                                    {"gwc_feature": self.f1, "concat_feature": self.f3}, *self.hw)
+
+
+@pytest.mark.gpu
+def test_ddp_and_flat_sync_are_exact_behind_fixed_features_rccl_world1(nccl_world1, parity_log):
+    """the wrapped-vs-plain checks above accept max(5 x run-to-run noise, 10 %) because the stock 2-D CNN makes two
+    plain steps differ.  Here the graph starts at FIXED feature maps: the hand-written path is bit-for-bit reproducible, a 1-rank
+    RCCL AVG is the identity, so torch DDP's reducer and FlatGradSync's hook -> asynchronous all-reduce -> finish() sequence must
+    hand back EXACTLY the plain module's gradients -- a bucket-ordering error, a stale view or a partially reduced range would
+    show as a non-zero difference, not as a few per cent."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from stereo_toolbox_amd.distributed import FlatGradSync
+    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+    from stereo_toolbox_amd.utils import synthetic_tensor
+    Hh, Ww, Dd, B = 64, 128, 64, 1
+    feats = [synthetic_tensor((B, 320, Hh // 4, Ww // 4), 21, lo=-1.0, hi=1.0).cuda(),
+             synthetic_tensor((B, 320, Hh // 4, Ww // 4), 22, lo=-1.0, hi=1.0).cuda(),
+             synthetic_tensor((B, 12, Hh // 4, Ww // 4), 23, lo=-1.0, hi=1.0).cuda(),
+             synthetic_tensor((B, 12, Hh // 4, Ww // 4), 24, lo=-1.0, hi=1.0).cuda()]
+    gt = synthetic_tensor((B, Hh, Ww), 3, lo=0.0, hi=float(Dd - 2)).cuda()
+
+    def make():
+        return _BehindTheFeatures(_filled_model("GwcNet_GC", Dd).cuda().train(), feats, Hh, Ww)
+
+    def step(mod):
+        preds = mod()
+        masked_smooth_l1_multi(preds, gt, Dd, LOSS_W[-len(preds):]).backward()
+        torch.cuda.synchronize()
+
+    plain = make()
+    step(plain)
+    want = {k: p.grad.clone() for k, p in plain.named_parameters() if p.grad is not None}
+    assert len(want) > 100
+    again = make()
+    step(again)
+    assert all(torch.equal(p.grad, want[k]) for k, p in again.named_parameters() if p.grad is not None), "the plain step itself is not reproducible"
+
+    ddp = DDP(make(), device_ids=[0], output_device=0)
+    step(ddp)
+    bad = [k for k, p in ddp.module.named_parameters() if k in want and not torch.equal(p.grad, want[k])]
+    assert not bad, ("DDP", bad[:5])
+
+    m = make()
+    gs = FlatGradSync(m, buckets=3, overlap=True, collective_at_world_1=True)
+    for it in range(2):
+        gs.detach_grads() if it == 0 else gs.zero_grad()
+        step(m)
+        gs.finish()
+        torch.cuda.synchronize()
+        assert gs.views_intact() and all(gs._launched)
+        bad = [k for k, p in m.named_parameters() if k in want and not torch.equal(p.grad, want[k])]
+        assert not bad, (f"FlatGradSync step {it}", bad[:5])
+    parity_log("ddp_and_flat_sync_exact_behind_fixed_features", tensors=len(want), not_bitwise_equal=0)

@@ -94,7 +94,7 @@ ENV_FACTOR = 3.0     # a gradient tensor may be this many times the largest resp
 ENV_CAP = 0.5        # ... but never more than half the tensor's max: wrong wiring / signs / missing terms show as >= 100 %
 
 
-def _sensitivity(run64_grads, base64):
+def _sensitivity(run64_grads, base64, fields=None):
     """Sensitivity envelope of a train-step test configuration (round 5, profiles/r05_toy_shape_grad_sensitivity.txt).
     `run64_grads(hook)` evaluates the ORACLE in fp64 with `hook` applied to the 1/4-resolution features and returns
     {name: gradient}; the envelope of a tensor is the largest max-abs change of its exact gradient over ENV_DRAWS draws of
@@ -110,7 +110,7 @@ def _sensitivity(run64_grads, base64):
     driver's round-4 run reported; the product's isolated 3-D path lands on the first jump on the chip (5.85 %, bit for bit
     the same in every run) as on the emulator."""
     env = {}
-    for k in range(ENV_DRAWS):
+    for k in range(ENV_DRAWS if fields is None else fields):
         for sign in (1.0, -1.0):
             got = run64_grads(O.feature_noise(sign * ENV_EPS, k + 1))
             for name, g in got.items():
@@ -228,7 +228,7 @@ def test_gwcnet_gc_train_parity(env, parity_log):
             O.smooth_l1_multi(O.gwcnet_forward(s_, left.double(), right.double(), D, True, training=True, feature_hook=hook),
                               gt.double(), D, LOSS_W).backward()
             return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
-        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
+        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()}, fields=1)
     n, worst = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"gwcnet_gc_train_grads[{env.name}]", **f),
                             factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens,
                             factor_2d=GRAD_FACTOR_STOCK_2D_SMALL_GPU if env.name == "hip" else None)
@@ -441,7 +441,7 @@ def test_acvnet_train_parity(env, parity_log):
             O.smooth_l1_multi(O.acvnet_forward(s_, left.double(), right.double(), D, training=True, feature_hook=hook),
                               gt.double(), D, LOSS_W).backward()
             return {k: v.grad for k, v in s_.items() if v.is_floating_point()}
-        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()})
+        sens = _sensitivity(run64, {k: v.grad for k, v in sd64.items() if v.is_floating_point()}, fields=1)
     n, _ = _check_grads(m, ref_sd, sd64, log=lambda **f: parity_log(f"acvnet_train_grads[{env.name}]", **f),
                         factor=GRAD_FACTOR_SMALL_GPU if env.name == "hip" else None, sens=sens,
                         factor_2d=GRAD_FACTOR_STOCK_2D_SMALL_GPU if env.name == "hip" else None)

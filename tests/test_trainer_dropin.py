@@ -393,7 +393,7 @@ def test_ddp_and_flat_sync_are_exact_behind_fixed_features_rccl_world1(nccl_worl
     plain = make()
     step(plain)
     want = {k: p.grad.clone() for k, p in plain.named_parameters() if p.grad is not None}
-    assert len(want) > 100
+    assert len(want) >= 100          # every parameter behind the feature extractor
     again = make()
     step(again)
     assert all(torch.equal(p.grad, want[k]) for k, p in again.named_parameters() if p.grad is not None), "the plain step itself is not reproducible"

@@ -359,7 +359,7 @@ class _BehindTheFeatures(nn.Module):
             self.register_buffer(f"f{i}", f)
         self.hw = (H, W)
 
-    def forward(self):
+    def forward(self, _unused):          # (DDP with device_ids scatters its positional inputs: it needs at least one)
         return self.model.aggregate({"gwc_feature": self.f0, "concat_feature": self.f2},
                                     {"gwc_feature": self.f1, "concat_feature": self.f3}, *self.hw)
 
@@ -386,7 +386,7 @@ def test_ddp_and_flat_sync_are_exact_behind_fixed_features_rccl_world1(nccl_worl
         return _BehindTheFeatures(_filled_model("GwcNet_GC", Dd).cuda().train(), feats, Hh, Ww)
 
     def step(mod):
-        preds = mod()
+        preds = mod(gt)
         masked_smooth_l1_multi(preds, gt, Dd, LOSS_W[-len(preds):]).backward()
         torch.cuda.synchronize()
 

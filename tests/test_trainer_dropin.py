@@ -223,16 +223,20 @@ def _same_grads(named_params, want, noise, what, parity_log=None):
     BatchNorm amplifies one-ulp feature differences to 1e-3 .. 1e-2 of a gradient's max (GPU call D of round 4: 0 of 269
     tensors bitwise equal between two plain runs, worst 0.6 % / 4 %).  `noise` is that run-to-run distance measured in the
     same test (plain vs two more plain instances); the wrapped module may be at most 5 x as far from plain as plain is from
-    itself (floor 10 % -- a few runs are a noisy estimate of that distance: 0.2 % .. 3 % for the 3-D path over the calls of
-    round 4).  A wrapper that dropped, doubled or
+    itself (floor: see below -- a few runs are a noisy estimate of that distance: 0.2 % .. 3 % for the 3-D path over the calls of
+    round 4, 9.5 % once in round 5).  A wrapper that dropped, doubled or
     mis-scaled a gradient would be off by O(1); the exact-equality form of this check runs on the deterministic CPU /
     gloo / emulator path (test_reference_trainer_prepare_model_two_ranks: 1e-6)."""
     worst, n_exact, n = _grad_distance(named_params, want)
     if parity_log is not None:
         parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst["2d"], worst_rel_3d_path=worst["3d"],
                    plain_run_to_run_2d=noise["2d"], plain_run_to_run_3d=noise["3d"])
+    # floor 25 % (round 5; was 10 %): the toy configurations JUMP -- ACVNet's attention-only step moved a tensor by 9.5 % between
+    # two plain runs (calls E / N of round 5) and its full form has an 18.4 % jump (tests/test_models.py::_sensitivity).  This
+    # check is the smoke test (a dropped / doubled / mis-scaled gradient is off by O(1)); the EXACT one is
+    # test_ddp_and_flat_sync_are_exact_behind_fixed_features_rccl_world1 below (bitwise, no stock 2-D CNN in the graph).
     for k in ("2d", "3d"):
-        assert worst[k] <= max(5.0 * noise[k], 0.1), (what, k, worst[k], noise[k])
+        assert worst[k] <= max(5.0 * noise[k], 0.25), (what, k, worst[k], noise[k])
     return n_exact, n
 
 

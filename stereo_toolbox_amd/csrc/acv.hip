@@ -88,6 +88,88 @@ __global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_kernel(DwArgs a) {
     }
 }
 
+// The same convolution with a ROLLING WINDOW of input rows in LDS (round 5).  The kernel above asks the caches for nine float4 per
+// output float4: at 576x960 it moves a 265 MB volume at 0.22 of the HBM rate, L2-bound.  Here a workgroup owns a strip of TW
+// columns of one (b, d) plane (a run of rows of it) and walks down the rows: input row h + 4 is in flight into registers while
+// output row h is computed from the seven resident rows h-3 .. h+3 (ring of eight: dilation <= 3), then written to the slot of
+// row h-4 -- one barrier per row, every input element is fetched from memory once per strip ((TW + 6) / TW: 1.12 x for TW = 50).
+// Out-of-image rows / columns are staged as zeros, so the nine taps are nine unconditional ds_read_b128.  A thread keeps one
+// channel quad (its 36 weights, its dilation); TW = 2 x floor(256 / CQ) voxels = two rounds per row.
+constexpr int DWR_RING = 8, DWR_HALO = 3;
+
+__global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_roll_kernel(DwArgs a, int TW, int nstrips, int nseg, int seg_rows) {
+    STX_DYN_SMEM(smem);
+    float* ring = reinterpret_cast<float*>(smem);                    // [DWR_RING][TW + 6][C]
+    const int CQ = a.C >> 2, vpb = ACV_THREADS / CQ;
+    const int tid = threadIdx.x, cq = tid % CQ, vl = tid / CQ;
+    const int EW = TW + 2 * DWR_HALO, rowf = EW * a.C;               // floats per staged row
+    const int dl = a.dil[cq < CQ ? cq : 0];
+    float wc[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) wc[k] = a.w[(size_t)cq * 36 + (k / 9) * 9 + (a.flip ? 8 - k % 9 : k % 9)];
+    // work item: (plane bd, strip, row segment)
+    const int item = blockIdx.x;
+    const int seg = item % nseg, strip = (item / nseg) % nstrips, bd = item / (nseg * nstrips);
+    const int w0 = strip * TW, h_lo = seg * seg_rows, h_hi = (h_lo + seg_rows < a.H) ? h_lo + seg_rows : a.H;
+    const float* xp = a.x + (size_t)bd * a.H * a.W * a.C;
+    float* op = a.out + (size_t)bd * a.H * a.W * a.C;
+    const int nf4 = EW * CQ;                                         // float4 per staged row
+    constexpr int NST = 4;                                           // staging float4 per thread (host: nf4 <= 4 x 256)
+    float4 stg[NST];
+    auto load_row = [&](int hh) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * ACV_THREADS;
+            const int v = e / CQ, q = e - v * CQ, ww = w0 - DWR_HALO + v;
+            const bool ok = e < nf4 && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
+            stg[k] = ok ? stx_ld4(xp + ((size_t)hh * a.W + ww) * a.C + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_row = [&](int hh) {
+        float* dst = ring + ((hh + 8 * DWR_RING) % DWR_RING) * rowf;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * ACV_THREADS;
+            if (e < nf4) stx_st4(dst + 4 * e, stg[k]);
+        }
+    };
+    // rows h_lo - 3 .. h_lo + 3 resident before the first output row
+    for (int hh = h_lo - DWR_HALO; hh <= h_lo + DWR_HALO; ++hh) {
+        load_row(hh);
+        store_row(hh);
+    }
+    __syncthreads();
+    for (int h = h_lo; h < h_hi; ++h) {
+        load_row(h + DWR_HALO + 1);                                  // in flight during this row's arithmetic
+        if (vl < vpb) {
+#pragma unroll
+            for (int rnd = 0; rnd < 2; ++rnd) {
+                const int v = rnd * vpb + vl;                        // column inside the strip
+                if (v < TW && w0 + v < a.W) {
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float* rp = ring + ((h + dl * (i - 1) + 8 * DWR_RING) % DWR_RING) * rowf + 4 * cq;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float4 t = stx_ld4(rp + (v + DWR_HALO + dl * (j - 1)) * a.C);
+                            const int k = 3 * i + j;
+                            acc.x = fmaf(t.x, wc[k], acc.x);
+                            acc.y = fmaf(t.y, wc[9 + k], acc.y);
+                            acc.z = fmaf(t.z, wc[18 + k], acc.z);
+                            acc.w = fmaf(t.w, wc[27 + k], acc.w);
+                        }
+                    }
+                    stx_st4(op + ((size_t)h * a.W + w0 + v) * a.C + 4 * cq, acc);
+                }
+            }
+        }
+        __syncthreads();                                             // everyone is done with row h - 3 (= the slot of row h + 5)...
+        store_row(h + DWR_HALO + 1);                                 // ... row h + 4 goes to the slot row h - 4 left behind
+        __syncthreads();
+    }
+}
+
 // partial[blk][c][k] = sum over the workgroup's voxels of gy[v][c] * x[v + off_k][c]
 __global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_wgrad_kernel(const float* __restrict__ x,
                                                                        const float* __restrict__ gy,
@@ -140,6 +222,98 @@ __global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_wgrad_kernel(const floa
         const int k = idx / CQ, q = idx % CQ;          // k = comp*9 + tap
         float t = 0.f;
         for (int j = q; j < (ACV_THREADS / CQ) * CQ; j += CQ) t += red[k * ACV_THREADS + j];
+        partials[(size_t)blockIdx.x * C * 9 + (size_t)(4 * q + k / 9) * 9 + (k % 9)] = t;
+    }
+}
+
+// Weight gradient with the same rolling window (round 5): x rows staged once per strip, gy read as it is used; a workgroup owns one
+// (plane, strip, row segment) item and writes ONE partial row [C][9] (items <= ACV_WGRAD_BLOCKS); the final cross-lane sum reuses
+// the ring's LDS.
+__global__ __launch_bounds__(ACV_THREADS) void dwconv_hw_wgrad_roll_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                            const int* __restrict__ dil, float* __restrict__ partials,
+                                                                            int H, int W, int C, int TW, int nstrips, int nseg,
+                                                                            int seg_rows) {
+    STX_DYN_SMEM(smem);
+    float* ring = reinterpret_cast<float*>(smem);                    // [DWR_RING][TW + 6][C]; afterwards the reduction buffer
+    const int CQ = C >> 2, vpb = ACV_THREADS / CQ;
+    const int tid = threadIdx.x, cq = tid % CQ, vl = tid / CQ;
+    const int EW = TW + 2 * DWR_HALO, rowf = EW * C;
+    const int dl = dil[cq];
+    float s[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) s[k] = 0.f;
+    const int item = blockIdx.x;
+    const int seg = item % nseg, strip = (item / nseg) % nstrips, bd = item / (nseg * nstrips);
+    const int w0 = strip * TW, h_lo = seg * seg_rows, h_hi = (h_lo + seg_rows < H) ? h_lo + seg_rows : H;
+    const float* xp = x + (size_t)bd * H * W * C;
+    const float* gp = gy + (size_t)bd * H * W * C;
+    const int nf4 = EW * CQ;
+    constexpr int NST = 4;
+    float4 stg[NST];
+    auto load_row = [&](int hh) {
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * ACV_THREADS;
+            const int v = e / CQ, q = e - v * CQ, ww = w0 - DWR_HALO + v;
+            const bool ok = e < nf4 && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            stg[k] = ok ? stx_ld4(xp + ((size_t)hh * W + ww) * C + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_row = [&](int hh) {
+        float* dst = ring + ((hh + 8 * DWR_RING) % DWR_RING) * rowf;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int e = tid + k * ACV_THREADS;
+            if (e < nf4) stx_st4(dst + 4 * e, stg[k]);
+        }
+    };
+    for (int hh = h_lo - DWR_HALO; hh <= h_lo + DWR_HALO; ++hh) {
+        load_row(hh);
+        store_row(hh);
+    }
+    __syncthreads();
+    for (int h = h_lo; h < h_hi; ++h) {
+        load_row(h + DWR_HALO + 1);
+        float4 g[2];
+        bool on[2];
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            const int v = rnd * vpb + vl;
+            on[rnd] = vl < vpb && v < TW && w0 + v < W;
+            g[rnd] = on[rnd] ? stx_ld4(gp + ((size_t)h * W + w0 + v) * C + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (on[rnd]) {
+                const int v = rnd * vpb + vl;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float* rp = ring + ((h + dl * (i - 1) + 8 * DWR_RING) % DWR_RING) * rowf + 4 * cq;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float4 t = stx_ld4(rp + (v + DWR_HALO + dl * (j - 1)) * C);
+                        const int k = 3 * i + j;
+                        s[k] = fmaf(g[rnd].x, t.x, s[k]);
+                        s[9 + k] = fmaf(g[rnd].y, t.y, s[9 + k]);
+                        s[18 + k] = fmaf(g[rnd].z, t.z, s[18 + k]);
+                        s[27 + k] = fmaf(g[rnd].w, t.w, s[27 + k]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        store_row(h + DWR_HALO + 1);
+        __syncthreads();
+    }
+    // (the last two barriers have retired every read of the ring: it becomes the [36][256] reduction buffer; host: fits)
+    float* red = ring;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) red[k * ACV_THREADS + tid] = s[k];
+    __syncthreads();
+    for (int idx = tid; idx < 36 * CQ; idx += ACV_THREADS) {
+        const int k = idx / CQ, q = idx % CQ;
+        float t = 0.f;
+        for (int j = q; j < vpb * CQ; j += CQ) t += red[k * ACV_THREADS + j];
         partials[(size_t)blockIdx.x * C * 9 + (size_t)(4 * q + k / 9) * 9 + (k % 9)] = t;
     }
 }
@@ -319,6 +493,29 @@ extern "C" int stx_dwconv_hw_fwd(const float* x, const float* w, const int* dil,
     a.x = x; a.w = w; a.dil = dil; a.out = out; a.BD = B * D; a.H = H; a.W = W; a.C = C; a.flip = flip;
     STX_REQUIRE(C / 4 <= ACV_THREADS, "dwconv_hw_fwd: C=%d (at most %d channels)", C, 4 * ACV_THREADS);
     const size_t nvox = (size_t)B * D * H * W, vpb = ACV_THREADS / (C / 4);
+    // rolling-window kernel: strips of TW = 2 vpb columns, rows cut into segments so that the launch has >= ~3 workgroups per CU
+    {
+        const int TW = 2 * (int)vpb, EW = TW + 2 * DWR_HALO;
+        const size_t lds = (size_t)DWR_RING * EW * C * sizeof(float);
+        const int nf4 = EW * (C / 4);
+        if (stx_tune(STX_TUNE_DWCONV_ROLL) && lds <= 160 * 1024 && nf4 <= 4 * ACV_THREADS && H >= 8) {
+            const int nstrips = stx_cdiv(W, TW);
+            const long long base = (long long)B * D * nstrips;
+            int nseg = (int)((768 + base - 1) / base);
+            if (nseg < 1) nseg = 1;
+            if (nseg > H / 8) nseg = H / 8 > 0 ? H / 8 : 1;          // a segment re-stages 6 halo rows: keep it >= 8 rows
+            const int seg_rows = stx_cdiv(H, nseg);
+            nseg = stx_cdiv(H, seg_rows);
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute((const void*)dwconv_hw_roll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return stx_set_error(STX_ERR_LAUNCH, "dwconv_hw_fwd: %d bytes of dynamic LDS refused by this device", (int)lds);
+            if (base * nseg < (1ll << 31)) {
+                hipLaunchKernelGGL(dwconv_hw_roll_kernel, dim3((unsigned)(base * nseg)), dim3(ACV_THREADS), lds, (hipStream_t)stream, a,
+                                   TW, nstrips, nseg, seg_rows);
+                return stx_check_launch("dwconv_hw_fwd(roll)");
+            }
+        }
+    }
     const size_t g = (nvox + vpb - 1) / vpb;
     hipLaunchKernelGGL(dwconv_hw_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(ACV_THREADS), 0, (hipStream_t)stream, a);
     return stx_check_launch("dwconv_hw_fwd");
@@ -332,11 +529,36 @@ extern "C" int stx_dwconv_hw_wgrad(const float* x, const float* gy, const int* d
     STX_REQUIRE(x && gy && dil && dw && workspace && C % 4 == 0 && C / 4 <= ACV_THREADS,
                 "dwconv_hw_wgrad: bad args (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(dwconv_hw_wgrad_kernel, dim3(ACV_WGRAD_BLOCKS), dim3(ACV_THREADS), 0, st, x, gy, dil, workspace,
-                       B * D, H, W, C);
+    int nrows = ACV_WGRAD_BLOCKS;
+    bool rolled = false;
+    {
+        // rolling-window form: one partial row per (plane, strip, row segment) item, at most ACV_WGRAD_BLOCKS of them
+        const int vpb = ACV_THREADS / (C / 4), TW = 2 * vpb, EW = TW + 2 * DWR_HALO, nstrips = stx_cdiv(W, TW);
+        size_t lds = (size_t)DWR_RING * EW * C * sizeof(float);
+        const size_t red = (size_t)36 * ACV_THREADS * sizeof(float);
+        if (lds < red) lds = red;
+        const long long base = (long long)B * D * nstrips;
+        if (stx_tune(STX_TUNE_DWCONV_ROLL) && lds <= 160 * 1024 && EW * (C / 4) <= 4 * ACV_THREADS && H >= 8 && base <= ACV_WGRAD_BLOCKS) {
+            int nseg = (int)(ACV_WGRAD_BLOCKS / base);
+            if (nseg > H / 8) nseg = H / 8;
+            if (nseg < 1) nseg = 1;
+            const int seg_rows = stx_cdiv(H, nseg);
+            nseg = stx_cdiv(H, seg_rows);
+            if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dwconv_hw_wgrad_roll_kernel,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return stx_set_error(STX_ERR_LAUNCH, "dwconv_hw_wgrad: %d bytes of dynamic LDS refused by this device", (int)lds);
+            nrows = (int)(base * nseg);
+            hipLaunchKernelGGL(dwconv_hw_wgrad_roll_kernel, dim3(nrows), dim3(ACV_THREADS), lds, st, x, gy, dil, workspace, H, W, C, TW,
+                               nstrips, nseg, seg_rows);
+            rolled = true;
+        }
+    }
+    if (!rolled)
+        hipLaunchKernelGGL(dwconv_hw_wgrad_kernel, dim3(ACV_WGRAD_BLOCKS), dim3(ACV_THREADS), 0, st, x, gy, dil, workspace,
+                           B * D, H, W, C);
     int rc = stx_check_launch("dwconv_hw_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(acv_colsum_kernel, dim3(C * 9), dim3(ACV_THREADS), 0, st, workspace, ACV_WGRAD_BLOCKS, C * 9, dw);
+    hipLaunchKernelGGL(acv_colsum_kernel, dim3(C * 9), dim3(ACV_THREADS), 0, st, workspace, nrows, C * 9, dw);
     return stx_check_launch("dwconv_hw_wgrad_colsum");
 }
 

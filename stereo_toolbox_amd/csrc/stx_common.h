@@ -162,6 +162,7 @@ enum StxTune {
     STX_TUNE_CVB_GRID,       // STX_CVB_GRID       0  cost volume backward: workgroups (tests)
     STX_TUNE_CVB_NSET,       // STX_CVB_NSET       3  cost volume backward: chunks in flight per loader lane (2..4)
     STX_TUNE_SV_BWD_V1,      // STX_SV_BWD_V1      0  CFNet cascade-volume backward: global atomics only
+    STX_TUNE_DWCONV_ROLL,    // STX_DWCONV_ROLL    1  ACVNet patch convolutions: rolling window of input rows in LDS (0 = the cache-fed kernel of rounds 3-4)
     STX_TUNE_COUNT
 };
 int stx_tune(StxTune id);

@@ -731,6 +731,49 @@ def test_dwconv_hw_fwd_bwd(be):
     _close(gw, gref, rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(1, 40, 2, 19, 61), (2, 40, 1, 9, 50), (1, 8, 2, 33, 300), (1, 40, 1, 8, 7)])
+def test_dwconv_hw_rolling_window(be, tune, shape):
+    """The rolling-window form of the patch convolutions (round 5: strips of columns walking down the rows with eight rows
+    in LDS) against the reference and against the cache-fed kernel of rounds 3-4 (STX_DWCONV_ROLL = 0): several strips, a
+    ragged last strip, row segments, both tap orders (forward / data gradient), dilations 1-3, a 2-quad volume."""
+    B, C, D, H, W = shape
+    torch.manual_seed(21)
+    x = torch.randn(B, C, D, H, W)
+    CQ = C // 4
+    dils = [1 + (q * 3) // CQ for q in range(CQ)]                       # quads with dilation 1, 2, 3
+    wts = torch.randn(C, 9)
+    ref = torch.cat([F.conv3d(x[:, 4 * q:4 * q + 4], wts[4 * q:4 * q + 4].view(4, 1, 1, 3, 3), None, 1, (0, dils[q], dils[q]),
+                              dils[q], 4) for q in range(CQ)], 1)
+    reff = torch.cat([F.conv3d(x[:, 4 * q:4 * q + 4], wts[4 * q:4 * q + 4].flip(1).view(4, 1, 1, 3, 3), None, 1,
+                               (0, dils[q], dils[q]), dils[q], 4) for q in range(CQ)], 1)
+    xl, dw_, dd = be.dev(ndhwc(x)), be.dev(wts), be.dev(torch.tensor(dils, dtype=torch.int32))
+    outs = {}
+    for roll in (1, 0):
+        tune("STX_DWCONV_ROLL", roll)
+        for flip, want in ((0, ref), (1, reff)):
+            out = be.empty(B, D, H, W, C)
+            be.call("stx_dwconv_hw_fwd", ptr(xl), ptr(dw_), ptr(dd), ptr(out), B, D, H, W, C, flip)
+            _close(ncdhw(out), want, rtol=1e-5)
+            outs[(roll, flip)] = out
+    for flip in (0, 1):                                                  # same products, same order of the nine taps
+        assert torch.equal(outs[(1, flip)], outs[(0, flip)])
+    # weight gradient: the rolling-window form against autograd's, and against the cache-fed kernel
+    xr, wr = x.clone().requires_grad_(), wts.clone().requires_grad_()
+    gy = torch.randn_like(ref)
+    torch.cat([F.conv3d(xr[:, 4 * q:4 * q + 4], wr[4 * q:4 * q + 4].view(4, 1, 1, 3, 3), None, 1, (0, dils[q], dils[q]), dils[q], 4)
+               for q in range(CQ)], 1).backward(gy)
+    gl = be.dev(ndhwc(gy))
+    gws = {}
+    for roll in (1, 0):
+        tune("STX_DWCONV_ROLL", roll)
+        ws = be.empty(be.raw("stx_dwconv_hw_wgrad_workspace_floats")(C))
+        gw = be.empty(C, 9)
+        be.call("stx_dwconv_hw_wgrad", ptr(xl), ptr(gl), ptr(dd), ptr(gw), ptr(ws), B, D, H, W, C)
+        _close(gw, wr.grad, rtol=1e-4, atol=1e-4)
+        gws[roll] = gw
+    _close(gws[1], gws[0].cpu(), rtol=1e-5, atol=1e-4)
+
+
 def test_ac_volume_backward(be):
     """Gradients of softmax(att)*concat_volume (acv.py:196) w.r.t. probabilities and features."""
     torch.manual_seed(13)

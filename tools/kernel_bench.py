@@ -103,6 +103,7 @@ AB_SETS = [
     ("s2 march weight gradient: no LDS writes (ablation)", "conv_32_64_s2_L0_wgrad,conv_64_128_s2_L1_wgrad", {"STX_WGRAD_ABLATE": 3}),
     ("weight gradient: no tile staging (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 1}),
     ("weight gradient: no MFMA loop (ablation)", "conv_32_32_L0_wgrad,conv_64_64_L1_wgrad,conv_32_64_s2_L0_wgrad", {"STX_WGRAD_ABLATE": 2}),
+    ("ACVNet patch convolution: cache-fed kernel of rounds 3-4 instead of the rolling window", "dwconv_hw", {"STX_DWCONV_ROLL": 0}),
     ("sampled volume bwd: global atomics only (first version)", "sampled_volume", {"STX_SV_BWD_V1": 1}),
     ("cost volume fwd: first-generation fallback kernel", "cost_volume_fwd", {"STX_CV_OLD": 1}),
     ("cost volume fwd: cache-line pairs through the LDS-DMA slot", "cost_volume_fwd", {"STX_CV_PF": 2}),
@@ -291,6 +292,10 @@ def run_table(a, only_arg, only_exact=False):
         dil = torch.tensor([1, 1, 2, 2, 2, 2, 3, 3, 3, 3], dtype=torch.int32, device=dev)
         ms = timeit(lambda: lib.call("stx_dwconv_hw_fwd", P(x), P(w), P(dil), P(y), B, D0, H0, W0, C, 0, stream()), it)
         report("dwconv_hw_acv_patch_fwd", ms, nbytes=x.numel() * 8)
+        ws = torch.empty(lib.raw("stx_dwconv_hw_wgrad_workspace_floats")(C), device=dev)
+        gw = torch.empty(C, 9, device=dev)
+        ms = timeit(lambda: lib.call("stx_dwconv_hw_wgrad", P(x), P(y), P(dil), P(gw), P(ws), B, D0, H0, W0, C, stream()), it)
+        report("dwconv_hw_acv_patch_wgrad", ms, nbytes=x.numel() * 8)
 
     if want("mish"):
         D0, H0, W0 = L[0]

@@ -95,11 +95,13 @@ ENV_CAP = 0.5        # ... but never more than half the tensor's max: wrong wiri
 
 
 ENV_EPS_WHOLE = 1e-5     # whole-model toy tests: the stock 2-D CNN's features are 1-3e-6 from the oracle's (measured); a perturbation
-ENV_FIELDS_WHOLE = 2     # several times that size reaches a pre-activation MIOpen's noise can push across 0 with probability > 0.8
+ENV_FIELDS_WHOLE = 3     # several times that size reaches a pre-activation MIOpen's noise can push across 0 with probability > 0.8
                          # per antithetic pair instead of ~0.5 -- these tests check wiring, the numbers are pinned by the isolated
                          # and the full-size tests.  (The round-4 driver failure, 18.4 % on ACVNet's dres2.conv4.0.0.weight,
                          # is the jump field 3 reproduces at 3e-6; 3 x the largest response of fields 1-2 there is 16.9 %: one more
-                         # field or a larger reach, not a larger factor, is what makes the bound hold.)
+                         # field or a larger reach, not a larger factor, is what makes the bound hold.  Live example, GPU call V of
+                         # round 5: GwcNet_GC's dres4.redir2.0.weight came out 10.2 x the fp32 oracle's own error -- inside the
+                         # envelope, outside any flat factor used so far.)
 ENV_FIELDS_ISOLATED = 3
 
 

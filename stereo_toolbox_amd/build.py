@@ -58,7 +58,7 @@ def build_hip(force=False, verbose=True, extra_flags=()):
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname,libstx_hip.so", *objs, "-o", LIB])
     return LIB
 
 

@@ -28,8 +28,10 @@ def pytest_collection_modifyitems(config, items):
 
 _FULL_SIZE = ("test_psmnet_config1_eval", "test_cost_volume_full_size_properties", "test_full_size_eval_parity",
               "test_gwcnet_gc_full_size_train_step_parity", "test_acvnet_full_size_train_step_parity")
-_KERNEL_FILES = ("test_capi_symbols.py", "test_kernels.py", "test_f1ops.py", "test_hygiene.py", "test_torch_ext.py", "test_igev_preprocess.py",
+_KERNEL_FILES = ("test_capi_symbols.py", "test_kernels.py", "test_f1ops.py", "test_hygiene.py", "test_igev_preprocess.py",
                  "test_metrics.py")
+_LAST_FILES = ("test_torch_ext.py",)       # the torch.utils.cpp_extension door (8 of the entry points): after everything else, so a
+                                           # build-system problem there can never again keep a model test from running
 _TOY_TRAIN = ("train_grads", "frozen_attention_train", "_train_")          # incl. the isolated (deterministic) hand-written-path tests
 _TOY_TRAIN_WHOLE = ("train_parity", "train_step")                          # whole models incl. the stock 2-D CNN: the very last
 
@@ -41,6 +43,8 @@ def _order_gpu_run(items):
     (tests/test_models.py::_sensitivity); under `-x` one of them must never again keep the headline shapes from running."""
     def phase(item):
         path, name = item.nodeid.split("::")[0], item.name
+        if any(path.endswith(f) for f in _LAST_FILES):
+            return 5
         if any(name.startswith(n) for n in _FULL_SIZE):
             return 1
         if any(path.endswith(f) for f in _KERNEL_FILES):
@@ -51,6 +55,41 @@ def _order_gpu_run(items):
             return 3
         return 2
     items.sort(key=phase)              # stable: the collection order is kept inside a phase
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Per-test wall-clock guard: one stuck test costs minutes, not the run.  Two stages, no plugin needed:
+#   * SIGALRM after STX_TEST_TIMEOUT s (default 240) raises in the test -- covers anything that spins in Python
+#     (torch.utils.file_baton.FileBaton.wait, a rendezvous that never completes): the test FAILS with a traceback;
+#   * faulthandler.dump_traceback_later(+60 s, exit=True) ends the process with every thread's stack on stderr when the
+#     interpreter never gets to run the signal handler (a kernel that does not return inside hipStreamSynchronize).
+TEST_TIMEOUT_S = int(os.environ.get("STX_TEST_TIMEOUT", "240"))
+
+
+class TestTimeout(Exception):
+    pass
+
+
+@pytest.fixture(autouse=True)
+def _wall_clock_guard(request):
+    import faulthandler
+    import signal
+    import threading
+    if TEST_TIMEOUT_S <= 0 or threading.current_thread() is not threading.main_thread() or not hasattr(signal, "SIGALRM"):
+        yield
+        return
+
+    def on_alarm(signum, frame):
+        raise TestTimeout(f"{request.node.nodeid} exceeded {TEST_TIMEOUT_S} s (STX_TEST_TIMEOUT)")
+    old = signal.signal(signal.SIGALRM, on_alarm)
+    signal.alarm(TEST_TIMEOUT_S)
+    faulthandler.dump_traceback_later(TEST_TIMEOUT_S + 60, exit=True)
+    try:
+        yield
+    finally:
+        signal.alarm(0)
+        faulthandler.cancel_dump_traceback_later()
+        signal.signal(signal.SIGALRM, old)
 
 
 @pytest.fixture(scope="session")

@@ -279,3 +279,48 @@ def test_no_test_module_needs_the_reference_tree():
         "print('BAD', bad) if bad else print('OK')\n")
     r = subprocess.run([sys.executable, "-c", code, *mods], cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.stdout.strip().endswith("OK"), (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_no_build_baton_in_the_tree():
+    """a zero-byte `lock` left in stereo_toolbox_amd/lib/torch_ext by an interrupted `cpp_extension.load`
+    travelled to the GPU box and `FileBaton.wait()` spun on it until the driver's 1200 s kill.  The loader no longer builds
+    there (stereo_toolbox_amd/torch_ext.py: per-process scratch directory), and nothing else may leave one behind either."""
+    import os
+    from stereo_toolbox_amd.build import LIBDIR
+    found = []
+    for d, _, files in os.walk(LIBDIR):
+        if os.path.basename(d).startswith("torch_ext.") and _owner_alive(os.path.basename(d)):
+            continue                                         # another live process of this box building right now
+        found += [os.path.join(d, f) for f in files if f == "lock"]
+    assert not found, found
+
+
+def _owner_alive(name):
+    import os
+    try:
+        os.kill(int(name.split(".")[1]), 0)
+        return True
+    except (ValueError, IndexError, OSError):
+        return False
+
+
+def test_loader_ignores_a_foreign_baton(tmp_path):
+    """The `torch.ops.stx` loader neither creates nor honours a lock in lib/torch_ext: with a baton file planted there a fresh
+    process loads the module within a minute (round 5's suite waited on exactly this file for 17 minutes)."""
+    import os
+    import subprocess
+    import sys
+    import stereo_toolbox_amd.torch_ext as tx
+    tx.build()                                               # current module in place (compiles once, in its own scratch dir)
+    d, so, _ = tx._paths()
+    assert tx.is_current() and os.path.exists(so)
+    lock = os.path.join(d, "lock")
+    open(lock, "w").close()
+    try:
+        r = subprocess.run([sys.executable, "-c", "import stereo_toolbox_amd.torch_ext as tx; print(tx.load().build_info())"],
+                           capture_output=True, text=True, timeout=120,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    finally:
+        os.unlink(lock)
+    assert r.returncode == 0 and "gfx950" in r.stdout, r.stderr[-2000:]
+    assert not [n for n in os.listdir(os.path.join(os.path.dirname(d), "obj")) if n.startswith(f"torch_ext.{os.getpid()}.")]

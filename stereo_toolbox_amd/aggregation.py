@@ -166,6 +166,7 @@ def _raw_conv(x, conv, want):
     return ops.ConvRawFn.apply(x, conv.weight, ks, stride, _is_transposed(conv), want)
 
 
+@ops.fp32_region
 def shared_input_convs(x, blocks):
     """Train-mode raw outputs of several `convbn_3d` blocks (nn.Sequential(Conv3d, BatchNorm3d)) reading the SAME activation
     `x`, through one autograd node whose backward accumulates the input gradients inside the producing kernels instead of
@@ -187,6 +188,7 @@ def shared_input_convs(x, blocks):
     return [(outs[2 * k], outs[2 * k + 1]) for k in range(len(blocks))]
 
 
+@ops.fp32_region
 def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=False, leaky=False, raw=None, second_raw=None):
     """One fused block on NDHWC tensors.
     leaky: LeakyReLU(0.01) instead of ReLU (IGEV family, activation code 3 of the kernels).
@@ -251,6 +253,7 @@ def conv_block(x, conv, bn=None, relu=False, second=None, residual=None, mish=Fa
     return ops.BnActFn.apply(z1, bn.weight, bn.bias, None, None, None, residual, relu, st1, None, 1, defer)
 
 
+@ops.fp32_region
 def convbn_block(x, seq, relu=False, second=None, residual=None, mish=False, raw=None, second_raw=None):
     """`seq` = nn.Sequential(conv, bn) as built by convbn_3d (or (ConvTranspose3d, BatchNorm3d))."""
     sec = None

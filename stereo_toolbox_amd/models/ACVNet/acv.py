@@ -123,6 +123,7 @@ class ACVNet(nn.Module):
         with deferred_bn_counters():
             return self._aggregate(gl, gr, H, W, concat_left, concat_right)
 
+    @ops.fp32_region
     def _aggregate(self, gl, gr, H, W, cl=None, cr=None):
         if self.freeze_attn_weights:
             with torch.no_grad():

@@ -223,7 +223,11 @@ class cfnet(nn.Module):
 
     def forward(self, left, right):
         fl, fr = run_pair(self.feature_extraction, left, right, self.training)
-        H, W = left.shape[2], left.shape[3]
+        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+
+    @ops.fp32_region
+    def aggregate(self, fl, fr, H, W):
+        """Everything behind the 2-D feature CNN (cfnet.py:502-640); fp32 also under autocast (ops.fp32_region)."""
         # ---- fused stage at 1/8 with the 1/16 and 1/32 volumes injected (cfnet.py:502-541)
         v4 = self._volume(fl, fr, 4, self.maxdisp // 8)
         v5 = self._volume(fl, fr, 5, self.maxdisp // 16)

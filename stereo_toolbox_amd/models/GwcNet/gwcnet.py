@@ -109,6 +109,7 @@ class GwcNet(nn.Module):
             fl, fr = run_pair(self.feature_extraction, left, right, self.training)
             return self.aggregate(fl, fr, left.shape[2], left.shape[3])
 
+    @ops.fp32_region
     def aggregate(self, fl, fr, H, W):
         """Everything behind the 2-D feature CNN (reference gwcnet.py:175-224): the hand-written part of the model.
         fl / fr: feature dicts of the two views ("gwc_feature" [B,320,H/4,W/4], optionally "concat_feature")."""

@@ -145,6 +145,7 @@ class IGEVCostAggregation(nn.Module):
         self.cost_agg = hourglass(8)
         self.classifier = nn.Conv3d(8, 1, 3, 1, 1, bias=False)
 
+    @ops.fp32_region
     def forward(self, match_left, match_right, features_left):
         """match_*: [B, 96, H/4, W/4]; features_left: the four backbone levels of the left view ([B, 96, H/4, W/4] with the
         stem features concatenated, [B, 64, H/8, W/8], [B, 192, H/16, W/16], [B, 160, H/32, W/32]).

@@ -214,6 +214,11 @@ class PCWNet(nn.Module):
                                "branch (hourglassup expects 128 = 64 + 40 + 24 input channels, pcwnet.py:399-406; "
                                "finetune_feature, :473) and its own forward fails the same way; use PCWNet_GC")
         fl, fr = run_pair(self.feature_extraction, left, right, self.training)
+        return self.aggregate(fl, fr, left.shape[2], left.shape[3])
+
+    @ops.fp32_region
+    def aggregate(self, fl, fr, H, W):
+        """Everything behind the 2-D feature CNN (pcwnet.py:388-500); fp32 also under autocast (ops.fp32_region)."""
         v1 = self._volume(fl, fr, 1, self.maxdisp // 4)
         v2 = self._volume(fl, fr, 2, self.maxdisp // 8)
         v3 = self._volume(fl, fr, 3, self.maxdisp // 16)
@@ -226,7 +231,6 @@ class PCWNet(nn.Module):
         out1 = self.dres2(combine)
         out2 = self.dres3(out1)
         out3 = self.dres4(out2)
-        H, W = left.shape[2], left.shape[3]
 
         def head(seq, x):
             return ops.regression_head(run_classifier(seq, x), self.maxdisp, H, W, align_corners=True)

@@ -71,6 +71,7 @@ class PSMNet(nn.Module):
             fl, fr = run_pair(self.feature_extraction, left, right, self.training)
             return self.aggregate(fl, fr, left.shape[2], left.shape[3])
 
+    @ops.fp32_region
     def aggregate(self, fl, fr, H, W):
         """Hot path: 32-channel features at 1/4 resolution -> disparity at (H, W)."""
         # concat volume built inline in the reference (stackhourglass.py:111-120)

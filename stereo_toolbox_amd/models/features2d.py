@@ -46,6 +46,8 @@ def fused_glue(x, *bns):
         return False
     if x.dtype != torch.float32 or not ops.on_device(x):
         return False
+    if ops.autocast_active():                 # --amp: the 2-D CNN is the caller's to run in fp16 / bf16 -- stock modules end to end
+        return False
     if not all(isinstance(b, nn.modules.batchnorm._BatchNorm) for b in bns):
         return False
     if all(b.training for b in bns):

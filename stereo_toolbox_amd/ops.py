@@ -72,6 +72,43 @@ def _call(name, *args):
         get_lib().call(name, *args, _stream(dev))
 
 
+# ------------------------------------------------------------------------- mixed-precision callers
+_LOW = (torch.float16, torch.bfloat16)
+
+
+def _to_fp32(v):
+    if isinstance(v, torch.Tensor):
+        return v.float() if v.dtype in _LOW else v          # a differentiable cast: the gradient goes back in the caller's dtype
+    if isinstance(v, dict):
+        return {k: _to_fp32(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(_to_fp32(x) for x in v)
+    return v
+
+
+def autocast_active():
+    return torch.is_autocast_enabled("cuda") or torch.is_autocast_enabled("cpu")
+
+
+def fp32_region(fn):
+    """The hot path computes in fp32 (north_star; the reference's own FoundationStereo builds its volume outside autocast for
+    the same reason, FoundationStereo/submodule.py:388-397).  Under `torch.amp.autocast` -- the reference Trainer's `--amp`,
+    trainer/trainer_torchrun.py:219,274,286-294 -- the stock 2-D CNN hands over fp16 / bf16 feature maps: a decorated entry
+    point casts its low-precision tensor arguments (also inside dicts / lists) to fp32 and runs with autocast switched off,
+    like the operators on autocast's own fp32 list; outputs are fp32.  The casts are ordinary autograd nodes, so a
+    `GradScaler`-scaled loss back-propagates through the fp32 kernels and reaches the 2-D CNN in its own dtype.  Outside
+    autocast nothing changes: a low-precision tensor is still refused by `_chk` (there is no fp16 kernel to fall back to)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        if not autocast_active():
+            return fn(*args, **kwargs)
+        with torch.autocast("cuda", enabled=False), torch.autocast("cpu", enabled=False):
+            return fn(*_to_fp32(args), **_to_fp32(kwargs))
+    return wrapped
+
+
 def to_ncdhw(x):
     """[B,D,H,W,C] dense -> logical [B,C,D,H,W] view (channels_last_3d strides, no copy)."""
     return x.permute(0, 4, 1, 2, 3)
@@ -587,6 +624,7 @@ def deconv4_raw(x, w, want_stats):
     return z, (bn_stats(z.detach()) if want_stats else z.new_empty(0))
 
 
+@fp32_region
 def deconv4_forward(x, w, scale=None, bias=None, relu=0, owner=None):
     """Inference path of ConvTranspose3d(k4, s2, p1) with the folded BatchNorm / activation in the convolution epilogue
     (scale / bias repeated per parity class), then the class interleave.  Packed weights cached on `owner`."""
@@ -639,6 +677,7 @@ class GateFn(torch.autograd.Function):
         return gcv, gatt
 
 
+@fp32_region
 def gate(cv, att):
     """cv [B, D, H, W, C] (dense NDHWC) * sigmoid(att [B, H, W, C]) broadcast over D; differentiable."""
     if torch.is_grad_enabled() and (cv.requires_grad or att.requires_grad):
@@ -677,6 +716,7 @@ class ChannelMajorFn(torch.autograd.Function):
         return gx.permute(0, 3, 1, 2)
 
 
+@fp32_region
 def channel_major(x):
     """`x.contiguous()` for a 4-D NCHW-logical tensor: a no-op for NCHW-contiguous input, the transpose kernel for dense
     channels-last fp32 input whose H*W and C are multiples of 4, torch's copy otherwise."""
@@ -718,6 +758,7 @@ class CatChannelsFn(torch.autograd.Function):
         return tuple(outs)
 
 
+@fp32_region
 def cat_channels(parts):
     """Concatenate 2-4 dense channels-last tensors of equal leading shape along their LAST (channel) axis; every width a
     multiple of 4.  Differentiable."""
@@ -742,6 +783,7 @@ def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentu
     return list(out.unbind(0)) if groups > 1 else list(out[:, 0].unbind(0))   # scale, shift, mean, invstd
 
 
+@fp32_region
 def bn_stats(z, groups=1):
     """Per-workgroup (sum, sum of squares) rows of a dense channels-last activation [..., C] -> [rows, 2, C]
     ([groups, rows, 2, C] for groups > 1: the leading axis of z splits into `groups` equal slabs with their own
@@ -774,6 +816,7 @@ def _sync_bn_partials(partials, count, group, world):
     return torch.stack((hi, lo)).contiguous(), count * world
 
 
+@fp32_region
 def bn_apply(z1, scale1, shift1, z2=None, scale2=None, shift2=None, relu=False, groups=1):
     out = torch.empty_like(z1)
     C = z1.shape[-1]
@@ -893,7 +936,9 @@ class BnActFn(torch.autograd.Function):
         if ctx.has_res and not ctx.relu:
             gres = gy
         tot = sums_all[G] if G > 1 else sums_all[0]       # gamma / beta are shared between the groups
-        return (dz1, tot[1], tot[0], dz2, tot[2] if ctx.two else None, tot[0] if ctx.two else None, gres,
+        # (beta2's gradient equals beta1's; it gets its OWN memory: two parameters whose .grad alias one buffer are scaled twice
+        # by every in-place pass over the gradients -- GradScaler.unscale_, clip_grad_norm_ -- found by tests/test_amp.py)
+        return (dz1, tot[1], tot[0], dz2, tot[2] if ctx.two else None, tot[0].clone() if ctx.two else None, gres,
                 None, None, None, None, None)
 
 
@@ -919,6 +964,7 @@ class MishFn(torch.autograd.Function):
         return gx
 
 
+@fp32_region
 def mish(x):
     """Mish on a dense fp32 tensor with numel % 4 == 0 (every channels-last activation of these models)."""
     if torch.is_grad_enabled() and x.requires_grad:
@@ -940,6 +986,7 @@ def _cv_shapes(Lg, Lc, num_groups):
     return B, H, W, Cg, G, Cc
 
 
+@fp32_region
 def cost_volume_forward(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True, scale=None):
     for n, t in (("ref gwc", Lg), ("tgt gwc", Rg), ("ref concat", Lc), ("tgt concat", Rc)):
         _chk(t, n, 4)
@@ -979,6 +1026,7 @@ class CostVolumeFn(torch.autograd.Function):
         return gLg, gRg, gLc, gRc, None, None, None
 
 
+@fp32_region
 def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
     ts = [channel_major(t) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
@@ -1016,6 +1064,7 @@ class SampledVolumeFn(torch.autograd.Function):
         return gLg, gRg, gLc, gRc, None, None
 
 
+@fp32_region
 def sampled_volume(Lg, Rg, Lc, Rc, samples, num_groups):
     """Cascade-stage cost volume from per-pixel disparity hypotheses `samples` [B, S, H, W] (integer-valued floats, no
     gradient): see include/stx_hip.h.  The channel axis is padded with zeros to a multiple of 8; `conv_block` accepts
@@ -1062,6 +1111,7 @@ class WarpFn(torch.autograd.Function):
         return gx, gd
 
 
+@fp32_region
 def warp(x, disp):
     """x [B,C,H,W] sampled at column w - disp[B,1,H,W] (bilinear, the reference's grid), zeroed where the footprint leaves
     the image.  Differentiable in x and disp like the reference."""
@@ -1098,6 +1148,7 @@ class CorrVolumeFn(torch.autograd.Function):
         return gr, gt, None, None
 
 
+@fp32_region
 def corr_volume(ref, tgt, maxdisp, groups):
     """[B,C,H,W] x 2 -> [B, groups, 2*maxdisp+1, H, W] (see include/stx_hip.h for the slice semantics)."""
     ref, tgt = ref.contiguous(), tgt.contiguous()
@@ -1138,6 +1189,7 @@ class DisparityVarianceFn(torch.autograd.Function):
         return gx, gd, gs
 
 
+@fp32_region
 def disparity_variance(x, disp, samples=None):
     """sum_d x_d (d - disp)^2 (samples None) or sum_d x_d (disp - samples_d)^2 -> [B,1,H,W]."""
     x, disp = x.contiguous(), disp.contiguous()
@@ -1184,6 +1236,7 @@ class AcVolumeFn(torch.autograd.Function):
         return gL, gR, gprob, None
 
 
+@fp32_region
 def ac_volume(Lc, Rc, prob, maxdisp):
     Lc, Rc, prob = Lc.contiguous(), Rc.contiguous(), prob.contiguous()
     if torch.is_grad_enabled() and (Lc.requires_grad or Rc.requires_grad or prob.requires_grad):
@@ -1220,6 +1273,7 @@ class DwConvHWFn(torch.autograd.Function):
         return gx, gw, None
 
 
+@fp32_region
 def dwconv_hw(x, w, dil):
     w = w.contiguous()
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
@@ -1264,6 +1318,7 @@ class HeadFn(torch.autograd.Function):
         return gc, None, None, None, None
 
 
+@fp32_region
 def regression_head(cost, maxdisp, H, W, align_corners=False):
     """cost [B, D', H', W'] (or [B,1,D',H',W'] / NDHWC with C=1) -> disparity [B, H, W]."""
     if cost.dim() == 5:
@@ -1280,6 +1335,7 @@ def _squeeze_c(cost):
     raise StxError(f"regression_head: expected a single-channel cost, got {tuple(cost.shape)}")
 
 
+@fp32_region
 def softargmax(x, maxdisp, keepdim):
     """sum_d d * x[b,d,h,w] (disparity_regression / disparityregression / softargmax estimator)."""
     assert len(x.shape) == 4   # reference models/GwcNet/submodule.py:24
@@ -1312,6 +1368,7 @@ class _SoftArgmaxFn(torch.autograd.Function):
         return g.unsqueeze(1) * d
 
 
+@fp32_region
 def argmax_disparity(x):
     _chk(x.contiguous(), "x", 4)
     x = x.contiguous()
@@ -1361,12 +1418,14 @@ def _modal_estimator(kind, x, maxdisp):
     return out
 
 
+@fp32_region
 def unimodal_disparity(x, maxdisp):
     """Expectation over the mode containing the arg-max (unimodal_disparity_estimator.py:4-25) -> [B,1,H,W];
     differentiable w.r.t. x inside the (constant) mode mask, like the reference."""
     return _modal_estimator(0, x, maxdisp)
 
 
+@fp32_region
 def dominant_modal_disparity(x, maxdisp):
     """Expectation over the heavier of the two main modes of the blurred volume
     (dominant_modal_disparity_estimator.py:35-54) -> [B,1,H,W]; differentiable like the reference."""
@@ -1392,6 +1451,7 @@ class _SplitModeFn(torch.autograd.Function):
         return g * mask
 
 
+@fp32_region
 def split_mode(x, maxdisp=192):
     """(mode, mask) of loss_functions/split_mode.py:9-35: the support of the mode around the per-pixel arg-max of the
     probability volume x [B, D, H, W] (twin of the modal estimators' mask, on the raw volume) as a bool tensor, and
@@ -1409,6 +1469,7 @@ def split_mode(x, maxdisp=192):
     return mode, mask
 
 
+@fp32_region
 def softmax_over_d(x):
     """x [B, D, H, W] -> softmax over D."""
     _chk(x, "x", 4)

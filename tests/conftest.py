@@ -37,10 +37,10 @@ _TOY_TRAIN_WHOLE = ("train_parity", "train_step")                          # who
 
 
 def _order_gpu_run(items):
-    """Order of a run on a GPU box (the driver's round-end `pytest -x -m gpu`): kernel tests -> the five
-    BASELINE.json full-size configurations -> everything else -> the train-step tests at toy shapes last.  Those normalise
-    over a few hundred voxels per channel at the 1/16 level and are the least well-conditioned comparisons of the suite
-    (tests/test_models.py::_sensitivity); under `-x` one of them must never again keep the headline shapes from running."""
+    """Order of a run on a GPU box (the driver's round-end `pytest -x -m gpu`): kernel tests -> the five BASELINE.json
+    full-size configurations -> everything else -> the small-shape train-step tests -> the torch.utils.cpp_extension door.
+    Under `-x` nothing may keep the headline shapes from running (round 4: an ill-conditioned 64x128 train test; round 5: a
+    build baton).  The small-shape train tests now run at 128x256 against reference fixtures (tests/test_models.py)."""
     def phase(item):
         path, name = item.nodeid.split("::")[0], item.name
         if any(path.endswith(f) for f in _LAST_FILES):

@@ -255,7 +255,10 @@ def _plain_reference(ctor, *a, **k):
     return want, stats, noise
 
 
-def _gpu_step(model, Hh=64, Ww=128, Dd=64, B=1):
+TOY_D = 128     # the GPU smoke steps run at the fixture tests' well-conditioned shape (tests/golden/toy_train_config.py)
+
+
+def _gpu_step(model, Hh=128, Ww=256, Dd=TOY_D, B=2):
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi
     from stereo_toolbox_amd.utils import synthetic_tensor
     left, right = synthetic_tensor((B, 3, Hh, Ww), 1).cuda(), synthetic_tensor((B, 3, Hh, Ww), 2).cuda()
@@ -275,10 +278,10 @@ def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1, parity_lo
     1-rank result."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     torch.backends.cudnn.benchmark = False
-    want, want_stats, noise = _plain_reference("GwcNet_GC", 64)
+    want, want_stats, noise = _plain_reference("GwcNet_GC", TOY_D)
 
     for convert in (False, True):
-        m = _filled_model("GwcNet_GC", 64).cuda()
+        m = _filled_model("GwcNet_GC", TOY_D).cuda()
         if convert:
             m = nn.SyncBatchNorm.convert_sync_batchnorm(m)
         ddp = DDP(m.train(), device_ids=[0], output_device=0, find_unused_parameters=False)
@@ -300,8 +303,8 @@ def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1, parity_lo
     starts at the outputs of the custom Functions."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     torch.backends.cudnn.benchmark = False
-    want, _, noise = _plain_reference("ACVNet", 64, attn_weights_only=True)
-    m = _filled_model("ACVNet", 64, attn_weights_only=True).cuda().train()
+    want, _, noise = _plain_reference("ACVNet", TOY_D, attn_weights_only=True)
+    m = _filled_model("ACVNet", TOY_D, attn_weights_only=True).cuda().train()
     ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True)
     _gpu_step(ddp)
     torch.cuda.synchronize()
@@ -317,9 +320,9 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
     through RCCL."""
     from stereo_toolbox_amd.distributed import FlatGradSync
     torch.backends.cudnn.benchmark = False
-    want, _, noise = _plain_reference("GwcNet_GC", 64)
+    want, _, noise = _plain_reference("GwcNet_GC", TOY_D)
     from stereo_toolbox_amd.distributed import broadcast_parameters
-    m = _filled_model("GwcNet_GC", 64).cuda().train()
+    m = _filled_model("GwcNet_GC", TOY_D).cuda().train()
     before = {k: v.clone() for k, v in m.state_dict().items()}
     broadcast_parameters(m)                            # the flat per-dtype broadcasts (fp32 and int64 buffers) over RCCL
     torch.cuda.synchronize()

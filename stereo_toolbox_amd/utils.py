@@ -44,13 +44,20 @@ def synthetic_modal_volume(B, D, H, W, seed):
     return x / x.sum(1, keepdim=True)
 
 
-def fill_state_dict(sd, seed=1234, head_gain=4.0, gain2d=0.5, gain3d=0.85):
+def fill_state_dict(sd, seed=1234, head_gain=4.0, gain2d=0.5, gain3d=0.85, bn_beta_shift=0.0):
     """In-place deterministic fill of a model state-dict: He-like uniform conv/linear
     weights, BN gamma in [0.5,1.5), beta / running_mean in +-0.1, running_var in [0.5,1.5).
     `head_gain` scales the single-channel classifier convs (`classif*.2.weight`) so that the
     softmax over disparities is moderately peaky (random nets otherwise regress ~ (D-1)/2
     everywhere and hide errors; much larger gains turn the head into an argmax whose output flips
-    by whole bins on fp32 rounding noise)."""
+    by whole bins on fp32 rounding noise).
+    `bn_beta_shift` is added to every BatchNorm beta (a 1-D `.bias` with a `running_mean` beside it).  With zero-mean betas a
+    random-weight stack of ~55 conv + batch-stat BatchNorm + ReLU layers is in the chaotic regime: its train-step GRADIENTS
+    respond to a 1e-6 relative input change by 1-3 % of a tensor's max at any test size (measured round 6,
+    tools/toy_grad_attribution.py), so two correct fp32 implementations differ by that much.  A shift of 1.0 keeps ~84 % of the
+    pre-activations on ReLU's linear side; the reference's own fp32-vs-fp64 gradient distance drops from 2e-3 (median) / 1.5e-2
+    (worst tensor) to 3e-5 / 3e-4 of a tensor's max, which is what lets the train-step tests hold flat tolerances
+    (tests/golden/toy_train_config.py).  Default 0: every other fixture and the benchmark weights are unchanged."""
     for name in sorted(sd.keys()):
         t = sd[name]
         if name.endswith("num_batches_tracked"):
@@ -65,6 +72,8 @@ def fill_state_dict(sd, seed=1234, head_gain=4.0, gain2d=0.5, gain3d=0.85):
             v = 0.5 + u
         elif t.dim() == 1:
             v = 0.1 * (2 * u - 1)
+            if bn_beta_shift and name.endswith(".bias") and (name[:-4] + "running_mean") in sd:
+                v = v + bn_beta_shift
         else:
             # gains chosen so that activations stay O(1) through the ~25 residual 2-D blocks and the
             # ~30 3-D layers with these (un-calibrated) BN statistics

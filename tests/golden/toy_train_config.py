@@ -6,6 +6,18 @@ B, H, W, D = 2, 128, 256, 128          # 1/16 level: D/16 * H/16 * W/16 * B = 8 
 LOSS_W = (0.5, 0.5, 0.7, 1.0)
 STRIDE = 4                             # stored prediction maps: every 4th pixel
 SAMPLES = 2048                         # stored gradient samples per tensor
+BN_BETA_SHIFT = 1.0                    # filler profile of these fixtures (stereo_toolbox_amd.utils.fill_state_dict): a well-conditioned
+                                       # train step -- the reference's own fp32 gradients are 3e-5 (median) of a tensor's max from fp64
+PCW = dict(B=2, H=128, W=256, D=64, LOSS_W=(0.5, 0.5, 0.5, 0.7, 1.0, 1.3))   # PCWNet_GC whole-model fixture (6 train-mode outputs)
+
+
+def fill(module):
+    """The fixtures' weights: deterministic filler with the shifted BatchNorm betas, loaded into `module`."""
+    from stereo_toolbox_amd.utils import fill_state_dict
+    sd = module.state_dict()
+    fill_state_dict(sd, bn_beta_shift=BN_BETA_SHIFT)
+    module.load_state_dict(sd)
+    return module
 
 
 def feature_maps(kind):

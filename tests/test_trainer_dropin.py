@@ -231,12 +231,12 @@ def _same_grads(named_params, want, noise, what, parity_log=None):
     if parity_log is not None:
         parity_log(what, tensors=n, bitwise_equal=n_exact, worst_rel_2d_cnn=worst["2d"], worst_rel_3d_path=worst["3d"],
                    plain_run_to_run_2d=noise["2d"], plain_run_to_run_3d=noise["3d"])
-    # floor 25 % (round 5; was 10 %): the toy configurations JUMP -- ACVNet's attention-only step moved a tensor by 9.5 % between
-    # two plain runs (calls E / N of round 5) and its full form has an 18.4 % jump (tests/test_models.py::_sensitivity).  This
-    # check is the smoke test (a dropped / doubled / mis-scaled gradient is off by O(1)); the EXACT one is
+    # floor 5 % (round 6; rounds 4-5: 10 % -> 25 % at the chaotic 64x128 toy configuration).  The smoke steps now run at the
+    # fixture tests' shape and weight profile (B=2 128x256 D=128, shifted BatchNorm betas): two plain runs differ by 0.3-2.2 %
+    # (2-D CNN tensors) / 0.03-0.7 % (3-D path) over the calls of round 6.  The EXACT check is
     # test_ddp_and_flat_sync_are_exact_behind_fixed_features_rccl_world1 below (bitwise, no stock 2-D CNN in the graph).
     for k in ("2d", "3d"):
-        assert worst[k] <= max(5.0 * noise[k], 0.25), (what, k, worst[k], noise[k])
+        assert worst[k] <= max(5.0 * noise[k], 0.05), (what, k, worst[k], noise[k])
     return n_exact, n
 
 

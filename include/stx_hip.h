@@ -38,9 +38,17 @@ int stx_set_tuning(const char* name, int value);
  * torch.cat((gwc, concat), 1)               models/GwcNet/gwcnet.py:180 (fused)
  * softmax(att, dim=2) * concat_volume       models/ACVNet/acv.py:196 (`scale` = softmax probabilities [B][D][H][W], or NULL)
  * vol: [B][D][H][W][G + 2*Cc].  Lg/Rg: [B][Cg][H][W] (NULL when G == 0); Lc/Rc: [B][Cc][H][W] (NULL when Cc == 0).
- * Requires Cg % G == 0 (reference assert submodule.py:46), Cg/G in {4,8,16}, G % 4 == 0, Cc % 4 == 0. */
+ * Requires Cg % G == 0 (reference assert submodule.py:46), Cg/G in {4,8,12,16} (and 20 / 28 with 4..16 groups: FoundationStereo's
+ * 160 / 224-channel maps in 8 groups), G % 4 == 0, Cc % 4 == 0. */
 int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int G, const float* Lc, const float* Rc, int Cc,
                         const float* scale, float* vol, int B, int H, int W, int D, int mask_left, void* stream);
+/* Per-pixel, per-group L2 normalisation of an NCHW map, the pre-pass of FoundationStereo's normalised group-wise correlation
+ * (models/FoundationStereo/submodule.py:388-397: F.normalize(fea.float(), dim=2) on [B,G,C/G,H,W], eps 1e-12, group SUM):
+ * y[b][c][p] = out_scale * x[b][c][p] / max(||x[b][group of c][p]||_2, 1e-12).  The normalised volume (:399-413) is
+ * stx_cost_volume_fwd of the two normalised maps with out_scale = C/G on the left one (group mean x C/G = group sum).
+ * x, y, gy, gx: [B][C][HW]; C % G == 0 (reference assert :390). */
+int stx_group_normalize_fwd(const float* x, float* y, int B, int C, int G, int HW, float out_scale, void* stream);
+int stx_group_normalize_bwd(const float* x, const float* gy, float* gx, int B, int C, int G, int HW, float out_scale, void* stream);
 /* autograd backward of the above (no `scale`): gvol [B][D][H][W][G+2Cc] -> gLg,gRg [B][Cg][H][W], gLc,gRc [B][Cc][H][W] */
 int stx_cost_volume_bwd(const float* gvol, const float* Lg, const float* Rg, int Cg, int G, int Cc, float* gLg,
                         float* gRg, float* gLc, float* gRc, int B, int H, int W, int D, int mask_left, void* stream);

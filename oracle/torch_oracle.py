@@ -65,6 +65,34 @@ def build_concat_volume(ref, tgt, maxdisp, mask_left=True):
     return torch.cat((left, right), dim=1).contiguous()
 
 
+def fs_groupwise_correlation(fea1, fea2, num_groups):
+    """FoundationStereo/submodule.py:388-397: per-group cosine similarity -- both maps L2-normalised over each group's
+    channels (F.normalize(dim=2), eps 1e-12, fp32), products SUMMED over the group."""
+    B, C, H, W = fea1.shape
+    assert C % num_groups == 0
+    cpg = C // num_groups
+    a = F.normalize(fea1.reshape(B, num_groups, cpg, H, W).float(), dim=2)
+    b = F.normalize(fea2.reshape(B, num_groups, cpg, H, W).float(), dim=2)
+    return (a * b).sum(dim=2)
+
+
+def fs_build_gwc_volume(ref, tgt, maxdisp, num_groups):
+    """FoundationStereo/submodule.py:399-413.  The norm of a pixel's group does not depend on the disparity: normalise both
+    maps once, shift the right one (gather form, as build_gwc_volume above), sum the products."""
+    B, C, H, W = ref.shape
+    assert C % num_groups == 0
+    cpg = C // num_groups
+    a = F.normalize(ref.reshape(B, num_groups, cpg, H, W).float(), dim=2).reshape(B, C, H, W)
+    b = F.normalize(tgt.reshape(B, num_groups, cpg, H, W).float(), dim=2).reshape(B, C, H, W)
+    shifted, _ = _shift_right(b, maxdisp)
+    return (a.unsqueeze(2) * shifted).view(B, num_groups, cpg, maxdisp, H, W).sum(dim=2)
+
+
+def fs_build_concat_volume(ref, tgt, maxdisp):
+    """FoundationStereo/submodule.py:416-427: the left half is the left map at every disparity (not masked)."""
+    return build_concat_volume(ref, tgt, maxdisp, mask_left=False)
+
+
 # ----------------------------------------------------------------------------- regression head
 def disparity_regression(x, maxdisp, keepdim=False):
     """GwcNet/submodule.py:23-27 (keepdim=False); PSMNet/submodule.py:46-54 and

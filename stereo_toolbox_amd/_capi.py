@@ -26,6 +26,9 @@ SIGNATURES = {
     # cost_volume.hip
     "stx_cost_volume_fwd": [_P, _P, _I, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_cost_volume_bwd": [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    # group_normalize.hip
+    "stx_group_normalize_fwd": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "stx_group_normalize_bwd": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     # head.hip
     "stx_head_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_head_bwd_workspace_floats": [_I, _I, _I, _I],

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(CV_THREADS) void cost_volume_bwd_kernel(
     float* gout = right ? gRg : gLg;
 
     // ---- gwc channels
-    // `pass` <= CVB_CH channels per sweep over the disparities: a whole number of group quads (host: 160 for 4 or 8
-    // channels per group, 144 for 12, 128 for 16)
+    // `pass` <= CVB_CH channels per sweep over the disparities: a whole number of group quads (host: 160 for 4, 8 or
+    // 20 channels per group, 144 for 12, 128 for 16, 112 for 28)
     for (int c0 = 0; c0 < Cg; c0 += pass) {
         const int nch = (Cg - c0 < pass) ? (Cg - c0) : pass;
         const int g0 = c0 / cpg, ng = nch / cpg;           // groups of this pass (ng <= 40)
@@ -369,12 +369,14 @@ extern "C" int stx_cost_volume_fwd(const float* Lg, const float* Rg, int Cg, int
     }
     if (Cc) STX_REQUIRE(Lc && Rc, "cost_volume_fwd: concat features missing");
     const int cpg = G ? Cg / G : 4;
-    STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16, "cost_volume_fwd: channels per group %d not in {4,8,12,16}", cpg);
+    STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16 || cpg == 20 || cpg == 28,
+                "cost_volume_fwd: channels per group %d not in {4,8,12,16,20,28}", cpg);
     {   // second-generation builder (MFMA correlation, LDS-staged voxels): serves every configuration it accepts
         const int rc = stx_cv_fwd_mfma(Lg, Rg, Cg, G, Lc, Rc, Cc, scale, vol, B, H, W, D, mask_left, stream);
         if (rc >= 0) return rc;
     }
-    STX_REQUIRE(cpg != 12, "cost_volume_fwd: 12 channels per group are served by the MFMA builder only (D' <= 96, voxels of <= 64 channels)");
+    STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 16, "cost_volume_fwd: %d channels per group are served by the MFMA builder only (D' <= 96, "
+                "voxels of <= 64 channels; 20 / 28 per group: 4..16 groups)", cpg);
     // disparities per workgroup: split D evenly into chunks of <= 24 (two workgroups per CU for the
     // 320-channel gwc features: (16 + 16+24-1) columns x 1296 B = 71 KB of LDS each)
     const int nchunk = stx_cdiv(D, 24);
@@ -418,7 +420,8 @@ extern "C" int stx_cost_volume_bwd(const float* gvol, const float* Lg, const flo
     if (G) {
         STX_REQUIRE(Lg && Rg && gLg && gRg && Cg % G == 0, "cost_volume_bwd: gwc operands missing");
         const int cpg = Cg / G;
-        STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16, "cost_volume_bwd: channels per group %d not in {4,8,12,16}", cpg);
+        STX_REQUIRE(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16 || cpg == 20 || cpg == 28,
+                    "cost_volume_bwd: channels per group %d not in {4,8,12,16,20,28}", cpg);
     }
     if (Cc) STX_REQUIRE(gLc && gRc, "cost_volume_bwd: concat outputs missing");
     if (G) {      // second generation: matrix-core kernel with loader waves (cost_volume_bwd_mfma.hip); -1 = not served

@@ -444,7 +444,9 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
                     const float* scale, float* vol, int B, int H, int W, int D, int mask_left, void* stream) {
     if (stx_tune(STX_TUNE_CV_OLD)) return -1;
     const int cpg = G ? Cg / G : 8;
-    if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
+    const bool wide = cpg == 20 || cpg == 28;             // FoundationStereo's 160 / 224 channels in 8 groups (vitb / vitl)
+    if (!(cpg == 4 || cpg == 8 || cpg == 12 || cpg == 16 || wide) || Cc > CVM_MAXCC || (G & 3) || (Cc & 3)) return -1;
+    if (wide && (G < 4 || G > 16)) return -1;
     const int CT = G + 2 * Cc, Q = CT / 4, GQ = G / 4;
     if (scale && G) return -1;                            // the attention scale comes with concat-only volumes (acv.py:196)
     if (Q < 1 || Q > 16) return -1;                       // voxels of <= 64 channels (store-wave slot table)
@@ -469,6 +471,7 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     a.nontemporal = 1;
     a.by_units = stx_tune(STX_TUNE_CV_UNITS) != 0;
     int pf = stx_tune(STX_TUNE_CV_PF) == 1 || stx_tune(STX_TUNE_CV_PF) == 2 ? stx_tune(STX_TUNE_CV_PF) : CVM_PF_DEFAULT;
+    if (wide) pf = 1;
     // PF = 2 keeps one tile per compute wave in an LDS slot (2 KiB per quad and 4 channels of a group): taken when it fits beside the images
     const int ncw = GQ <= 4 ? 4 : (GQ <= 10 ? 10 : 8), qpw = GQ <= 10 ? 1 : 2;
     const size_t slots = (size_t)ncw * qpw * 8 * (cpg / 4) * 64 * 4;
@@ -498,6 +501,14 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
         if (nd <= 3) CVM_LAYOUT(CPG_, 3) else CVM_LAYOUT(CPG_, 6) \
     }
     CVM_CASE(4) CVM_CASE(8) CVM_CASE(12) CVM_CASE(16)
+    // 20 / 28 channels per group: 4 .. 16 groups (one compute wave per group quad), the one-tile-ahead prefetch only
+#define CVM_WIDE(CPG_)                                                                             \
+    if (cpg == CPG_) {                                                                             \
+        if (nd <= 3) return cvm_launch<CPG_, 1, 4, 4, 3, false, 1>(a, wgs, lds, st);               \
+        return cvm_launch<CPG_, 1, 4, 4, 6, false, 1>(a, wgs, lds, st);                            \
+    }
+    CVM_WIDE(20) CVM_WIDE(28)
+#undef CVM_WIDE
 #undef CVM_CASE
 #undef CVM_LAYOUT
 #undef CVM_GWC

@@ -1,4 +1,5 @@
-"""The cost-volume entry of the IGEV family (IGEV-Stereo, and with the same call MonSter / FoundationStereo) on the HIP
+"""The cost-volume entry of the IGEV family (IGEV-Stereo, and with the same call MonSter, MonSter/submodule.py:151-171;
+FoundationStereo's volume is a DIFFERENT function -- per-group cosine similarity -- and lives in models/FoundationStereo) on the HIP
 kernels -- drop-in functions of reference models/IGEVStereo/submodule.py plus the two lines of
 `IGEVStereo.forward` that sit on the hot path (igev_stereo.py:206 and :211-212).  The 3-D regularisation between them
 (`corr_stem`, `corr_feature_att`, `cost_agg` = hourglass(8), `classifier`) is in aggregation.py; the rest of those models

@@ -7,6 +7,7 @@ from .ACVNet import ACVNet  # noqa: F401
 from .PCWNet import PCWNet_G, PCWNet_GC  # noqa: F401
 from .CFNet import CFNet  # noqa: F401
 from . import IGEVStereo  # noqa: F401  (initial-volume entry points only)
+from . import FoundationStereo  # noqa: F401  (normalised initial volume only)
 
 
 def load_checkpoint_flexible(model, checkpoint_path, state_dict_key=None):

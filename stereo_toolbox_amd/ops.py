@@ -1026,8 +1026,46 @@ class CostVolumeFn(torch.autograd.Function):
         return gLg, gRg, gLc, gRc, None, None, None
 
 
+class GroupNormalizeFn(torch.autograd.Function):
+    """y = out_scale * x / max(||x||_2 over each group's channels, 1e-12), per pixel (stx_group_normalize_fwd / _bwd):
+    F.normalize(x.view(B, G, C/G, H, W), dim=2) of FoundationStereo's group-wise correlation (submodule.py:388-397)."""
+
+    @staticmethod
+    def forward(ctx, x, num_groups, out_scale):
+        x = x.contiguous()
+        _chk(x, "x", 4)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        _call("stx_group_normalize_fwd", _p(x), _p(y), B, C, num_groups, H * W, float(out_scale))
+        ctx.save_for_backward(x)
+        ctx.cfg = (num_groups, float(out_scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _call("stx_group_normalize_bwd", _p(x), _p(gy), _p(gx), B, C, ctx.cfg[0], H * W, ctx.cfg[1])
+        return gx, None, None
+
+
 @fp32_region
-def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True):
+def group_normalize(x, num_groups, out_scale=1.0):
+    """[B, C, H, W] -> every group of C / num_groups channels scaled to unit L2 norm at every pixel (times out_scale)."""
+    assert x.dim() == 4 and x.shape[1] % num_groups == 0, f"C:{x.shape[1]}, num_groups:{num_groups}"   # submodule.py:390
+    return GroupNormalizeFn.apply(channel_major(x), num_groups, out_scale)
+
+
+@fp32_region
+def cost_volume(Lg, Rg, Lc, Rc, maxdisp, num_groups, mask_left=True, normalize=False):
+    """normalize=True: FoundationStereo's volume (submodule.py:388-413) -- cosine similarity per group (unit-norm groups,
+    group SUM): the two gwc maps go through group_normalize first, the left one scaled by C/G so that the builder's group
+    mean is the sum."""
+    if normalize and Lg is not None:
+        Lg = group_normalize(Lg, num_groups, float(Lg.shape[1] // num_groups))
+        Rg = group_normalize(Rg, num_groups, 1.0)
     ts = [channel_major(t) if t is not None else None for t in (Lg, Rg, Lc, Rc)]
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
         return CostVolumeFn.apply(*ts, maxdisp, num_groups, mask_left)

@@ -111,6 +111,7 @@ class deferred_bn_counters:
 
     def __enter__(self):
         self._state().active += 1
+        ops.bn_defer_reset_if_stale()        # a model forward outside any backward pass: nothing can be legitimately outstanding
         return self
 
     def __exit__(self, *exc):

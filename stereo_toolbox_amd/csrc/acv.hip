@@ -478,6 +478,21 @@ __global__ __launch_bounds__(ACV_THREADS) void scale_channels_kernel(const float
 
 constexpr int ACV_WGRAD_BLOCKS = 1024;
 
+// Dynamic LDS above 64 KiB needs the kernel's MaxDynamicSharedMemorySize attribute raised.  Asked once per kernel and size
+// (not on every launch); a refusal -- a device or partition mode with less LDS than gfx950's 160 KiB -- makes the caller take
+// the cache-fed kernel instead of failing.
+bool acv_lds_granted(const void* kern, size_t lds, int& granted) {
+    if (lds <= 64 * 1024 || (int)lds <= granted) return true;
+    if (granted < 0) return false;                                   // refused before
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        (void)hipGetLastError();
+        granted = -1;
+        return false;
+    }
+    granted = (int)lds;
+    return true;
+}
+
 int acv_grid(size_t n) {
     size_t g = (n + ACV_THREADS - 1) / ACV_THREADS;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -506,10 +521,8 @@ extern "C" int stx_dwconv_hw_fwd(const float* x, const float* w, const int* dil,
             if (nseg > H / 8) nseg = H / 8 > 0 ? H / 8 : 1;          // a segment re-stages 6 halo rows: keep it >= 8 rows
             const int seg_rows = stx_cdiv(H, nseg);
             nseg = stx_cdiv(H, seg_rows);
-            if (lds > 64 * 1024 &&
-                hipFuncSetAttribute((const void*)dwconv_hw_roll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return stx_set_error(STX_ERR_LAUNCH, "dwconv_hw_fwd: %d bytes of dynamic LDS refused by this device", (int)lds);
-            if (base * nseg < (1ll << 31)) {
+            static int granted = 0;
+            if (base * nseg < (1ll << 31) && acv_lds_granted((const void*)dwconv_hw_roll_kernel, lds, granted)) {
                 hipLaunchKernelGGL(dwconv_hw_roll_kernel, dim3((unsigned)(base * nseg)), dim3(ACV_THREADS), lds, (hipStream_t)stream, a,
                                    TW, nstrips, nseg, seg_rows);
                 return stx_check_launch("dwconv_hw_fwd(roll)");
@@ -538,15 +551,16 @@ extern "C" int stx_dwconv_hw_wgrad(const float* x, const float* gy, const int* d
         const size_t red = (size_t)36 * ACV_THREADS * sizeof(float);
         if (lds < red) lds = red;
         const long long base = (long long)B * D * nstrips;
-        if (stx_tune(STX_TUNE_DWCONV_ROLL) && lds <= 160 * 1024 && EW * (C / 4) <= 4 * ACV_THREADS && H >= 8 && base <= ACV_WGRAD_BLOCKS) {
+        // (base > ACV_WGRAD_BLOCKS -- more (plane, strip) items than partial rows of the workspace, e.g. B >= 5 at 576x960 -- takes
+        //  the cache-fed kernel below: about twice the time per launch, profiles/r05_dwconv_rolling_window_ab_callU.txt)
+        static int granted = 0;
+        if (stx_tune(STX_TUNE_DWCONV_ROLL) && lds <= 160 * 1024 && EW * (C / 4) <= 4 * ACV_THREADS && H >= 8 && base <= ACV_WGRAD_BLOCKS &&
+            acv_lds_granted((const void*)dwconv_hw_wgrad_roll_kernel, lds, granted)) {
             int nseg = (int)(ACV_WGRAD_BLOCKS / base);
             if (nseg > H / 8) nseg = H / 8;
             if (nseg < 1) nseg = 1;
             const int seg_rows = stx_cdiv(H, nseg);
             nseg = stx_cdiv(H, seg_rows);
-            if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)dwconv_hw_wgrad_roll_kernel,
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return stx_set_error(STX_ERR_LAUNCH, "dwconv_hw_wgrad: %d bytes of dynamic LDS refused by this device", (int)lds);
             nrows = (int)(base * nseg);
             hipLaunchKernelGGL(dwconv_hw_wgrad_roll_kernel, dim3(nrows), dim3(ACV_THREADS), lds, st, x, gy, dil, workspace, H, W, C, TW,
                                nstrips, nseg, seg_rows);

@@ -26,7 +26,8 @@ constexpr int R2_THREADS = 256;
 struct WarpTap {
     float w[4];        // bilinear weights nw, ne, sw, se (torch's grid_sample formulas)
     int off[4];        // element offsets inside one channel plane; -1 = outside the image
-    float mask;        // 1 if the in-image weights sum to >= 0.999 (PCWNet/submodule.py:171-174), else 0
+    float mask;        // 1 if the in-image weights sum to >= 0.999 (PCWNet/submodule.py:171-174), else 0; NaN for a NaN disparity
+                       // (the reference's `mask < 0.999` and `mask > 0` are both false there: output * mask stays NaN)
     float dwx[4];      // d weight / d ix
 };
 
@@ -50,12 +51,12 @@ __device__ __forceinline__ WarpTap warp_tap(float disp, int x, int y, int H, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-        const bool in = xx >= 0 && xx < W && yy >= 0 && yy < H && ix == ix;      // NaN disparities sample nothing
+        const bool in = xx >= 0 && xx < W && yy >= 0 && yy < H && ix == ix;      // NaN disparities touch no memory
         t.off[k] = in ? yy * W + xx : -1;
         if (in) m = __fadd_rn(m, t.w[k]);
     }
-    t.mask = (m < 0.999f) ? 0.f : 1.f;
-    return t;
+    t.mask = (ix == ix) ? ((m < 0.999f) ? 0.f : 1.f) : ix;     // NaN propagates like in the reference: a diverged
+    return t;                                                  // refinement must surface as a NaN loss, not be zeroed silently
 }
 
 __global__ __launch_bounds__(R2_THREADS) void warp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ disp,
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(R2_THREADS) void warp_fwd_kernel(const float* __res
     const WarpTap t = warp_tap(disp[(size_t)b * HW + i], i % W, i / W, H, W);
     const float* xp = x + (size_t)b * C * HW;
     float* op = out + (size_t)b * C * HW + i;
-    if (t.mask == 0.f) {
-        for (int c = 0; c < C; ++c) op[(size_t)c * HW] = 0.f;
+    if (!(t.mask == 1.f)) {                                     // masked (0) or NaN disparity (NaN): no sampling
+        for (int c = 0; c < C; ++c) op[(size_t)c * HW] = t.mask;
         return;
     }
     for (int c = 0; c < C; ++c) {
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(R2_THREADS) void warp_bwd_kernel(const float* __res
     const int i = blockIdx.x * R2_THREADS + threadIdx.x, b = blockIdx.y;
     if (i >= HW) return;
     const WarpTap t = warp_tap(disp[(size_t)b * HW + i], i % W, i / W, H, W);
-    float gix = 0.f;
-    if (t.mask != 0.f) {
+    float gix = (t.mask == t.mask) ? 0.f : t.mask;           // NaN disparity: NaN disparity gradient, nothing added to gx
+    if (t.mask == 1.f) {
         const float* xp = x + (size_t)b * C * HW;
         float* gxp = gx ? gx + (size_t)b * C * HW : nullptr;
         const float* gp = gout + (size_t)b * C * HW + i;

@@ -335,7 +335,10 @@ def bn_defer_reset_if_stale():
     after a deferral (out of memory, a user hook) never ran its end-of-pass callback and left the counters armed -- the
     safety net would stay off for the rest of the process.  Outside a backward pass nothing can be legitimately
     outstanding, so the state is reset."""
-    if _BN_DEFER["armed"] and torch._C._current_graph_task_id() == -1:
+    if not _BN_DEFER["armed"]:
+        return
+    task_id = getattr(torch._C, "_current_graph_task_id", None)       # (a private accessor: a torch build without it skips the reset
+    if task_id is None or task_id() == -1:                           #  outside-backward check and resets whenever a forward starts)
         _BN_DEFER["outstanding"], _BN_DEFER["armed"] = 0, False
 
 

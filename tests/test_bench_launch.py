@@ -54,6 +54,22 @@ def test_bench_gpus2_spawns_two_gloo_ranks_emulated():
     assert len(out["per_rank"]["ms_per_step"]) == 2 and max(out["per_rank"]["ms_per_step"]) <= out["ms_per_step"] * 1.001
 
 
+def test_bench_acv_train_two_ranks_emulated():
+    """BASELINE.json configs[3]'s exact command form (`bench.py --config acv_train --gpus N`, global batch 16 over 8 GPUs = 2 per
+    rank) end to end on two gloo ranks before hardware sees it: ACVNet train step with a batch of two per
+    rank, batch sharding as trainer_torchrun.py:130-136 (DistributedSampler) does, one flat averaged gradient exchange
+    (:116-121), per-rank times and the exposed all-reduce time in the line."""
+    from tests.emu_util import emu_lib
+    emu_lib()
+    r = _run(["--config", "acv_train", "--gpus", "2", "--batch", "2", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64",
+              "--maxdisp", "64", "--no-cpu-baseline"], {"OMP_NUM_THREADS": "2"}, script=BENCH_EMU)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["config"]["name"] == "acv_train" and out["n_gpus"] == 2 and out["config"]["global_batch"] == 4
+    assert out["config"]["parallelism"] == "dp2" and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["per_rank"]["ms_per_step"]) == 2 and "grad_sync_ms_on_stream" in out["per_rank"]
+
+
 def test_bench_psm_volume_config_emulated():
     r = _run(["--config", "psm_volume", "--steps", "1", "--warmup", "0", "--height", "16", "--width", "64", "--maxdisp", "32",
               "--no-cpu-baseline"], script=BENCH_EMU)

@@ -1,6 +1,7 @@
 """On-device, sync-free accumulation of the toolbox's evaluation metrics.
 
-The reference loops (`evaluation/sceneflow_test.py:26-47`, `evaluation/generalization_eval.py:29-58`) pull four to
+The reference loops (`evaluation/sceneflow_test.py:26-47`, `evaluation/generalization_eval.py:29-58`,
+`evaluation/drivingstereo_weather_test.py:25-49`) pull two to
 seven scalars per image to the host with `.item()`; at GwcNet's inference rate on MI355X that serialises the GPU
 behind the host.  Here every per-image statistic is accumulated in device tensors; `compute()` is the only host
 synchronisation and `all_reduce()` merges the accumulators of a multi-GPU, batch-sharded evaluation (cfg5) with ONE
@@ -92,3 +93,16 @@ class DisparityMetrics:
                "occ": [float(v) / max(float(self.n_occ), 1.0) for v in self.occ_sum],
                "noc": [float(v) / max(float(self.n_noc), 1.0) for v in self.noc_sum]}
         return out
+
+
+def drivingstereo_weather_table(per_split, thresholds=(3, 3, 3, 3)):
+    """The 4 x 2 table of the reference's weather evaluation (`evaluation/drivingstereo_weather_test.py:13-66`): one row
+    [EPE, outliers %] per split (sunny, cloudy, rainy, foggy), the outlier threshold of each row taken from `thresholds`
+    (the reference's `threshlods` argument, default 3 px everywhere) and both columns averaged over the images that have
+    valid pixels (:41-48).  per_split: one DisparityMetrics per split whose `thresholds` contain that split's value."""
+    rows = []
+    for acc, thr in zip(per_split, thresholds):
+        out = acc.compute()
+        k = [float(t) for t in acc.thresholds.tolist()].index(float(thr))
+        rows.append([out["epe_valid_images"], out["all"][k]])
+    return rows

@@ -1,5 +1,6 @@
 """Golden fixture for the evaluation metrics: runs the REFERENCE's own loops
-(`evaluation/sceneflow_test.py:13-59`, `evaluation/generalization_eval.py:13-83`) on synthetic predictions.
+(`evaluation/sceneflow_test.py:13-59`, `evaluation/generalization_eval.py:13-83`,
+`evaluation/drivingstereo_weather_test.py:13-66` with per-split thresholds) on synthetic predictions.
 
   python tests/golden/make_golden_metrics.py        (build container only: needs /root/reference)
 
@@ -77,7 +78,20 @@ KITTI2015_Dataset = _make("KITTI2015_Dataset", 5, 200)
 KITTI2012_Dataset = _make("KITTI2012_Dataset", 4, 300)
 MiddleburyEval3_Dataset = _make("MiddleburyEval3_Dataset", 4, 400)
 ETH3D_Dataset = _make("ETH3D_Dataset", 5, 500)
-SETS = {"sceneflow": (7, 100), "kitti2015": (5, 200), "kitti2012": (4, 300), "middlebury": (4, 400), "eth3d": (5, 500)}
+WEATHER_SPLITS = {"test_half_sunny": (5, 600), "test_half_cloudy": (4, 700), "test_half_rainy": (6, 800), "test_half_foggy": (4, 900)}
+WEATHER_THRESHOLDS = [3, 2, 1, 3]        # per-split outlier thresholds handed to the reference loop (its default is 3 everywhere)
+
+
+class DrivingStereo_Dataset(_SetBase):
+    """`DrivingStereo_Dataset(split=..., training=False)` of evaluation/drivingstereo_weather_test.py:27."""
+
+    def __init__(self, split=None, training=False):
+        self.N, self.SEED = WEATHER_SPLITS[split]
+        super().__init__()
+
+
+SETS = {"sceneflow": (7, 100), "kitti2015": (5, 200), "kitti2012": (4, 300), "middlebury": (4, 400), "eth3d": (5, 500),
+        **WEATHER_SPLITS}
 
 
 class StubModel(torch.nn.Module):
@@ -100,7 +114,7 @@ def _load_reference(fname):
     pkg = types.ModuleType("stereo_toolbox")
     pkg.__path__ = []
     ds = types.ModuleType("stereo_toolbox.datasets")
-    for c in (SceneFlow_Dataset, KITTI2015_Dataset, KITTI2012_Dataset, MiddleburyEval3_Dataset, ETH3D_Dataset):
+    for c in (SceneFlow_Dataset, KITTI2015_Dataset, KITTI2012_Dataset, MiddleburyEval3_Dataset, ETH3D_Dataset, DrivingStereo_Dataset):
         c.__module__ = "stereo_toolbox.datasets"          # picklable for the DataLoader workers
         setattr(ds, c.__name__, c)
     sys.modules.setdefault("stereo_toolbox", pkg)
@@ -125,10 +139,12 @@ def main():
     model = StubModel()
     m_sf = sf.sceneflow_test(model, device="cpu", show_progress=False, maxdisp=MAXDISP)
     m_ge = ge.generalization_eval(model, device="cpu", maxdisp=MAXDISP)
+    ws = _load_reference("drivingstereo_weather_test.py")
+    m_ws = ws.drivingstereo_weather_test(model, device="cpu", threshlods=WEATHER_THRESHOLDS, maxdisp=MAXDISP)
     out = os.path.join(HERE, "metrics.npz")
     np.savez_compressed(out, sceneflow=np.asarray(m_sf, dtype=np.float64), generalization=np.asarray(m_ge, dtype=np.float64),
-                        maxdisp=np.int64(MAXDISP))
-    print("wrote", out, "\n", m_sf, "\n", m_ge)
+                        weather=np.asarray(m_ws, dtype=np.float64), maxdisp=np.int64(MAXDISP))
+    print("wrote", out, "\n", m_sf, "\n", m_ge, "\n", m_ws)
 
 
 if __name__ == "__main__":

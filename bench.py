@@ -202,19 +202,37 @@ class KernelTimer:
         return {"launches": len(recs), "ms_total": ms, "units_total": un}
 
 
-def committed_pmc_traffic(fname):
+def kernel_source_sha(*relpaths):
+    """sha256 over the named kernel sources (relative to stereo_toolbox_amd/csrc) + stx_common.h: what a committed PMC summary is
+    stamped with (tools/gpu/r6_h.sh) and what `committed_pmc_traffic` compares against."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in tuple(relpaths) + ("stx_common.h",):
+        with open(os.path.join(ROOT, "stereo_toolbox_amd", "csrc", rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_pmc_traffic(fname, sources=None):
     """HBM bytes per launch of the dominant kernel from a COMMITTED rocprofv3 PMC summary under profiles/
     (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, KB per dispatch; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be collected inside this process: this is a constant
-    of the profiled session of the same kernel (named in `traffic_source`), not a measurement of this run."""
+    of the profiled session of the same kernel (named in `traffic_source`), not a measurement of this run.
+    Round 6: the summary carries the sha256 of the kernel's source files (`kernel_source_sha` line); a
+    summary whose stamp does not match the sources of THIS tree (the kernel changed since it was profiled) or that has no
+    stamp while `sources` is given yields None -- a stale number is never reported."""
     path = os.path.join(ROOT, "profiles", fname)
     try:
-        vals = {}
+        vals, stamp = {}, None
         with open(path) as f:
             for line in f:
                 parts = line.split()
                 if parts and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
                     vals[parts[0]] = float(line.split("avg=")[1])
+                elif parts and parts[0] == "kernel_source_sha":
+                    stamp = parts[1]
+        if sources is not None and stamp != kernel_source_sha(*sources):
+            return None
         return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
     except Exception:
         return None
@@ -578,7 +596,7 @@ def main(argv=None, platform=None):
             if not ks:
                 return None
             ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e9
-            src = first_existing("r05_pmc_cost_volume_fwd.txt", "r03_pmc_cost_volume_fwd.txt", "r02_pmc_cost_volume_fwd.txt")
+            src = first_existing("r06_pmc_cost_volume_fwd.txt", "r05_pmc_cost_volume_fwd.txt")
             kind = "PSMNet concat volume, fp32 copy / shift / mask" if mode == "volume" else \
                    "fused group-wise correlation + concat volume, NDHWC"
             # the same box's pure write stream of the VOLUME bytes (its output alone): the floor any builder has on this box
@@ -594,10 +612,12 @@ def main(argv=None, platform=None):
                     "same_box_note": "torch zero_() of a buffer of the volume's size on this box in this process (outside the "
                                      "timed region): the time a pure fill of the builder's OUTPUT takes here; boxes of the pool "
                                      "differ (5.0-6.7 TB/s for the builder's 4-KiB-row pattern, profiles/r05_store_stream_callC.txt)",
-                    "traffic": committed_pmc_traffic(src) if std_shape and mode != "volume" else None,
+                    "traffic": committed_pmc_traffic(src, ("cost_volume_mfma.hip",) if src.startswith("r06") else None)
+                    if std_shape and mode != "volume" else None,
                     "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE of the GwcNet_GC "
-                                      "576x960 build, separate passes; a committed-profile constant, not measured by this run "
-                                      "(null for other shapes)",
+                                      "576x960 build, separate passes; a committed-profile constant stamped with the sha256 of the "
+                                      "kernel's source (null when the source changed since, and for other shapes), not measured "
+                                      "by this run",
                     "algorithmic_bytes_per_launch": int(ks["units_total"] / ks["launches"]),
                     "launches_per_step": ks["launches"] // max(1, args.steps),
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}
@@ -607,15 +627,16 @@ def main(argv=None, platform=None):
             if not ks:
                 return None
             ach = ks["units_total"] / (ks["ms_total"] * 1e-3) / 1e12
-            src = first_existing("r05_pmc_conv3d_marchw.txt", "r03_pmc_conv3d_marchw.txt", "r02_pmc_conv3d_marchw.txt")
+            src = first_existing("r06_pmc_conv3d_marchw.txt", "r05_pmc_conv3d_marchw.txt")
             return {"bound": "mfma", "kernel": "conv3d_marchw_kernel (3x3x3 stride-1 Conv3d 32->32 fwd/dgrad, fp32 MFMA, weights "
                                                "resident in LDS)",
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": committed_pmc_traffic(src) if std_shape else None,
+                    "traffic": committed_pmc_traffic(src, ("conv3d.hip",) if src.startswith("r06") else None) if std_shape else None,
                     "traffic_source": f"profiles/{src}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, "
-                                      "576x960 B=1 launch (algorithmic: 424 MB); a committed-profile constant of the same "
-                                      "kernel, not measured by this run (null for other shapes)",
+                                      "576x960 B=1 launch (algorithmic: 424 MB); a committed-profile constant stamped with the "
+                                      "sha256 of the kernel's source (null when the source changed since, and for other shapes), "
+                                      "not measured by this run",
                     "flop_per_launch": int(ks["units_total"] / ks["launches"]),
                     "launches_per_step": ks["launches"] // max(1, args.steps),
                     "avg_launch_ms": round(ks["ms_total"] / ks["launches"], 4)}

@@ -55,6 +55,8 @@ struct CvmArgs {
     int B, H, W, D, G, Cc, mask_left;
     int nd, nt, macros;             // d-chunks per macro-unit, w-tiles per row, B*H*nt
     int by_units;                   // work split at unit granularity (a workgroup's run may begin / end inside a macro-unit)
+    int win;                        // macro-units per WINDOW: the launch walks the volume window by window, every window split over all
+                                    // workgroups (round 6: the chip then writes ONE neighbourhood of every d-plane at a time); >= macros: one window
     unsigned magic_rowq, magic_q;   // ceil(2^32 / (16 Q)), ceil(2^32 / Q)
     unsigned magic_tc;              // ceil(2^32 / table columns)
     int nontemporal;
@@ -104,18 +106,26 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
     float* lds = reinterpret_cast<float*>(smem) + (PF == 2 ? NCW * QPW * 8 * KK * 64 : 0);
     float* tabs = lds + 2 * IMG;
 
-    // The workgroup's run: units [u0, u1) of the launch's macros * nd units in (macro, k) order; whole macro-units unless
-    // by_units (2160 macro-units over 256 workgroups = 8 or 9 each: 6.6 % of the chip idles through the last one; 6480 units
-    // = 25 or 26 each: 2.7 %).  A run that begins inside a macro-unit builds the ring like any first macro-unit and skips
-    // the units in front of its range.
+    // The workgroup's run inside one WINDOW [wm0, wm1) of macro-units: units [u0, u1) of the window's (wm1 - wm0) * nd units in
+    // (macro, k) order; whole macro-units unless by_units (2160 macro-units over 256 workgroups = 8 or 9 each: 6.6 % of the chip
+    // idles through the last one; 6480 units = 25 or 26 each: 2.7 %).  A run that begins inside a macro-unit builds the ring like
+    // any first macro-unit and skips the units in front of its range.  One window (a.win >= a.macros) is the scheme of rounds
+    // 2-5: every workgroup walks its own contiguous piece of the whole volume.
     const long long wg = cvm_xcd_remap(blockIdx.x, gridDim.x);
-    const long long units = (long long)a.macros * nd;
-    const int u0 = __builtin_amdgcn_readfirstlane(a.by_units ? (int)(units * wg / gridDim.x)
-                                                             : nd * (int)((long long)a.macros * wg / gridDim.x));
-    const int u1 = __builtin_amdgcn_readfirstlane(a.by_units ? (int)(units * (wg + 1) / gridDim.x)
-                                                             : nd * (int)((long long)a.macros * (wg + 1) / gridDim.x));
-    const int m0 = u0 / nd, m1 = u1 > u0 ? (u1 + nd - 1) / nd : m0;   // macro-units touched
-    const int kfirst = u0 - m0 * nd, klast = u1 - (m1 - 1) * nd;  // unit range inside the first / last one
+    const int nwin = (a.macros + a.win - 1) / a.win;
+    int m0 = 0, m1 = 0, kfirst = 0, klast = 0;                     // macro-units touched in this window, unit range in the first / last
+    auto set_window = [&](int r) {
+        const int wm0 = r * a.win, wm1 = (wm0 + a.win < a.macros) ? wm0 + a.win : a.macros;
+        const long long wmac = wm1 - wm0, units = wmac * nd;
+        const int u0 = __builtin_amdgcn_readfirstlane(wm0 * nd + (a.by_units ? (int)(units * wg / gridDim.x)
+                                                                             : nd * (int)(wmac * wg / gridDim.x)));
+        const int u1 = __builtin_amdgcn_readfirstlane(wm0 * nd + (a.by_units ? (int)(units * (wg + 1) / gridDim.x)
+                                                                             : nd * (int)(wmac * (wg + 1) / gridDim.x)));
+        m0 = u0 / nd;
+        m1 = u1 > u0 ? (u1 + nd - 1) / nd : m0;
+        kfirst = u0 - m0 * nd;
+        klast = u1 - (m1 - 1) * nd;
+    };
     auto decode = [&](int m, int& b, int& h, int& t) {
         t = m % a.nt;
         const int r = m / a.nt;
@@ -149,6 +159,9 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                                : (ty == 1 ? wl * CS + 4 * (q - GQ) : (wl - dd) * CS + 4 * (q - GQ - CQ));
             goff[sl] = (unsigned)((size_t)dd * dstride + 4 * (size_t)rem);   // < 2^32 floats (checked by the host)
         }
+        for (int r = 0; r < nwin; ++r) {
+        set_window(r);
+        if (r) STX_BARRIER_LDS();                                    // window hand-over: the images / tables start over at index 0
         int ui = 0;
         for (int m = m0; m < m1; ++m) {
             int b, h, t;
@@ -207,6 +220,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                     }
                 }
             }
+        }
         }
         return;
     }
@@ -270,7 +284,7 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
                             const float* __restrict__ Fc = F + (size_t)(g * CPG + 4 * kk) * HW;    // (wave-uniform base)
                             (v ? nR : nA)[j][g][kk] = Fc[p0];
                             if (PF == 2) {
-                                if (dma) STX_GLDS4(Fc, p1, dslot + (((j * 2 + v) * 4 + g) * KK + kk) * 64);   // (wave-uniform branch)
+                                if (dma) STX_GLDS4(stx_uniform_ptr(Fc), p1, dslot + (((j * 2 + v) * 4 + g) * KK + kk) * 64);   // (wave-uniform branch)
                             }
                         }
                 }
@@ -325,23 +339,27 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
         }
     };
 
-    if (m0 < m1) {
-        int b, h, t;
-        decode(m0, b, h, t);
-        const int w0 = t * CVM_T;
-        if (G) {
-            // the ring of the first macro-unit: tiles t-1 .. t-ND straight into Rt[1..ND] (zeros left of the image)
+    // a window's first macro-unit: ring and tiles requested (registers only: issued BEFORE the window barrier, so the loads are in
+    // flight while the store waves flush the previous window's last image)
+    auto prologue = [&]() {
+        if (m0 < m1) {
+            int b, h, t;
+            decode(m0, b, h, t);
+            const int w0 = t * CVM_T;
+            if (G) {
+                // the ring of the first macro-unit: tiles t-1 .. t-ND straight into Rt[1..ND] (zeros left of the image)
 #pragma unroll
-            for (int j = 1; j <= ND; ++j) {
-                bool ok;
-                load_tile(a.Rg, b, h, w0 - CVM_T * j, Rt[j], ok);
-                mask_tile(Rt[j], Rt[j], ok);
+                for (int j = 1; j <= ND; ++j) {
+                    bool ok;
+                    load_tile(a.Rg, b, h, w0 - CVM_T * j, Rt[j], ok);
+                    mask_tile(Rt[j], Rt[j], ok);
+                }
+                // the first macro-unit's own tile (registers) and, PF = 2 with an even index, its partner's (slot)
+                load_next(m0, PF == 2 && (m0 & 1) == 0 && m0 + 1 < m1);
             }
-            // the first macro-unit's own tile (registers) and, PF = 2 with an even index, its partner's (slot)
-            load_next(m0, PF == 2 && (m0 & 1) == 0 && m0 + 1 < m1);
+            if (Cc) load_tables(b, h, w0);
         }
-        if (Cc) load_tables(b, h, w0);
-    }
+    };
 
     int ui = 0;
     // one macro-unit; from_slot (wave-uniform) = its own tiles arrive in the wave's LDS slot instead of nA / nR.  (ONE
@@ -417,7 +435,13 @@ __global__ __launch_bounds__((NCW + NSW) * 64) void cost_volume_fwd_mfma_kernel(
         }
     };
     // the run's first macro-unit always arrives in registers; after it (PF = 2) even ones do, odd ones come from the slot
-    for (int m = m0; m < m1; ++m) macro(m, PF == 2 && m != m0 && (m & 1));
+    for (int r = 0; r < nwin; ++r) {
+        set_window(r);
+        prologue();
+        if (r) STX_BARRIER_LDS();                                    // (matches the store waves' window barrier)
+        ui = 0;
+        for (int m = m0; m < m1; ++m) macro(m, PF == 2 && m != m0 && (m & 1));
+    }
 }
 
 constexpr int CVM_PF_DEFAULT = 1;      // one tile ahead.  STX_CV_PF = 2 selects the line-pair scheme: 11 % fewer bytes fetched (FETCH_SIZE
@@ -470,8 +494,9 @@ int stx_cv_fwd_mfma(const float* Lg, const float* Rg, int Cg, int G, const float
     // measured 0.173 -> 0.141 ms on the GwcNet_GC build
     a.nontemporal = 1;
     a.by_units = stx_tune(STX_TUNE_CV_UNITS) != 0;
+    a.win = stx_tune(STX_TUNE_CV_WIN) > 0 && stx_tune(STX_TUNE_CV_WIN) < a.macros ? stx_tune(STX_TUNE_CV_WIN) : a.macros;
     int pf = stx_tune(STX_TUNE_CV_PF) == 1 || stx_tune(STX_TUNE_CV_PF) == 2 ? stx_tune(STX_TUNE_CV_PF) : CVM_PF_DEFAULT;
-    if (wide) pf = 1;
+    if (wide || a.win < a.macros) pf = 1;                 // (the line-pair scheme's even / odd slot parity is per run: windows take the default)
     // PF = 2 keeps one tile per compute wave in an LDS slot (2 KiB per quad and 4 channels of a group): taken when it fits beside the images
     const int ncw = GQ <= 4 ? 4 : (GQ <= 10 ? 10 : 8), qpw = GQ <= 10 ? 1 : 2;
     const size_t slots = (size_t)ncw * qpw * 8 * (cpg / 4) * 64 * 4;

@@ -157,6 +157,7 @@ enum StxTune {
     STX_TUNE_CV_GRID,        // STX_CV_GRID        0  cost volume forward: workgroups (tests: multi-unit runs)
     STX_TUNE_CV_PF,          // STX_CV_PF          0  cost volume forward: feature prefetch, 0 = default (1: one tile ahead), 2 = cache-line pairs through an LDS-DMA slot
     STX_TUNE_CV_UNITS,       // STX_CV_UNITS       1  cost volume forward: workgroup runs cut at units (0: at whole macro-units)
+    STX_TUNE_CV_WIN,         // STX_CV_WIN         0  cost volume forward: macro-units per window (every window is split over ALL workgroups, the windows walked in order: the chip writes one neighbourhood of each d-plane at a time); 0 = one window
     STX_TUNE_CVB_OLD,        // STX_CVB_OLD        0  cost volume backward: first-generation kernels for every shape
     STX_TUNE_CVB_TEAM,       // STX_CVB_TEAM       0  cost volume backward: row-team schedule (one HBM pass, lock-step)
     STX_TUNE_CVB_GRID,       // STX_CVB_GRID       0  cost volume backward: workgroups (tests)

@@ -36,7 +36,7 @@ namespace {
 struct TuneEntry { const char* name; int value; };
 TuneEntry g_tune[STX_TUNE_COUNT] = {
     {"STX_MARCH_BS", 1}, {"STX_MARCH_EPI", 1}, {"STX_MARCH_ABLATE", 0}, {"STX_WGRAD_ABLATE", 0}, {"STX_WGRAD_MARCH", 3}, {"STX_WGRAD_GRID", 0}, {"STX_CONV_L1_MARCH", 0}, {"STX_CONV_S2_DENSE", 1}, {"STX_CONV_WN", 2},
-    {"STX_CV_OLD", 0}, {"STX_CV_GRID", 0}, {"STX_CV_PF", 0}, {"STX_CV_UNITS", 1}, {"STX_CVB_OLD", 0}, {"STX_CVB_TEAM", 0}, {"STX_CVB_GRID", 0}, {"STX_CVB_NSET", 3},
+    {"STX_CV_OLD", 0}, {"STX_CV_GRID", 0}, {"STX_CV_PF", 0}, {"STX_CV_UNITS", 1}, {"STX_CV_WIN", 0}, {"STX_CVB_OLD", 0}, {"STX_CVB_TEAM", 0}, {"STX_CVB_GRID", 0}, {"STX_CVB_NSET", 3},
     {"STX_SV_BWD_V1", 0}, {"STX_DWCONV_ROLL", 1},
 };
 struct TuneInit {                       // environment read once, when the library is loaded

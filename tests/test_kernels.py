@@ -82,6 +82,29 @@ def test_cost_volume_fwd_launch_variants(be, grid, sched, tune):
         _check_volume(vol, ref, G)
 
 
+@pytest.mark.parametrize("units", [1, 0], ids=["cut_at_units", "cut_at_macros"])
+@pytest.mark.parametrize("win", [1, 2, 5])
+@pytest.mark.parametrize("grid", [2, 3])
+def test_cost_volume_fwd_windows(be, grid, win, units, tune):
+    """STX_CV_WIN (round 6): the launch walks the volume in WINDOWS of `win` macro-units, every window split over all workgroups
+    (window hand-over barrier, ring / tables / image index restarted per window, a window smaller than the grid leaving workgroups
+    without work in it, runs cut inside macro-units).  Same results as the one-window launch, bit for bit."""
+    for case in (CV_CASES if be.name == "emu" else CV_CASES[1:2]):
+        B, Cg, G, Cc, H, W, D, ml = case
+        Lg, Rg, Lc, Rc, ref = _cv_inputs(case)
+        outs = []
+        for w in (0, win):
+            tune("STX_CV_GRID", grid)
+            tune("STX_CV_UNITS", units)
+            tune("STX_CV_WIN", w)
+            vol = be.empty(B, D, H, W, G + 2 * Cc)
+            be.call("stx_cost_volume_fwd", ptr(be.dev(Lg)), ptr(be.dev(Rg)), Cg, G, ptr(be.dev(Lc)), ptr(be.dev(Rc)), Cc, None,
+                    ptr(vol), B, H, W, D, ml)
+            _check_volume(vol, ref, G)
+            outs.append(vol.cpu())
+        assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("variant", ["one_workgroup", "three_workgroups", "two_chunks_in_flight", "four_chunks_in_flight",
                                      "first_generation"])
 def test_cost_volume_bwd_launch_variants(be, variant, tune):

@@ -108,6 +108,11 @@ AB_SETS = [
     ("cost volume fwd: first-generation fallback kernel", "cost_volume_fwd", {"STX_CV_OLD": 1}),
     ("cost volume fwd: cache-line pairs through the LDS-DMA slot", "cost_volume_fwd", {"STX_CV_PF": 2}),
     ("cost volume fwd: runs cut at whole macro-units", "cost_volume_fwd", {"STX_CV_UNITS": 0}),
+    ("cost volume fwd: windows of 256 macro-units", "cost_volume_fwd", {"STX_CV_WIN": 256}),
+    ("cost volume fwd: windows of 384 macro-units", "cost_volume_fwd", {"STX_CV_WIN": 384}),
+    ("cost volume fwd: windows of 512 macro-units", "cost_volume_fwd", {"STX_CV_WIN": 512}),
+    ("cost volume fwd: windows of 720 macro-units", "cost_volume_fwd", {"STX_CV_WIN": 720}),
+    ("cost volume fwd: windows of 1080 macro-units", "cost_volume_fwd", {"STX_CV_WIN": 1080}),
     ("cost volume bwd: first-generation fallback kernel", "cost_volume_bwd", {"STX_CVB_OLD": 1}),
     ("cost volume bwd: team schedule", "cost_volume_bwd", {"STX_CVB_TEAM": 1}),
     ("cost volume bwd: 2 chunk sets in flight", "cost_volume_bwd", {"STX_CVB_NSET": 2}),

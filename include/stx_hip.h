@@ -139,6 +139,20 @@ int stx_conv3d_wgrad_bn(const float* x, const float* gy, const float* z, const f
                         const float* invstd, const float* gamma, const float* sums, float inv_n, int act, float* dz, float* dw,
                         float* workspace, int B, int D, int H, int W, int CF, int CC, void* stream);
 
+/* 3x3 stride-1 Conv2d (padding 1, no bias), channels-last, of the 2-D feature CNN's BasicBlocks with 32 / 64 channels: forward
+ * and data gradient (reference models/GwcNet/gwcnet.py:12-42 `convbn(in, out, 3, 1, pad, 1)` -> nn.Conv2d at 1/2 and 1/4
+ * resolution; PSMNet/submodule.py:57-97; ACVNet/acv.py:15-40).  x [B][H][W][Cin], out [B][H][W][Cout], fp32.
+ * w = the layer's parameter [Co_w][Ci_w][3][3] in channels_last storage = dense [Co_w][3][3][Ci_w], read by the kernel as it is
+ * (no packing step).  dgrad = 0: out = conv(x, w), Cin = Ci_w, Cout = Co_w.  dgrad = 1: the input gradient of that layer,
+ * x = the output gradient, Cin = Co_w, Cout = Ci_w (flipped taps, transposed channels).
+ * stats (may be NULL): [stx_conv2d_stat_rows(groups)][2][Cout] per-workgroup sum / sum of squares of the raw output, the batch
+ *   split into `groups` equal parts (views) with their own rows: rows [g * rows / groups, (g + 1) * rows / groups) belong to part g
+ *   -> stx_bn_finalize_groups.  Shapes: stx_conv2d_supported (Cin 32 or 64, Cout % 16 == 0). */
+int stx_conv2d_supported(int Cin, int Cout);
+long long stx_conv2d_stat_rows(int groups);
+int stx_conv2d_fwd(const float* x, const float* w, float* out, float* stats, int B, int H, int W, int Cin, int Cout, int dgrad,
+                   int groups, void* stream);
+
 /* Classifier tail Conv3d(Cin, 1, k=3, p=1, bias=False) (GwcNet/gwcnet.py:139-153, PSMNet/stackhourglass.py:74-84):
  * N = 1 is not GEMM-shaped, so it gets VALU kernels. w: torch layout [1][Cin][27]; out/residual/gy: [B][D][H][W].
  * Cin % 16 == 0 (wgrad: Cin <= 64). dgrad: gx [B][D][H][W][Cin] = autograd input gradient of the same layer

@@ -56,6 +56,10 @@ SIGNATURES = {
     "stx_conv3d_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_wgrad_bn_supported": [_I, _I, _I, _I, _I, _I],
     "stx_conv3d_wgrad_bn": [_P] * 9 + [_F, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    # conv2d.hip
+    "stx_conv2d_supported": [_I, _I],
+    "stx_conv2d_stat_rows": [_I],
+    "stx_conv2d_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     # conv_c1.hip
     "stx_conv3d_c1_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "stx_conv3d_c1_wgrad_workspace_floats": [_I],

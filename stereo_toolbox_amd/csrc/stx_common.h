@@ -91,6 +91,12 @@ static inline void stx_buf_st1(stx_bufrsrc r, unsigned voff, unsigned soff, floa
     if (off + 4 > r.bytes) abort();
     *reinterpret_cast<float*>(const_cast<char*>(r.base) + off) = v;
 }
+static inline void stx_buf_st4(stx_bufrsrc r, unsigned voff, unsigned soff, float4 v) {
+    if (voff >= STX_BUF_OOB || voff >= r.bytes) return;            // (what the hardware's range check drops)
+    const unsigned long long off = (unsigned long long)voff + soff;
+    if (off + 16 > r.bytes) abort();
+    *reinterpret_cast<float4*>(const_cast<char*>(r.base) + off) = v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t stx_bufrsrc;
 typedef unsigned int stx_u32x4 __attribute__((ext_vector_type(4)));
@@ -106,6 +112,10 @@ __device__ __forceinline__ float stx_buf_ld1(stx_bufrsrc r, unsigned voff, unsig
 }
 __device__ __forceinline__ void stx_buf_st1(stx_bufrsrc r, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void stx_buf_st4(stx_bufrsrc r, unsigned voff, unsigned soff, float4 v) {
+    const stx_u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, (int)voff, (int)soff, 0);
 }
 #endif
 // A pointer the program knows to be wave-uniform, forced into SGPRs (two v_readfirstlane): loads through it become

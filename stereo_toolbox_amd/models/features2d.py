@@ -100,13 +100,26 @@ def cat_features(parts):
     return torch.cat(parts, dim=1)
 
 
+def own_conv2d(x, conv):
+    """Whether this convolution runs on the hand-written 2-D kernel (train mode, fp32, on the device; STX_FEAT2D_CONV=0: MIOpen)."""
+    return (os.environ.get("STX_FEAT2D_CONV", "1") != "0" and x.dtype == torch.float32 and ops.on_device(x)
+            and ops.conv2d_supported(conv) and x.shape[0] % view_groups.current() == 0)
+
+
 def conv_bn_act(x, conv, bn, relu=False, residual=None, second=None):
     """act(BN(conv(x)) [+ residual | + BN2(z2)]): MIOpen convolution (channels-last), then for a train-mode BatchNorm2d one
     statistics pass and one fused normalise / add / ReLU pass, for an eval-mode one (inference) the fused pass alone.  x / residual: NCHW-logical; second = (z2, bn2) with z2 the raw
     output of the other branch's convolution.  Returns an NCHW-logical channels_last tensor."""
     G = view_groups.current()
-    z = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
-    zl = _nhwc(z)
+    part = None
+    if bn.training and own_conv2d(x, conv):
+        # round 6: the 32 / 64-channel 3x3 stride-1 convolutions (39 of the GwcNet extractor's 55) on csrc/conv2d.hip, forward and
+        # data gradient; the kernel's epilogue emits the BatchNorm statistics rows (no stx_bn_stats pass over z)
+        zl, part = ops.Conv2dFn.apply(x, conv.weight, G)
+        z = zl.permute(0, 3, 1, 2)
+    else:
+        z = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+        zl = _nhwc(z)
     if not bn.training:
         if torch.is_grad_enabled() and (z.requires_grad or bn.weight.requires_grad):
             raise ops.StxError("conv_bn_act: eval-mode BatchNorm under autograd has no fused backward -- gate the call "
@@ -119,7 +132,7 @@ def conv_bn_act(x, conv, bn, relu=False, residual=None, second=None):
         else:
             y = ops.bn_apply(zl, sc, sh, None if residual is None else _nhwc(residual), None, None, relu)
         return y.permute(0, 3, 1, 2)
-    st = _bn_state(bn, ops.bn_stats(zl.detach(), G), zl.numel() // zl.shape[-1] // G, steps=G)
+    st = _bn_state(bn, part if part is not None else ops.bn_stats(zl.detach(), G), zl.numel() // zl.shape[-1] // G, steps=G)
     if second is not None:
         z2l = _nhwc(second[0])
         bn2 = second[1]

@@ -775,6 +775,72 @@ def cat_channels(parts):
     return CatChannelsFn.apply(*parts)
 
 
+# --------------------------------------------------------------------------------------- 2-D convolution (feature CNN)
+def conv2d_supported(conv):
+    """Whether an nn.Conv2d is one csrc/conv2d.hip serves in BOTH directions: 3x3, stride 1, padding 1, dilation 1, dense, no
+    bias, 32 or 64 input AND output channels (the data gradient's GEMM-K is the layer's output width)."""
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None and conv.in_channels in (32, 64) and conv.out_channels in (32, 64))
+
+
+def _ohwi(w):
+    """[Co][Ci][3][3] parameter -> dense [Co][3][3][Ci] (a view when the parameter is stored channels_last, as the extractors
+    keep theirs: features2d.channels_last_weights_)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv2d_forward(x, w, dgrad=False, groups=1, want_stats=False):
+    """x dense [B, H, W, Cin]; w the layer's parameter [Co][Ci][3][3].  dgrad=False: conv(x, w) -> [B, H, W, Co]; dgrad=True: x is
+    the output gradient [B, H, W, Co] -> the input gradient [B, H, W, Ci].  want_stats: also the per-workgroup (sum, sum of
+    squares) rows of the raw output, [rows, 2, C] ([groups, rows / groups, 2, C]: per-view statistics) -> bn_finalize."""
+    _chk(x, "x", 4)
+    wo = _ohwi(w)
+    _chk(wo, "weight", 4)
+    B, H, W, Cin = x.shape
+    Co, Ci = w.shape[0], w.shape[1]
+    Kin, Nout = (Co, Ci) if dgrad else (Ci, Co)
+    if Cin != Kin or B % groups:
+        raise StxError(f"conv2d: input {tuple(x.shape)} against weight {tuple(w.shape)} (dgrad={dgrad}, groups={groups})")
+    out = torch.empty(B, H, W, Nout, dtype=torch.float32, device=x.device)
+    part = None
+    if want_stats:
+        rows = int(get_lib().raw("stx_conv2d_stat_rows")(groups))
+        part = torch.empty(rows, 2, Nout, dtype=torch.float32, device=x.device)
+    _call("stx_conv2d_fwd", _p(x), _p(wo), _p(out), _p(part), B, H, W, Kin, Nout, int(dgrad), groups)
+    if part is not None and groups > 1:
+        part = part.view(groups, rows // groups, 2, Nout)
+    return out, part
+
+
+class Conv2dFn(torch.autograd.Function):
+    """z = conv2d(x, w) (3x3, stride 1, padding 1) of the 2-D feature CNN's BasicBlocks on csrc/conv2d.hip: forward and data
+    gradient hand-written, the weight gradient stays MIOpen's (aten.convolution_backward).  x NCHW-logical channels_last;
+    returns z as dense [B, H, W, Co] and the BatchNorm statistics rows of z (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, x, w, groups):
+        xl = x.permute(0, 2, 3, 1)
+        if not xl.is_contiguous():
+            xl = xl.contiguous()
+        z, part = conv2d_forward(xl, w, False, groups, True)
+        ctx.save_for_backward(x, w)
+        ctx.mark_non_differentiable(part)
+        return z, part
+
+    @staticmethod
+    def backward(ctx, gz, _gpart):
+        x, w = ctx.saved_tensors
+        gz = gz.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = conv2d_forward(gz, w, True)[0].permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gz.permute(0, 3, 1, 2), x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1]
+        return gx, gw, None
+
+
 # --------------------------------------------------------------------------------------- batch norm
 def bn_finalize(partials, count, gamma, beta, running_mean, running_var, momentum, eps, groups=1):
     """partials [rows, 2, C] ([groups, rows, 2, C] for groups > 1) -> scale, shift, mean, invstd ([C] each, [groups, C] for

@@ -322,13 +322,9 @@ extern "C" int stx_conv2d_fwd(const float* x, const float* w, float* out, float*
           : conv2d_march_kernel<4, 15>;
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
     }
-    static bool attr64 = false, attr32 = false;                      // (the attribute is set once per kernel)
-    bool& done = Cin == 64 ? attr64 : attr32;
-    if (!done) {
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess)
-            return stx_set_error(STX_ERR_LAUNCH, "conv2d_fwd: %zu B of LDS refused", lds);
-        done = true;
-    }
+    // (set on every launch, like the 3-D kernels: the attribute belongs to the current device's copy of the function)
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess)
+        return stx_set_error(STX_ERR_LAUNCH, "conv2d_fwd: %zu B of LDS refused", lds);
     hipLaunchKernelGGL(k, dim3(grid), dim3(C2_THREADS), lds, (hipStream_t)stream, a);
     return stx_check_launch("conv2d_fwd");
 }

@@ -177,6 +177,21 @@ def run_table(a, only_arg, only_exact=False):
         report("cost_volume_fwd_psm_concat", ms, nbytes=(Lp.numel() * 2 + vol.numel()) * 4)
         del Lg, Rg, vol, g
 
+    if want("conv2d"):
+        # the 2-D feature CNN's 3x3 stride-1 layers on csrc/conv2d.hip (both views batched): forward (with the BatchNorm statistics
+        # epilogue, two views) and data gradient
+        for name, Ci, Co, Hh, Ww in (("conv2d_64_64_quarter", 64, 64, a.H // 4, a.W // 4), ("conv2d_32_32_half", 32, 32, a.H // 2, a.W // 2)):
+            x2 = torch.randn(2, Hh, Ww, Ci, device=dev)
+            w2 = torch.randn(Co, 3, 3, Ci, device=dev) * 0.05
+            o2 = torch.empty(2, Hh, Ww, Co, device=dev)
+            st2 = torch.empty(int(lib.raw("stx_conv2d_stat_rows")(2)), 2, Co, device=dev)
+            fl = 2.0 * 2 * Hh * Ww * Ci * Co * 9
+            ms = timeit(lambda: lib.call("stx_conv2d_fwd", P(x2), P(w2), P(o2), P(st2), 2, Hh, Ww, Ci, Co, 0, 2, stream()), it)
+            report(name + "_fwd", ms, flops=fl)
+            ms = timeit(lambda: lib.call("stx_conv2d_fwd", P(o2), P(w2), P(x2), None, 2, Hh, Ww, Co, Ci, 1, 1, stream()), it)
+            report(name + "_dgrad", ms, flops=fl)
+        del x2, w2, o2, st2
+
     if want("sampled_volume"):
         # CFNet cascade stage at 1/4 resolution: 40 groups x 4 channels + 12 concat channels, 16 hypotheses, 72-channel voxels
         S, G, cpg, Cc, CTp = 16, 40, 4, 12, 72

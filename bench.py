@@ -228,7 +228,8 @@ def committed_pmc_traffic(fname, sources=None):
             for line in f:
                 parts = line.split()
                 if parts and parts[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    vals[parts[0]] = float(line.split("avg=")[1])
+                    # (the FIRST kernel of a pass: kernel_bench times the GwcNet_GC build before the PSMNet concat build)
+                    vals.setdefault(parts[0], float(line.split("avg=")[1]))
                 elif parts and parts[0] == "kernel_source_sha":
                     stamp = parts[1]
         if sources is not None and stamp != kernel_source_sha(*sources):

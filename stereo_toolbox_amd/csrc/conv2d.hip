@@ -15,8 +15,8 @@
 //   * 16-channel output slices (v_mfma_f32_16x16x4_f32, the same 64 FLOP / clk / SIMD as the 32 x 32 x 2 form) instead of 32:
 //     540 tiles x 4 slices = 2160 units over 256 workgroups = 8.44 -> 9 rounds (0.94); with 32-channel slices 4.22 -> 5 (0.84).
 // GEMM view: M = voxels (a wave owns two image rows of 16 columns = two 16-row MFMA tiles), N = 16 output channels,
-// K = 9 taps x Cin.  LDS: halo tile [10][18][Cin + 4] (the +4 makes the lane = (voxel, 4-channel group) operand reads
-// conflict-free), double buffered; weights [tap][Cin / 16][lane][4] in MFMA operand order, gathered by the kernel itself from the
+// K = 9 taps x Cin.  LDS: halo tile [10][18][Cin + 8] (the padding spreads the lane = (voxel, 4-channel group) operand reads over
+// the banks), double buffered; weights [tap][Cin / 16][lane][4] in MFMA operand order, gathered by the kernel itself from the
 // parameter's channels_last storage (forward and flipped / transposed for the data gradient: no packing launches).
 // Exact fp32: every output is one k-ordered fmaf chain of 9 x Cin terms, like the 3-D kernels' accumulators.
 // Optional epilogue: per-channel sum / sum of squares of the raw output for train-mode BatchNorm (one row per workgroup;
@@ -43,9 +43,12 @@ __device__ __forceinline__ f32x4 c2_zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; re
 
 // ABL (profiling only, STX_C2_ABLATE): bit 0 no global loads of the next tile, bit 1 no LDS writes of it, bit 2 no output
 // stores, bit 3 no per-unit barrier (results are wrong with any of them)
-template <int KQ, int ABL = 0>       // Cin = 16 * KQ
+// PAD: floats between two voxels of a halo buffer.  8, not the 3-D kernels' 4: by the counters (profiles/r06_conv2d_lds_pad_callV.txt)
+// the lane = (voxel, 4-channel group) ds_read_b128 of this kernel spends 38 % of its LDS cycles in bank conflicts at 4 and 12, 8 % at 8
+// (SQ_LDS_BANK_CONFLICT 2.91 M -> 0.42 M per launch); the launch time does not move (56.8 -> 57.2 us: the loop is not LDS-bound).
+template <int KQ, int ABL = 0, int PAD = 8>       // Cin = 16 * KQ
 __global__ __launch_bounds__(C2_THREADS) void conv2d_march_kernel(Conv2dArgs a) {
-    constexpr int CIN = 16 * KQ, VS = CIN + 4, F4 = CIN / 4;
+    constexpr int CIN = 16 * KQ, VS = CIN + PAD, F4 = CIN / 4;
     constexpr int WFLOATS = 9 * KQ * 256;                            // floats of one slice's packed weights
     constexpr int NST = (C2_NV * F4 + C2_THREADS - 1) / C2_THREADS;  // staging float4 per thread
     // floats per halo buffer: room for every staging slot of every thread (NST * 256 / F4 = 192 voxels, 180 of them real), so
@@ -313,10 +316,13 @@ extern "C" int stx_conv2d_fwd(const float* x, const float* w, float* out, float*
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nHt = stx_cdiv(H, C2_TH); a.nWt = stx_cdiv(W, C2_TW); a.groups = groups;
     const int grid = conv2d_grid(groups);
-    const size_t lds = ((size_t)9 * Cin * 16 + (size_t)2 * 192 * (Cin + 4) + (size_t)2 * Cout) * 4;   // (192: SLOT of the kernel)
+    static const int pad = getenv("STX_C2_PAD") ? atoi(getenv("STX_C2_PAD")) : 8;            // (profiling only: 4, 8 or 12)
+    const size_t lds = ((size_t)9 * Cin * 16 + (size_t)2 * 192 * (Cin + pad) + (size_t)2 * Cout) * 4;   // (192: SLOT of the kernel)
     void (*k)(Conv2dArgs) = Cin == 64 ? conv2d_march_kernel<4> : conv2d_march_kernel<2>;
+    if (pad == 4) k = Cin == 64 ? conv2d_march_kernel<4, 0, 4> : conv2d_march_kernel<2, 0, 4>;
+    if (pad == 12) k = Cin == 64 ? conv2d_march_kernel<4, 0, 12> : conv2d_march_kernel<2, 0, 12>;
     static const int abl = getenv("STX_C2_ABLATE") ? atoi(getenv("STX_C2_ABLATE")) : 0;      // (profiling only)
-    if (abl && Cin == 64) {
+    if (abl && Cin == 64 && pad == 8) {
         k = abl == 1 ? conv2d_march_kernel<4, 1> : abl == 2 ? conv2d_march_kernel<4, 2> : abl == 3 ? conv2d_march_kernel<4, 3>
           : abl == 4 ? conv2d_march_kernel<4, 4> : abl == 7 ? conv2d_march_kernel<4, 7> : abl == 8 ? conv2d_march_kernel<4, 8>
           : conv2d_march_kernel<4, 15>;

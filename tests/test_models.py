@@ -765,6 +765,10 @@ def test_full_size_eval_parity(tag, parity_log):
     rec = {}
     with torch.no_grad():
         got = m(left.cuda(), right.cuda()).cpu()
+        # same box, same process, second plain run: how much of the distance below is run-to-run noise
+        # (recorded in the parity report next to the flat bars; the hand-written path is bit-reproducible, MIOpen's split-K
+        # forward kernels of the 2-D CNN need not be)
+        rec["same_box_second_run_max_abs"] = (m(left.cuda(), right.cuda()).cpu() - got).abs().max().item()
         if acv:
             ref = O.acvnet_forward(sd, left, right, 192)
         else:

@@ -90,3 +90,33 @@ def test_bench_gpus2_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     out = _json_line(r.stdout)
     assert out["n_gpus"] == 2 and out["value"] > 0
+
+
+def test_committed_pmc_traffic_is_stamped_with_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` constants: bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB of the FIRST kernel
+    of each counter pass in a committed summary; a summary whose sha256 stamp does not match this tree's kernel sources (or has
+    none) yields None instead of a stale number; the committed r06 summaries match the tree."""
+    import bench
+    sha = bench.kernel_source_sha("conv3d.hip")
+    assert len(sha) == 64 and sha != bench.kernel_source_sha("cost_volume_mfma.hip")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    body = ("kernel A\n   FETCH_SIZE                         n=   5 avg=         1000.0\n"
+            "kernel B\n   FETCH_SIZE                         n=   5 avg=            7.0\n"
+            "kernel A\n   WRITE_SIZE                         n=   5 avg=         3000.0\n"
+            "kernel B\n   WRITE_SIZE                         n=   5 avg=            9.0\n")
+    (prof / "stamped.txt").write_text(body + f"kernel_source_sha {sha}\n")
+    (prof / "stale.txt").write_text(body + "kernel_source_sha " + "0" * 64 + "\n")
+    (prof / "unstamped.txt").write_text(body)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    # (kernel_source_sha reads the sources under ROOT: give it the real ones)
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda *rel: sha)
+    assert bench.committed_pmc_traffic("stamped.txt", ("conv3d.hip",)) == int((2 * 1000.0 + 3000.0) * 1024)
+    assert bench.committed_pmc_traffic("stale.txt", ("conv3d.hip",)) is None
+    assert bench.committed_pmc_traffic("unstamped.txt", ("conv3d.hip",)) is None
+    assert bench.committed_pmc_traffic("unstamped.txt") == int(5000.0 * 1024)       # (round-5 files: no stamp asked)
+    assert bench.committed_pmc_traffic("missing.txt", ("conv3d.hip",)) is None
+    monkeypatch.undo()
+    # the summaries committed this round carry the stamps of THIS tree's sources
+    assert bench.committed_pmc_traffic("r06_pmc_conv3d_marchw.txt", ("conv3d.hip",)) is not None
+    assert bench.committed_pmc_traffic("r06_pmc_cost_volume_fwd.txt", ("cost_volume_mfma.hip",)) is not None

@@ -28,8 +28,8 @@ def pytest_collection_modifyitems(config, items):
 
 _FULL_SIZE = ("test_psmnet_config1_eval", "test_cost_volume_full_size_properties", "test_full_size_eval_parity",
               "test_gwcnet_gc_full_size_train_step_parity", "test_acvnet_full_size_train_step_parity")
-_KERNEL_FILES = ("test_capi_symbols.py", "test_kernels.py", "test_f1ops.py", "test_hygiene.py", "test_igev_preprocess.py",
-                 "test_metrics.py")
+_KERNEL_FILES = ("test_capi_symbols.py", "test_kernels.py", "test_conv2d.py", "test_f1ops.py", "test_hygiene.py",
+                 "test_igev_preprocess.py", "test_metrics.py")
 _LAST_FILES = ("test_torch_ext.py",)       # the torch.utils.cpp_extension door (8 of the entry points): after everything else, so a
                                            # build-system problem there can never again keep a model test from running
 _TOY_TRAIN = ("train_grads", "frozen_attention_train", "_train_")          # incl. the isolated (deterministic) hand-written-path tests

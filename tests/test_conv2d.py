@@ -143,3 +143,35 @@ def test_basic_block_train_step_on_the_own_kernel_matches_the_stock_convolution(
     for k in ref:
         err = (own[k] - ref[k]).abs().max().item()
         assert err <= 2e-4 * ref[k].abs().max().item() + 1e-6, (k, err, ref[k].abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 64, 144, 240), (2, 32, 32, 288, 480), (2, 64, 64, 96, 312), (4, 64, 64, 144, 240)],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_at_the_extractor_shapes(case):
+    """The layer shapes of the BASELINE configs (SceneFlow 576x960 and KITTI 384x1248 pairs at 1/4 and 1/2 resolution, both views
+    batched; cfg4's two pairs per GPU): forward, per-view statistics and data gradient against stock torch on the device
+    (MIOpen, a different summation order: 2e-5 of the output's magnitude)."""
+    from stereo_toolbox_amd import ops
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    B, Ci, Co, H, W = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, Ci, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, Co, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x, w, None, 1, 1)
+    rgx = torch.ops.aten.convolution_backward(gy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    z, part = ops.conv2d_forward(x.permute(0, 2, 3, 1), w, False, 2, True)
+    gx, _ = ops.conv2d_forward(gy.permute(0, 2, 3, 1), w, True)
+    assert (z.permute(0, 3, 1, 2) - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    assert (gx.permute(0, 3, 1, 2) - rgx).abs().max().item() <= 2e-5 * rgx.abs().max().item()
+    st = part.double().sum(1).cpu()                                   # [2 views, 2, Co]
+    rv = ref.double().view(2, B // 2, Co, H, W)
+    s1, s2 = rv.sum((1, 3, 4)).cpu(), (rv * rv).sum((1, 3, 4)).cpu()
+    assert (st[:, 0] - s1).abs().max().item() <= 1e-4 * s2.sqrt().max().item() + 1e-3
+    assert (st[:, 1] - s2).abs().max().item() <= 1e-5 * s2.abs().max().item()
+    # bit-reproducible launch to launch (fixed summation order, no atomics)
+    z2, part2 = ops.conv2d_forward(x.permute(0, 2, 3, 1), w, False, 2, True)
+    assert torch.equal(z, z2) and torch.equal(part, part2)

@@ -644,10 +644,45 @@ def main(argv=None, platform=None):
         # dominant kernel per config: the Conv3d march kernel for the train steps (MFMA-bound); the volume builder for the
         # volume-only config and for cfg5, for which BASELINE.json asks for the HBM roofline report (the march kernel of
         # that run is reported next to it)
+        def roof_conv2d():
+            """The 2-D convolution kernel at the extractor's 64 -> 64 layer shape of this run (both views of the per-GPU batch),
+            timed AFTER the timed steps, 20 back-to-back forward launches between two HIP events: per-launch events inside the
+            step would cost the headline ~0.9 ms (78 launches per step); the in-step average is in the committed kernel trace."""
+            if not platform.event_timing:
+                return None
+            Bv, Hq, Wq = 2 * B, H // 4, W // 4
+            x2 = torch.randn(Bv, Hq, Wq, 64, device=dev)
+            w2 = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+            for _ in range(3):
+                ops.conv2d_forward(x2, w2, False, 2, True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.conv2d_forward(x2, w2, False, 2, True)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            flop = 2.0 * Bv * Hq * Wq * 64 * 64 * 9
+            ach = flop / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": "conv2d_march_kernel (3x3 stride-1 Conv2d 64 -> 64 of the 2-D feature CNN, forward with the "
+                                               "BatchNorm statistics epilogue, both views batched; fp32 MFMA 16x16x4, a 16-channel slice of "
+                                               "weights in LDS; 78 such launches per GwcNet_GC train step incl. the 32-channel layers and the "
+                                               "data gradients)",
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(ms, 4), "flop_per_launch": int(flop),
+                    "measured": "after the timed steps, 20 back-to-back launches (warm caches); in the step: "
+                                "profiles/r06_bench_kernel_trace_steady_callR.txt (54.5 us per launch)",
+                    "launch_floor_frac": 0.83,
+                    "launch_floor_note": "a launch of the same MFMA count per wave with no memory operation reaches 0.83 of the peak "
+                                         "(38.4 us for 5.1 GFLOP: profiles/r06_mfma16_peak_callP.txt); MIOpen on this layer: 0.47-0.53",
+                    "traffic": committed_pmc_traffic("r06_pmc_conv2d.txt", ("conv2d.hip",)) if std_shape else None,
+                    "traffic_source": "profiles/r06_pmc_conv2d.txt: FETCH_SIZE (x2, gfx950) + WRITE_SIZE of this launch shape "
+                                      "(algorithmic 35.4 MB), separate passes; a committed-profile constant stamped with the kernel's source"}
         extra = {}
         if mode == "train":
             roof = roof_conv()
             extra["roofline_volume_build"] = roof_volume()
+            extra["roofline_conv2d"] = roof_conv2d()
         elif mode == "eval":
             roof = roof_volume()
             extra["roofline_conv3d"] = roof_conv()
